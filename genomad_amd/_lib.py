@@ -1,0 +1,104 @@
+"""ctypes binding of libgenomad_nn_hip.so (include/genomad_nn.h).
+
+There is no CPU fallback: if the shared library is missing, or no gfx950 device is
+visible, the product path raises.  Loading the library itself needs no GPU (used by
+the CPU test-suite to check the exported symbols).
+"""
+import ctypes as C
+import os
+from pathlib import Path
+
+_HERE = Path(__file__).resolve().parent
+LIB_PATH = Path(os.environ.get("GENOMAD_AMD_LIB", _HERE / "csrc" / "libgenomad_nn_hip.so"))
+
+WINDOW, TOKENS, DEPTH, CH = 6000, 5997, 257, 128
+PATCHES, PATCH_SIZE, POOLED, FEAT, HIDDEN, CLASSES = 2100, 4, 749, 256, 512, 3
+
+PREC_F32, PREC_BF16X3, PREC_BF16 = 0, 1, 2
+PRECISIONS = {"f32": PREC_F32, "bf16x3": PREC_BF16X3, "bf16": PREC_BF16}
+OH_U8, OH_BF16, OH_F32 = 0, 1, 2
+K_FUSED, K_BACKEND, K_ENCODER, K_F32_FRONT = 0, 1, 2, 3
+
+_f32p = C.POINTER(C.c_float)
+_i32p = C.POINTER(C.c_int32)
+
+
+class IglooWeights(C.Structure):
+    _fields_ = [("patches", _i32p), ("w_mult", _f32p), ("w_summer", _f32p), ("w_bias", _f32p),
+                ("w_qk", _f32p), ("w_v", _f32p)]
+
+
+class DenseBN(C.Structure):
+    _fields_ = [("kernel", _f32p), ("bias", _f32p), ("gamma", _f32p), ("beta", _f32p),
+                ("mean", _f32p), ("var", _f32p)]
+
+
+class Weights(C.Structure):
+    _fields_ = [("conv1_kernel", _f32p), ("conv1_bias", _f32p), ("conv2_kernel", _f32p),
+                ("conv2_bias", _f32p), ("conv3_kernel", _f32p), ("conv3_bias", _f32p),
+                ("igloo_a", IglooWeights), ("igloo_b", IglooWeights), ("enc", DenseBN),
+                ("head", DenseBN), ("out_kernel", _f32p), ("out_bias", _f32p)]
+
+
+class Taps(C.Structure):
+    _fields_ = [(k, _f32p) for k in ("x1", "x2", "x3", "m_a", "m_b", "yp_a", "yp_b",
+                                     "alpha_a", "alpha_b", "feat")]
+
+
+# name -> (restype, argtypes); every entry is declared in include/genomad_nn.h
+_vp, _i64, _int, _sz, _u64 = C.c_void_p, C.c_int64, C.c_int, C.c_size_t, C.c_uint64
+SIGNATURES = {
+    "gnn_last_error": (C.c_char_p, []),
+    "gnn_version": (_int, []),
+    "gnn_device_count": (_int, [C.POINTER(_int)]),
+    "gnn_create": (_int, [_int, C.POINTER(_vp)]),
+    "gnn_destroy": (_int, [_vp]),
+    "gnn_sync": (_int, [_vp]),
+    "gnn_device_info": (_int, [_vp, C.c_char_p, _sz, C.POINTER(_int), C.POINTER(_i64)]),
+    "gnn_load_weights": (_int, [_vp, C.POINTER(Weights)]),
+    "gnn_dev_alloc": (_int, [_vp, _sz, C.POINTER(_vp)]),
+    "gnn_dev_free": (_int, [_vp, _vp]),
+    "gnn_memcpy_h2d": (_int, [_vp, _vp, _vp, _sz]),
+    "gnn_memcpy_d2h": (_int, [_vp, _vp, _vp, _sz]),
+    "gnn_tokenize": (_int, [_vp, _vp, _i64, _vp]),
+    "gnn_tokenize_dev": (_int, [_vp, _vp, _i64, _vp]),
+    "gnn_onehot_dev": (_int, [_vp, _vp, _i64, _int, _vp]),
+    "gnn_classify": (_int, [_vp, _vp, _i64, _int, _vp]),
+    "gnn_classify_dev": (_int, [_vp, _vp, _i64, _int, _vp]),
+    "gnn_segment_mean": (_int, [_vp, _vp, _vp, _i64, _i64, _vp]),
+    "gnn_debug_forward": (_int, [_vp, _vp, _i64, _int, _vp, C.POINTER(Taps)]),
+    "gnn_synth_windows_dev": (_int, [_vp, _u64, _i64, _i64, _vp]),
+    "gnn_profile_enable": (_int, [_vp, _int]),
+    "gnn_profile_reset": (_int, [_vp]),
+    "gnn_profile_get": (_int, [_vp, _int, C.POINTER(C.c_double), C.POINTER(_i64)]),
+    "gnn_set_chunk": (_int, [_vp, _i64]),
+}
+
+_lib = None
+
+
+class GnnError(RuntimeError):
+    pass
+
+
+def load():
+    """dlopen the C-ABI library and attach the prototypes.  Raises if it was not built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not LIB_PATH.is_file():
+        raise GnnError(
+            f"{LIB_PATH} not found: build it with genomad_amd/csrc/build.sh (or "
+            "python -c 'import __graft_entry__ as g; g.build()').  There is no CPU fallback.")
+    lib = C.CDLL(str(LIB_PATH))
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)
+        fn.restype, fn.argtypes = res, args
+    _lib = lib
+    return lib
+
+
+def check(rc: int):
+    if rc != 0:
+        msg = load().gnn_last_error()
+        raise GnnError(f"libgenomad_nn_hip error {rc}: {msg.decode() if msg else '?'}")

@@ -1,0 +1,568 @@
+// Host side of the C ABI declared in include/genomad_nn.h.
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+
+#include "gnn_common.h"
+
+namespace gnn {
+
+static thread_local std::string g_last_error;
+void set_error(const std::string& msg) { g_last_error = msg; }
+
+struct ProfScope {
+    gnn_ctx* ctx;
+    int id;
+    hipEvent_t a = nullptr, b = nullptr;
+    ProfScope(gnn_ctx* c, int kid) : ctx(c), id(kid) {
+        if (!ctx->profile) return;
+        auto take = [&]() {
+            hipEvent_t e = nullptr;
+            if (!ctx->event_pool.empty()) {
+                e = ctx->event_pool.back();
+                ctx->event_pool.pop_back();
+            } else if (hipEventCreate(&e) != hipSuccess) {
+                e = nullptr;
+            }
+            return e;
+        };
+        a = take();
+        b = take();
+        if (a) (void)hipEventRecord(a, ctx->stream);
+    }
+    ~ProfScope() {
+        if (!ctx->profile || !a || !b) return;
+        (void)hipEventRecord(b, ctx->stream);
+        ctx->prof[id].pending.emplace_back(a, b);
+    }
+};
+
+template <typename Tp>
+static int upload(gnn_ctx* ctx, const Tp* host, size_t count, Tp** dev) {
+    void* p = nullptr;
+    GNN_HIP(hipMalloc(&p, count * sizeof(Tp)));
+    ctx->owned.push_back(p);
+    GNN_HIP(hipMemcpy(p, host, count * sizeof(Tp), hipMemcpyHostToDevice));
+    *dev = static_cast<Tp*>(p);
+    return GNN_OK;
+}
+
+static int dev_buffer(gnn_ctx* ctx, size_t bytes, void** out) {
+    void* p = nullptr;
+    hipError_t e = hipMalloc(&p, bytes);
+    if (e != hipSuccess) {
+        set_error("hipMalloc of " + std::to_string(bytes) + " bytes failed: " + hipGetErrorString(e));
+        return GNN_ERR_NOMEM;
+    }
+    *out = p;
+    return GNN_OK;
+}
+
+static void free_ws(Workspace& ws) {
+    auto f = [](auto*& p) {
+        if (p) (void)hipFree(p);
+        p = nullptr;
+    };
+    f(ws.tokens);
+    f(ws.x[0]);
+    f(ws.x[1]);
+    f(ws.x[2]);
+    f(ws.mp);
+    f(ws.yp);
+    f(ws.logits);
+    f(ws.alpha);
+    f(ws.feat);
+    ws.chunk = 0;
+    ws.x_chunk = 0;
+}
+
+// Make sure the workspace holds `chunk` windows (and the f32 activation buffers `x_chunk`).
+static int ensure_ws(gnn_ctx* ctx, int64_t chunk, int64_t x_chunk) {
+    Workspace& ws = ctx->ws;
+    if (ws.chunk < chunk) {
+        GNN_HIP(hipStreamSynchronize(ctx->stream));
+        auto re = [&](auto*& p, size_t bytes) -> int {
+            if (p) (void)hipFree(p);
+            p = nullptr;
+            void* q = nullptr;
+            int rc = dev_buffer(ctx, bytes, &q);
+            p = static_cast<std::remove_reference_t<decltype(p)>>(q);
+            return rc;
+        };
+        int rc;
+        if ((rc = re(ws.mp, (size_t)chunk * 2 * NPAIR * sizeof(float)))) return rc;
+        if ((rc = re(ws.yp, (size_t)chunk * 2 * POOLED * C * sizeof(float)))) return rc;
+        if ((rc = re(ws.logits, (size_t)chunk * 2 * POOLED * sizeof(float)))) return rc;
+        if ((rc = re(ws.alpha, (size_t)chunk * 2 * POOLED * sizeof(float)))) return rc;
+        if ((rc = re(ws.feat, (size_t)chunk * FEAT * sizeof(float)))) return rc;
+        ws.chunk = chunk;
+    }
+    if (ws.x_chunk < x_chunk) {
+        GNN_HIP(hipStreamSynchronize(ctx->stream));
+        for (int i = 0; i < 3; ++i) {
+            if (ws.x[i]) (void)hipFree(ws.x[i]);
+            ws.x[i] = nullptr;
+            void* q = nullptr;
+            int rc = dev_buffer(ctx, (size_t)x_chunk * T * C * sizeof(float), &q);
+            if (rc) return rc;
+            ws.x[i] = static_cast<float*>(q);
+        }
+        if (ws.tokens) (void)hipFree(ws.tokens);
+        void* q = nullptr;
+        int rc = dev_buffer(ctx, (size_t)x_chunk * T * sizeof(uint16_t), &q);
+        if (rc) return rc;
+        ws.tokens = static_cast<uint16_t*>(q);
+        ws.x_chunk = x_chunk;
+    }
+    return GNN_OK;
+}
+
+static int check_ctx(gnn_ctx* ctx) {
+    if (!ctx) {
+        set_error("ctx is NULL");
+        return GNN_ERR_ARG;
+    }
+    GNN_HIP(hipSetDevice(ctx->device));
+    return GNN_OK;
+}
+
+// One pass of the hot path over n windows whose bases are on the device.
+static int classify_chunks(gnn_ctx* ctx, const uint8_t* bases_dev, int64_t n, int precision,
+                           float* scores_dev) {
+    if (!ctx->has_weights) {
+        set_error("gnn_load_weights has not been called");
+        return GNN_ERR_STATE;
+    }
+    if (precision != GNN_PREC_F32 && precision != GNN_PREC_BF16X3 && precision != GNN_PREC_BF16) {
+        set_error("unknown precision " + std::to_string(precision));
+        return GNN_ERR_ARG;
+    }
+    const bool f32 = precision == GNN_PREC_F32;
+    const int64_t chunk = std::min<int64_t>(f32 ? ctx->chunk_f32 : ctx->chunk_fused, std::max<int64_t>(n, 1));
+    int rc = ensure_ws(ctx, chunk, f32 ? chunk : 0);
+    if (rc) return rc;
+    for (int64_t a = 0; a < n; a += chunk) {
+        const int64_t m = std::min(chunk, n - a);
+        const uint8_t* b = bases_dev + a * W;
+        if (f32) {
+            ProfScope ps(ctx, GNN_K_F32_FRONT);
+            if ((rc = launch_front_f32(ctx, b, m))) return rc;
+        } else {
+            ProfScope ps(ctx, GNN_K_FUSED);
+            if ((rc = launch_front_fused(ctx, b, m, precision))) return rc;
+        }
+        {
+            ProfScope ps(ctx, GNN_K_BACKEND);
+            if ((rc = launch_backend(ctx, m, scores_dev + a * GNN_CLASSES))) return rc;
+        }
+    }
+    return GNN_OK;
+}
+
+}  // namespace gnn
+
+using namespace gnn;
+
+extern "C" {
+
+const char* gnn_last_error(void) { return g_last_error.c_str(); }
+
+int gnn_version(void) { return 100; }
+
+int gnn_device_count(int* count) {
+    if (!count) {
+        set_error("count is NULL");
+        return GNN_ERR_ARG;
+    }
+    GNN_HIP(hipGetDeviceCount(count));
+    return GNN_OK;
+}
+
+int gnn_create(int device, gnn_ctx** out) {
+    if (!out) {
+        set_error("out is NULL");
+        return GNN_ERR_ARG;
+    }
+    *out = nullptr;
+    int count = 0;
+    GNN_HIP(hipGetDeviceCount(&count));
+    if (device < 0 || device >= count) {
+        set_error("device " + std::to_string(device) + " out of range (" + std::to_string(count) + " visible)");
+        return GNN_ERR_ARG;
+    }
+    GNN_HIP(hipSetDevice(device));
+    hipDeviceProp_t prop;
+    GNN_HIP(hipGetDeviceProperties(&prop, device));
+    if (std::string(prop.gcnArchName).rfind("gfx950", 0) != 0) {
+        set_error(std::string("this library is built for gfx950 only; device is ") + prop.gcnArchName);
+        return GNN_ERR_HIP;
+    }
+    gnn_ctx* ctx = new gnn_ctx();
+    ctx->device = device;
+    ctx->cu_count = prop.multiProcessorCount;
+    hipError_t e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking);
+    if (e != hipSuccess) {
+        set_error(std::string("hipStreamCreate failed: ") + hipGetErrorString(e));
+        delete ctx;
+        return GNN_ERR_HIP;
+    }
+    *out = ctx;
+    return GNN_OK;
+}
+
+int gnn_destroy(gnn_ctx* ctx) {
+    if (!ctx) return GNN_OK;
+    (void)hipSetDevice(ctx->device);
+    (void)hipStreamSynchronize(ctx->stream);
+    free_ws(ctx->ws);
+    for (void* p : ctx->owned) (void)hipFree(p);
+    for (auto& s : ctx->prof)
+        for (auto& pr : s.pending) {
+            (void)hipEventDestroy(pr.first);
+            (void)hipEventDestroy(pr.second);
+        }
+    for (hipEvent_t e : ctx->event_pool) (void)hipEventDestroy(e);
+    (void)hipStreamDestroy(ctx->stream);
+    delete ctx;
+    return GNN_OK;
+}
+
+int gnn_sync(gnn_ctx* ctx) {
+    int rc = check_ctx(ctx);
+    if (rc) return rc;
+    GNN_HIP(hipStreamSynchronize(ctx->stream));
+    return GNN_OK;
+}
+
+int gnn_device_info(gnn_ctx* ctx, char* name, size_t name_len, int* cus, int64_t* hbm_bytes) {
+    int rc = check_ctx(ctx);
+    if (rc) return rc;
+    hipDeviceProp_t prop;
+    GNN_HIP(hipGetDeviceProperties(&prop, ctx->device));
+    if (name && name_len) {
+        std::string s = std::string(prop.name) + " (" + prop.gcnArchName + ")";
+        std::strncpy(name, s.c_str(), name_len - 1);
+        name[name_len - 1] = 0;
+    }
+    if (cus) *cus = prop.multiProcessorCount;
+    if (hbm_bytes) *hbm_bytes = (int64_t)prop.totalGlobalMem;
+    return GNN_OK;
+}
+
+int gnn_set_chunk(gnn_ctx* ctx, int64_t windows_per_chunk) {
+    if (!ctx || windows_per_chunk < 1) {
+        set_error("bad chunk");
+        return GNN_ERR_ARG;
+    }
+    ctx->chunk_fused = windows_per_chunk;
+    return GNN_OK;
+}
+
+int gnn_load_weights(gnn_ctx* ctx, const gnn_weights* w) {
+    int rc = check_ctx(ctx);
+    if (rc) return rc;
+    if (!w) {
+        set_error("weights is NULL");
+        return GNN_ERR_ARG;
+    }
+    const void* req[] = {w->conv1_kernel, w->conv1_bias, w->conv2_kernel, w->conv2_bias, w->conv3_kernel,
+                         w->conv3_bias,   w->out_kernel, w->out_bias,     w->enc.kernel,  w->enc.bias,
+                         w->enc.gamma,    w->enc.beta,   w->enc.mean,     w->enc.var,     w->head.kernel,
+                         w->head.bias,    w->head.gamma, w->head.beta,    w->head.mean,   w->head.var};
+    for (const void* p : req)
+        if (!p) {
+            set_error("a weight pointer is NULL");
+            return GNN_ERR_ARG;
+        }
+    if (ctx->has_weights) {
+        set_error("weights already loaded into this ctx (create a new ctx)");
+        return GNN_ERR_STATE;
+    }
+    DeviceWeights& d = ctx->w;
+    if ((rc = upload(ctx, w->conv1_kernel, (size_t)KS * GNN_DEPTH * C, &d.conv1_k))) return rc;
+    if ((rc = upload(ctx, w->conv1_bias, (size_t)C, &d.conv1_b))) return rc;
+    const float* ck[2] = {w->conv2_kernel, w->conv3_kernel};
+    const float* cb[2] = {w->conv2_bias, w->conv3_bias};
+    for (int i = 0; i < 2; ++i) {
+        if ((rc = upload(ctx, ck[i], (size_t)KS * C * C, &d.conv_k[i]))) return rc;
+        if ((rc = upload(ctx, cb[i], (size_t)C, &d.conv_b[i]))) return rc;
+    }
+    const gnn_igloo_weights* ig[2] = {&w->igloo_a, &w->igloo_b};
+    std::vector<float> weff[2];
+    for (int h = 0; h < 2; ++h) {
+        const gnn_igloo_weights* g = ig[h];
+        if (!g->patches || !g->w_mult || !g->w_summer || !g->w_bias || !g->w_qk || !g->w_v) {
+            set_error("an IGLOO weight pointer is NULL");
+            return GNN_ERR_ARG;
+        }
+        // W_eff[p,j,c] = w_mult[0,p,j,c] * w_summer[0, j*128+c, 0]  (igloo.py:195-204 folded)
+        weff[h].resize((size_t)NPAIR * C);
+        std::vector<int32_t> pos(NPAIR);
+        for (int p = 0; p < NP; ++p)
+            for (int j = 0; j < PS; ++j) {
+                const int32_t t = g->patches[p * PS + j];
+                if (t < 0 || t >= T) {
+                    set_error("patch index out of range [0,5997)");
+                    return GNN_ERR_WEIGHTS;
+                }
+                pos[p * PS + j] = t;
+                for (int c = 0; c < C; ++c)
+                    weff[h][((size_t)p * PS + j) * C + c] =
+                        g->w_mult[((size_t)p * PS + j) * C + c] * g->w_summer[j * C + c];
+            }
+        if ((rc = upload(ctx, weff[h].data(), weff[h].size(), &d.weff[h]))) return rc;
+        if ((rc = upload(ctx, pos.data(), pos.size(), &d.pair_pos[h]))) return rc;
+        if ((rc = upload(ctx, g->w_bias, (size_t)NP, &d.w_bias[h]))) return rc;
+        if ((rc = upload(ctx, g->w_qk, (size_t)NP * POOLED, &d.w_qk[h]))) return rc;
+        if ((rc = upload(ctx, g->w_v, (size_t)C * C, &d.w_v[h]))) return rc;
+    }
+    // Fold BatchNormalization (inference statistics) into the preceding Dense (model.py:28-30, 40-42):
+    // y = gamma * (x@K + b - mean) / sqrt(var + eps) + beta = x@(K*s) + ((b - mean)*s + beta)
+    auto fold = [&](const gnn_dense_bn& l, int in, float** dk, float** db) -> int {
+        std::vector<float> k((size_t)in * HID), b(HID);
+        for (int o = 0; o < HID; ++o) {
+            const float s = l.gamma[o] / std::sqrt(l.var[o] + BN_EPS);
+            b[o] = (l.bias[o] - l.mean[o]) * s + l.beta[o];
+            for (int i = 0; i < in; ++i) k[(size_t)i * HID + o] = l.kernel[(size_t)i * HID + o] * s;
+        }
+        int r = upload(ctx, k.data(), k.size(), dk);
+        if (r) return r;
+        return upload(ctx, b.data(), b.size(), db);
+    };
+    if ((rc = fold(w->enc, FEAT, &d.d1_k, &d.d1_b))) return rc;
+    if ((rc = fold(w->head, HID, &d.d2_k, &d.d2_b))) return rc;
+    if ((rc = upload(ctx, w->out_kernel, (size_t)HID * GNN_CLASSES, &d.d3_k))) return rc;
+    if ((rc = upload(ctx, w->out_bias, (size_t)GNN_CLASSES, &d.d3_b))) return rc;
+    if ((rc = pack_fused_weights(ctx, w, weff))) return rc;
+    ctx->has_weights = true;
+    return GNN_OK;
+}
+
+int gnn_dev_alloc(gnn_ctx* ctx, size_t bytes, void** dev_ptr) {
+    int rc = check_ctx(ctx);
+    if (rc) return rc;
+    if (!dev_ptr) {
+        set_error("dev_ptr is NULL");
+        return GNN_ERR_ARG;
+    }
+    return dev_buffer(ctx, bytes ? bytes : 1, dev_ptr);
+}
+
+int gnn_dev_free(gnn_ctx* ctx, void* dev_ptr) {
+    int rc = check_ctx(ctx);
+    if (rc) return rc;
+    GNN_HIP(hipStreamSynchronize(ctx->stream));
+    if (dev_ptr) GNN_HIP(hipFree(dev_ptr));
+    return GNN_OK;
+}
+
+int gnn_memcpy_h2d(gnn_ctx* ctx, void* dst_dev, const void* src_host, size_t bytes) {
+    int rc = check_ctx(ctx);
+    if (rc) return rc;
+    GNN_HIP(hipMemcpyAsync(dst_dev, src_host, bytes, hipMemcpyHostToDevice, ctx->stream));
+    GNN_HIP(hipStreamSynchronize(ctx->stream));
+    return GNN_OK;
+}
+
+int gnn_memcpy_d2h(gnn_ctx* ctx, void* dst_host, const void* src_dev, size_t bytes) {
+    int rc = check_ctx(ctx);
+    if (rc) return rc;
+    GNN_HIP(hipMemcpyAsync(dst_host, src_dev, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    GNN_HIP(hipStreamSynchronize(ctx->stream));
+    return GNN_OK;
+}
+
+int gnn_tokenize_dev(gnn_ctx* ctx, const uint8_t* bases_dev, int64_t n, uint16_t* tokens_dev) {
+    int rc = check_ctx(ctx);
+    if (rc) return rc;
+    if (n < 0 || (n > 0 && (!bases_dev || !tokens_dev))) {
+        set_error("bad argument to gnn_tokenize_dev");
+        return GNN_ERR_ARG;
+    }
+    if (n == 0) return GNN_OK;
+    return launch_tokenize(ctx, bases_dev, n, tokens_dev);
+}
+
+int gnn_tokenize(gnn_ctx* ctx, const uint8_t* bases_host, int64_t n, uint16_t* tokens_host) {
+    int rc = check_ctx(ctx);
+    if (rc) return rc;
+    if (n < 0 || (n > 0 && (!bases_host || !tokens_host))) {
+        set_error("bad argument to gnn_tokenize");
+        return GNN_ERR_ARG;
+    }
+    if (n == 0) return GNN_OK;
+    void *b = nullptr, *t = nullptr;
+    if ((rc = dev_buffer(ctx, (size_t)n * W, &b))) return rc;
+    if ((rc = dev_buffer(ctx, (size_t)n * T * sizeof(uint16_t), &t))) {
+        (void)hipFree(b);
+        return rc;
+    }
+    rc = gnn_memcpy_h2d(ctx, b, bases_host, (size_t)n * W);
+    if (!rc) rc = launch_tokenize(ctx, (const uint8_t*)b, n, (uint16_t*)t);
+    if (!rc) rc = gnn_memcpy_d2h(ctx, tokens_host, t, (size_t)n * T * sizeof(uint16_t));
+    (void)hipFree(b);
+    (void)hipFree(t);
+    return rc;
+}
+
+int gnn_onehot_dev(gnn_ctx* ctx, const uint8_t* bases_dev, int64_t n, int dtype, void* out) {
+    int rc = check_ctx(ctx);
+    if (rc) return rc;
+    if (n < 0 || (n > 0 && (!bases_dev || !out)) || dtype < GNN_OH_U8 || dtype > GNN_OH_F32) {
+        set_error("bad argument to gnn_onehot_dev");
+        return GNN_ERR_ARG;
+    }
+    if (n == 0) return GNN_OK;
+    ProfScope ps(ctx, GNN_K_ENCODER);
+    return launch_onehot(ctx, bases_dev, n, dtype, out);
+}
+
+int gnn_synth_windows_dev(gnn_ctx* ctx, uint64_t seed, int64_t first, int64_t n, uint8_t* bases_dev) {
+    int rc = check_ctx(ctx);
+    if (rc) return rc;
+    if (n < 0 || first < 0 || (n > 0 && !bases_dev)) {
+        set_error("bad argument to gnn_synth_windows_dev");
+        return GNN_ERR_ARG;
+    }
+    if (n == 0) return GNN_OK;
+    return launch_synth(ctx, seed, first, n, bases_dev);
+}
+
+int gnn_classify_dev(gnn_ctx* ctx, const uint8_t* bases_dev, int64_t n, int precision, float* scores_dev) {
+    int rc = check_ctx(ctx);
+    if (rc) return rc;
+    if (n < 0 || (n > 0 && (!bases_dev || !scores_dev))) {
+        set_error("bad argument to gnn_classify_dev");
+        return GNN_ERR_ARG;
+    }
+    if (n == 0) return GNN_OK;
+    return classify_chunks(ctx, bases_dev, n, precision, scores_dev);
+}
+
+int gnn_classify(gnn_ctx* ctx, const uint8_t* bases_host, int64_t n, int precision, float* scores_host) {
+    return gnn_debug_forward(ctx, bases_host, n, precision, scores_host, nullptr);
+}
+
+int gnn_debug_forward(gnn_ctx* ctx, const uint8_t* bases_host, int64_t n, int precision,
+                      float* scores_host, const gnn_taps* taps) {
+    int rc = check_ctx(ctx);
+    if (rc) return rc;
+    if (n < 0 || (n > 0 && (!bases_host || !scores_host))) {
+        set_error("bad argument to gnn_classify");
+        return GNN_ERR_ARG;
+    }
+    if (n == 0) return GNN_OK;
+    if (taps) {
+        // taps are copied out of the workspace, so the whole batch must be one chunk
+        const int64_t lim = precision == GNN_PREC_F32 ? ctx->chunk_f32 : ctx->chunk_fused;
+        if (n > lim) {
+            set_error("gnn_debug_forward with taps: n_windows exceeds one chunk (" + std::to_string(lim) + ")");
+            return GNN_ERR_ARG;
+        }
+        if ((taps->x1 || taps->x2 || taps->x3) && precision != GNN_PREC_F32) {
+            set_error("x1/x2/x3 taps exist only on the f32 path (the fused path keeps them in LDS)");
+            return GNN_ERR_ARG;
+        }
+    }
+    void *b = nullptr, *s = nullptr;
+    if ((rc = dev_buffer(ctx, (size_t)n * W, &b))) return rc;
+    if ((rc = dev_buffer(ctx, (size_t)n * GNN_CLASSES * sizeof(float), &s))) {
+        (void)hipFree(b);
+        return rc;
+    }
+    rc = gnn_memcpy_h2d(ctx, b, bases_host, (size_t)n * W);
+    if (!rc) rc = classify_chunks(ctx, (const uint8_t*)b, n, precision, (float*)s);
+    if (!rc) rc = gnn_memcpy_d2h(ctx, scores_host, s, (size_t)n * GNN_CLASSES * sizeof(float));
+    if (!rc && taps) {
+        const Workspace& ws = ctx->ws;
+        auto out = [&](float* dst, const float* src, size_t count) {
+            if (dst && !rc) rc = gnn_memcpy_d2h(ctx, dst, src, count * sizeof(float));
+        };
+        out(taps->x1, ws.x[0], (size_t)n * T * C);
+        out(taps->x2, ws.x[1], (size_t)n * T * C);
+        out(taps->x3, ws.x[2], (size_t)n * T * C);
+        out(taps->feat, ws.feat, (size_t)n * FEAT);
+        // per-head strided tensors: copy the (n,2,...) buffers and de-interleave on the host
+        auto out2 = [&](float* dst_a, float* dst_b, const float* src, size_t per) {
+            if ((!dst_a && !dst_b) || rc) return;
+            std::vector<float> tmp((size_t)n * 2 * per);
+            rc = gnn_memcpy_d2h(ctx, tmp.data(), src, tmp.size() * sizeof(float));
+            if (rc) return;
+            for (int64_t i = 0; i < n; ++i) {
+                if (dst_a) std::memcpy(dst_a + i * per, tmp.data() + (i * 2 + 0) * per, per * sizeof(float));
+                if (dst_b) std::memcpy(dst_b + i * per, tmp.data() + (i * 2 + 1) * per, per * sizeof(float));
+            }
+        };
+        out2(taps->yp_a, taps->yp_b, ws.yp, (size_t)POOLED * C);
+        out2(taps->alpha_a, taps->alpha_b, ws.alpha, (size_t)POOLED);
+        if ((taps->m_a || taps->m_b) && !rc) {
+            // m[p] = w_bias[p] + sum_j mp[p*4+j]  (same order as the backend kernel)
+            std::vector<float> mp((size_t)n * 2 * NPAIR), bias(NP);
+            rc = gnn_memcpy_d2h(ctx, mp.data(), ws.mp, mp.size() * sizeof(float));
+            for (int h = 0; h < 2 && !rc; ++h) {
+                float* dst = h ? taps->m_b : taps->m_a;
+                if (!dst) continue;
+                rc = gnn_memcpy_d2h(ctx, bias.data(), ctx->w.w_bias[h], NP * sizeof(float));
+                for (int64_t i = 0; i < n && !rc; ++i)
+                    for (int p = 0; p < NP; ++p) {
+                        const float* q = &mp[((size_t)i * 2 + h) * NPAIR + (size_t)p * PS];
+                        dst[i * NP + p] = bias[p] + q[0] + q[1] + q[2] + q[3];
+                    }
+            }
+        }
+    }
+    (void)hipFree(b);
+    (void)hipFree(s);
+    return rc;
+}
+
+int gnn_profile_enable(gnn_ctx* ctx, int on) {
+    if (!ctx) {
+        set_error("ctx is NULL");
+        return GNN_ERR_ARG;
+    }
+    ctx->profile = on != 0;
+    return GNN_OK;
+}
+
+static int drain_profile(gnn_ctx* ctx) {
+    GNN_HIP(hipStreamSynchronize(ctx->stream));
+    for (auto& s : ctx->prof) {
+        for (auto& pr : s.pending) {
+            float ms = 0.f;
+            GNN_HIP(hipEventElapsedTime(&ms, pr.first, pr.second));
+            s.total_ms += ms;
+            s.launches += 1;
+            ctx->event_pool.push_back(pr.first);
+            ctx->event_pool.push_back(pr.second);
+        }
+        s.pending.clear();
+    }
+    return GNN_OK;
+}
+
+int gnn_profile_reset(gnn_ctx* ctx) {
+    int rc = check_ctx(ctx);
+    if (rc) return rc;
+    if ((rc = drain_profile(ctx))) return rc;
+    for (auto& s : ctx->prof) {
+        s.total_ms = 0.0;
+        s.launches = 0;
+    }
+    return GNN_OK;
+}
+
+int gnn_profile_get(gnn_ctx* ctx, int kernel_id, double* total_ms, int64_t* launches) {
+    int rc = check_ctx(ctx);
+    if (rc) return rc;
+    if (kernel_id < 0 || kernel_id >= GNN_K_COUNT) {
+        set_error("bad kernel id");
+        return GNN_ERR_ARG;
+    }
+    if ((rc = drain_profile(ctx))) return rc;
+    if (total_ms) *total_ms = ctx->prof[kernel_id].total_ms;
+    if (launches) *launches = ctx->prof[kernel_id].launches;
+    return GNN_OK;
+}
+
+}  // extern "C"

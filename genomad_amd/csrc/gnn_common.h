@@ -1,0 +1,114 @@
+// Shared declarations of libgenomad_nn_hip.so (host side + kernel launchers).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <string>
+#include <vector>
+
+#include "../../include/genomad_nn.h"
+
+namespace gnn {
+
+constexpr int W = GNN_WINDOW;
+constexpr int T = GNN_TOKENS;
+constexpr int C = GNN_CH;
+constexpr int KS = GNN_KSIZE;
+constexpr int NP = GNN_PATCHES;
+constexpr int PS = GNN_PATCH_SIZE;
+constexpr int NPAIR = NP * PS;            // 8400 (patch, slot) pairs per head
+constexpr int POOLED = GNN_POOLED;
+constexpr int FEAT = GNN_FEAT;
+constexpr int HID = GNN_HIDDEN;
+constexpr float LRELU = 0.1f;             // igloo.py:48
+constexpr float BN_EPS = 1e-3f;           // Keras BatchNormalization default
+
+// ---- fused front end geometry (gnn_fused.hip) ----
+constexpr int FT = 128;                   // rows (token positions) per step of a workgroup
+constexpr int FSTEPS = (T + FT - 1) / FT; // 47 steps per window
+
+void set_error(const std::string& msg);
+
+#define GNN_HIP(call)                                                                          \
+    do {                                                                                       \
+        hipError_t e_ = (call);                                                                \
+        if (e_ != hipSuccess) {                                                                \
+            gnn::set_error(std::string(#call) + " failed: " + hipGetErrorString(e_));          \
+            return GNN_ERR_HIP;                                                                \
+        }                                                                                      \
+    } while (0)
+
+// Device-resident, re-packed weights.
+struct DeviceWeights {
+    // f32 reference layouts
+    float* conv1_k = nullptr;   // (6,257,128)
+    float* conv1_b = nullptr;
+    float* conv_k[2] = {nullptr, nullptr};   // conv2, conv3 (6,128,128)
+    float* conv_b[2] = {nullptr, nullptr};
+    float* weff[2] = {nullptr, nullptr};     // (8400,128)  w_mult * w_summer folded, per head
+    int32_t* pair_pos[2] = {nullptr, nullptr};  // (8400,) position of pair p*4+j
+    float* w_bias[2] = {nullptr, nullptr};   // (2100,)
+    float* w_qk[2] = {nullptr, nullptr};     // (2100,749)
+    float* w_v[2] = {nullptr, nullptr};      // (128,128) [in][out]
+    float* d1_k = nullptr;  // (256,512) BN folded
+    float* d1_b = nullptr;
+    float* d2_k = nullptr;  // (512,512) BN folded
+    float* d2_b = nullptr;
+    float* d3_k = nullptr;  // (512,3)
+    float* d3_b = nullptr;
+    // fused path packs (gnn_fused.hip): MFMA fragment order, bf16 hi / lo planes
+    uint16_t* conv_frag[2] = {nullptr, nullptr};  // conv2, conv3: [kstep 48][nblk 4][plane 2][lane 64][8]
+    uint16_t* wv_frag[2] = {nullptr, nullptr};    // head A, B:   [kstep 8][nblk 4][plane 2][lane 64][8]
+    // pairs bucketed by step: entry = (pair_id << 8) | local_row, CSR over FSTEPS
+    uint32_t* bucket_entries[2] = {nullptr, nullptr};   // (8400,)
+    int32_t* bucket_ptr[2] = {nullptr, nullptr};        // (FSTEPS+1,)
+};
+
+struct Workspace {
+    int64_t chunk = 0;          // windows per launch
+    uint16_t* tokens = nullptr; // (chunk, 5997)           f32 path only
+    float* x[3] = {nullptr, nullptr, nullptr};  // (chunk,5997,128) each, f32 path only
+    int64_t x_chunk = 0;        // windows the x buffers hold
+    float* mp = nullptr;        // (chunk, 2, 8400)
+    float* yp = nullptr;        // (chunk, 2, 749, 128)
+    float* logits = nullptr;    // (chunk, 2, 749)
+    float* alpha = nullptr;     // (chunk, 2, 749)   (tap)
+    float* feat = nullptr;      // (chunk, 256)
+};
+
+struct ProfileSlot {
+    double total_ms = 0.0;
+    int64_t launches = 0;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> pending;
+};
+
+}  // namespace gnn
+
+struct gnn_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    bool has_weights = false;
+    gnn::DeviceWeights w;
+    gnn::Workspace ws;
+    int64_t chunk_fused = 2048;
+    int64_t chunk_f32 = 64;
+    bool profile = false;
+    gnn::ProfileSlot prof[GNN_K_COUNT];
+    std::vector<hipEvent_t> event_pool;
+    std::vector<void*> owned;   // device allocations to free at destroy
+    int cu_count = 0;
+};
+
+namespace gnn {
+
+// ---- kernel launchers (each enqueues on ctx->stream, returns gnn_status) ----
+int launch_tokenize(gnn_ctx* ctx, const uint8_t* bases, int64_t n, uint16_t* tokens);
+int launch_onehot(gnn_ctx* ctx, const uint8_t* bases, int64_t n, int dtype, void* out);
+int launch_synth(gnn_ctx* ctx, uint64_t seed, int64_t first, int64_t n, uint8_t* bases);
+int launch_front_f32(gnn_ctx* ctx, const uint8_t* bases, int64_t n);         // -> ws.mp, ws.yp (+ ws.x)
+int launch_front_fused(gnn_ctx* ctx, const uint8_t* bases, int64_t n, int precision);  // -> ws.mp, ws.yp
+int launch_backend(gnn_ctx* ctx, int64_t n, float* scores_dev);              // ws.mp, ws.yp -> scores
+
+// host-side packing for the fused path (gnn_fused.hip)
+int pack_fused_weights(gnn_ctx* ctx, const gnn_weights* w, const std::vector<float> weff[2]);
+
+}  // namespace gnn

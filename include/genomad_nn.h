@@ -1,0 +1,181 @@
+/*
+ * genomad_nn.h — C ABI of libgenomad_nn_hip.so (MI355X / gfx950).
+ *
+ * Drop-in boundary for the nn-classification hot path of geNomad.  The reference
+ * has no FFI of its own: the seam is the Python function
+ *   genomad/modules/nn_classification.py:21-30  main(input_path, output_path, ...)
+ * and, inside it, the TensorFlow/numba calls listed per entry point below.  A
+ * maintainer binds these functions with ctypes; all arguments
+ * are plain pointers and sizes, no torch/numpy types.
+ *
+ * Conventions: every function returns 0 on success or a negative gnn_status; the
+ * message for the last failure on the calling thread is gnn_last_error().  The
+ * caller allocates all outputs.  One gnn_ctx is bound to one HIP device and one
+ * HIP stream; a ctx is not thread safe, different ctxs are independent (one process
+ * per GPU, or one ctx per device in one process).  "host"/"dev" in a parameter name
+ * says where the pointer must live.  No exceptions cross the ABI.
+ */
+#ifndef GENOMAD_NN_H
+#define GENOMAD_NN_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GNN_WINDOW 6000      /* nn_classification.py:68,72  window length / ljust width   */
+#define GNN_TOKENS 5997      /* model.py:15                 6000 - 4 + 1 tokens            */
+#define GNN_DEPTH 257        /* model.py:11                 one-hot depth (token 0 = N)    */
+#define GNN_CH 128           /* model.py:20                 nb_filters_conv1d              */
+#define GNN_KSIZE 6          /* model.py:22                 conv1d_kernel                  */
+#define GNN_PATCHES 2100     /* model.py:19                 nb_patches                     */
+#define GNN_PATCH_SIZE 4     /* igloo.py:33                 patch_size                     */
+#define GNN_POOL 8           /* model.py:23                 pooling_size                   */
+#define GNN_POOLED 749       /* igloo.py:176                int(5997 / 8)                  */
+#define GNN_FEAT 256         /* igloo.py:83                 concat of the two IGLOO heads  */
+#define GNN_HIDDEN 512       /* model.py:28,40                                             */
+#define GNN_CLASSES 3        /* model.py:44                 chromosome, plasmid, virus     */
+
+typedef enum gnn_status {
+    GNN_OK = 0,
+    GNN_ERR_ARG = -1,        /* bad argument (null pointer, negative size, bad enum) */
+    GNN_ERR_HIP = -2,        /* a HIP runtime call failed (message has the HIP error)  */
+    GNN_ERR_STATE = -3,      /* e.g. classify before gnn_load_weights                  */
+    GNN_ERR_WEIGHTS = -4,    /* weight tensor invalid (patch index out of range ...)   */
+    GNN_ERR_NOMEM = -5
+} gnn_status;
+
+/* Arithmetic of the conv / w_v contractions (everything else is always f32). */
+typedef enum gnn_precision {
+    GNN_PREC_F32 = 0,        /* f32 reference path: unfused f32 kernels, activations in HBM   */
+    GNN_PREC_BF16X3 = 1,     /* fused path: split-bf16 (hi+lo), 3 MFMA passes, f32 accumulate */
+    GNN_PREC_BF16 = 2        /* fused path: single bf16 MFMA pass (fails the 1e-4 tolerance;
+                                for roofline experiments only)                                */
+} gnn_precision;
+
+typedef enum gnn_onehot_dtype { GNN_OH_U8 = 0, GNN_OH_BF16 = 1, GNN_OH_F32 = 2 } gnn_onehot_dtype;
+
+/*
+ * Weights in the reference's own layouts (what Keras load_weights would put into the
+ * graph of model.py:34-45; nn_classification.py:309-310).  All pointers are HOST
+ * pointers, C-contiguous, float32 unless noted; the library copies and re-packs them.
+ */
+typedef struct gnn_igloo_weights {
+    const int32_t* patches;  /* (2100,4,1) int32  igloo.py:129-135 "random_patches" */
+    const float* w_mult;     /* (1,2100,4,128)    igloo.py:137-143                  */
+    const float* w_summer;   /* (1,512,1)         igloo.py:144-150                  */
+    const float* w_bias;     /* (1,2100)          igloo.py:166-172                  */
+    const float* w_qk;       /* (2100,749)        igloo.py:174-180                  */
+    const float* w_v;        /* (1,128,128)       igloo.py:182-188                  */
+} gnn_igloo_weights;
+
+typedef struct gnn_dense_bn {
+    const float* kernel;     /* (in,out) Keras Dense kernel          model.py:28,40 */
+    const float* bias;       /* (out,)                                              */
+    const float* gamma;      /* (out,) BatchNormalization, eps=1e-3  model.py:29,41 */
+    const float* beta;
+    const float* mean;       /* moving_mean     */
+    const float* var;        /* moving_variance */
+} gnn_dense_bn;
+
+typedef struct gnn_weights {
+    const float* conv1_kernel;   /* (6,257,128)  igloo.py:45-47 on the one-hot input */
+    const float* conv1_bias;     /* (128,)                                           */
+    const float* conv2_kernel;   /* (6,128,128)  igloo.py:66 (loop iteration 1)      */
+    const float* conv2_bias;
+    const float* conv3_kernel;   /* (6,128,128)  igloo.py:66 (loop iteration 2)      */
+    const float* conv3_bias;
+    gnn_igloo_weights igloo_a;   /* igloo.py:54-62, applied to conv1 output           */
+    gnn_igloo_weights igloo_b;   /* igloo.py:73-81, applied to conv3 output           */
+    gnn_dense_bn enc;            /* Dense(512)+BN, in=256   model.py:28-30            */
+    gnn_dense_bn head;           /* Dense(512)+BN, in=512   model.py:40-42            */
+    const float* out_kernel;     /* (512,3)                 model.py:44               */
+    const float* out_bias;       /* (3,)                                              */
+} gnn_weights;
+
+/* Host pointers that receive intermediates of gnn_debug_forward (any may be NULL). */
+typedef struct gnn_taps {
+    float* x1;       /* (n,5997,128) conv1+LeakyReLU            (F32 path only) */
+    float* x2;       /* (n,5997,128)                            (F32 path only) */
+    float* x3;       /* (n,5997,128)                            (F32 path only) */
+    float* m_a;      /* (n,2100)   igloo.py:205-206 "mpi" of head A             */
+    float* m_b;
+    float* yp_a;     /* (n,749,128) max-pooled y @ w_v   igloo.py:208-210       */
+    float* yp_b;
+    float* alpha_a;  /* (n,749)    igloo.py:211-212                             */
+    float* alpha_b;
+    float* feat;     /* (n,256)    igloo.py:83 concat                           */
+} gnn_taps;
+
+typedef struct gnn_ctx gnn_ctx;
+
+/* ---- life cycle -------------------------------------------------------------------- */
+const char* gnn_last_error(void);
+int gnn_version(void);
+int gnn_device_count(int* count);
+int gnn_create(int device, gnn_ctx** out);
+int gnn_destroy(gnn_ctx* ctx);
+int gnn_sync(gnn_ctx* ctx);                      /* hipStreamSynchronize on the ctx stream */
+int gnn_device_info(gnn_ctx* ctx, char* name, size_t name_len, int* cus, int64_t* hbm_bytes);
+
+/* replaces nn_model.load_weights(GenomadData.nn_model_file), nn_classification.py:310 */
+int gnn_load_weights(gnn_ctx* ctx, const gnn_weights* w);
+
+/* ---- raw device memory (so a ctypes host needs no torch for buffers) ------------------ */
+int gnn_dev_alloc(gnn_ctx* ctx, size_t bytes, void** dev_ptr);
+int gnn_dev_free(gnn_ctx* ctx, void* dev_ptr);
+int gnn_memcpy_h2d(gnn_ctx* ctx, void* dst_dev, const void* src_host, size_t bytes);
+int gnn_memcpy_d2h(gnn_ctx* ctx, void* dst_host, const void* src_dev, size_t bytes);
+
+/* ---- hot path ------------------------------------------------------------------------ */
+/* replaces sequence.tokenize_dna(window, 4) (sequence.py:170-193) on n padded, upper-cased
+ * 6000-byte windows: tokens_out[n][5997] in [0,256].  Host in / host out. */
+int gnn_tokenize(gnn_ctx* ctx, const uint8_t* bases_host, int64_t n_windows, uint16_t* tokens_host);
+int gnn_tokenize_dev(gnn_ctx* ctx, const uint8_t* bases_dev, int64_t n_windows, uint16_t* tokens_dev);
+
+/* replaces OneHotLayer (model.py:9-11): bases -> tokens -> one-hot depth 257, written to
+ * onehot_dev[n][5997][257] of the requested dtype (device pointer, caller-allocated). */
+int gnn_onehot_dev(gnn_ctx* ctx, const uint8_t* bases_dev, int64_t n_windows, int onehot_dtype,
+                   void* onehot_dev);
+
+/* replaces the predict loop nn_classification.py:316-317 (+ tokenisation :72-73):
+ * scores[n][3] = softmax class scores per window.  precision: gnn_precision. */
+int gnn_classify(gnn_ctx* ctx, const uint8_t* bases_host, int64_t n_windows, int precision,
+                 float* scores_host);
+int gnn_classify_dev(gnn_ctx* ctx, const uint8_t* bases_dev, int64_t n_windows, int precision,
+                     float* scores_dev);   /* asynchronous on the ctx stream */
+
+/* replaces tf.math.segment_mean(pred, contig_ids) nn_classification.py:320.
+ * ids sorted ascending, out has n_segments rows (zero row for an id with no window). */
+int gnn_segment_mean(gnn_ctx* ctx, const float* scores_host, const int64_t* ids_host, int64_t n,
+                     int64_t n_segments, float* out_host);
+
+/* same forward as gnn_classify, also copying intermediates out (parity tests). */
+int gnn_debug_forward(gnn_ctx* ctx, const uint8_t* bases_host, int64_t n_windows, int precision,
+                      float* scores_host, const gnn_taps* taps);
+
+/* ---- synthetic data + measurement ------------------------------------------------------ */
+/* windows first..first+n of the counter-based synthetic set (genomad_amd/synthetic.py) */
+int gnn_synth_windows_dev(gnn_ctx* ctx, uint64_t seed, int64_t first, int64_t n_windows,
+                          uint8_t* bases_dev);
+
+/* HIP-event timing of the kernels launched on the ctx stream.  kernel ids: */
+#define GNN_K_FUSED 0        /* fused tokens->conv1..3->IGLOO front end (dominant kernel) */
+#define GNN_K_BACKEND 1      /* logits GEMM + softmax + attention + dense stack           */
+#define GNN_K_ENCODER 2      /* stand-alone byte -> one-hot encoder                       */
+#define GNN_K_F32_FRONT 3    /* unfused f32 front end (all its kernels)                   */
+#define GNN_K_COUNT 4
+int gnn_profile_enable(gnn_ctx* ctx, int on);
+int gnn_profile_reset(gnn_ctx* ctx);
+/* synchronises the stream, then total milliseconds and number of launches of kernel_id */
+int gnn_profile_get(gnn_ctx* ctx, int kernel_id, double* total_ms, int64_t* launches);
+
+/* windows the ctx processes per launch of the fused front end (workspace sizing) */
+int gnn_set_chunk(gnn_ctx* ctx, int64_t windows_per_chunk);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GENOMAD_NN_H */

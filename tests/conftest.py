@@ -1,0 +1,47 @@
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (gfx950); run with -m gpu")
+
+
+def _gpu_explicitly_requested(config) -> bool:
+    expr = config.getoption("-m") or ""
+    return "gpu" in expr and "not gpu" not in expr
+
+
+@pytest.fixture(scope="session")
+def synth_weights():
+    from genomad_amd import synthetic
+    return synthetic.synth_weights()
+
+
+@pytest.fixture(scope="session")
+def engine(request, synth_weights):
+    """One NNEngine on device 0 with the synthetic weights.  No CPU fallback: with `-m gpu`
+    a missing library or device is a failure; without it the GPU tests are skipped."""
+    from genomad_amd import _lib
+    from genomad_amd.engine import NNEngine
+    try:
+        eng = NNEngine(0, synth_weights)
+    except Exception as exc:  # noqa: BLE001
+        if _gpu_explicitly_requested(request.config):
+            raise
+        pytest.skip(f"no usable gfx950 device: {exc}")
+    yield eng
+    eng.close()
+
+
+@pytest.fixture(scope="session")
+def golden_dir():
+    return GOLDEN
