@@ -158,3 +158,54 @@ def test_errors_are_reported_not_swallowed(engine):
         out = np.zeros((1, 3), np.float32)
         b = np.zeros((1, 6000), np.uint8)
         _lib.check(engine.lib.gnn_classify(engine.ctx, b.ctypes.data, 1, 77, out.ctypes.data))
+
+
+# ------------------------------------------------------------------ fused bf16x3 MFMA path
+def test_fused_bf16x3_intermediates(engine, oracle16):
+    """Fused kernel (activations in LDS, split-bf16 MFMA) against the fp64 oracle, per stage."""
+    bases, scores64, t64 = oracle16
+    scores, taps = engine.debug_forward(bases, "bf16x3")
+    checks = [("m_a", "mA", 1e-4), ("m_b", "mB", 1e-3), ("yp_a", "ypA", 1e-4), ("yp_b", "ypB", 1e-3),
+              ("alpha_a", "alphaA", 1e-5), ("alpha_b", "alphaB", 2e-4), ("feat", "f", 5e-4)]
+    for mine, ref, tol in checks:
+        err = np.abs(taps[mine] - t64[ref]).max()
+        assert err <= tol, f"{mine}: max abs err {err:.3e} > {tol}"
+    assert np.abs(scores - scores64).max() <= SCORE_TOL
+
+
+def test_fused_bf16x3_scores_256_windows(engine, synth_weights):
+    """256 synthetic windows (padded and N-run windows included) within 1e-4 of the fp32 oracle."""
+    bases = synthetic.synth_windows(0, 256)
+    got = engine.classify(bases, "bf16x3")
+    want = igloo_oracle.classify_windows(bases, synth_weights, np.float32)
+    err = np.abs(got - want).max()
+    assert err <= SCORE_TOL, f"max |dscore| = {err:.3e}"
+    assert got.std(axis=0).min() > 0.05          # the test is not vacuous: scores vary across windows
+
+
+def test_fused_equals_f32_path_and_is_batch_invariant(engine):
+    bases = synthetic.synth_windows(5000, 96)
+    a = engine.classify(bases, "bf16x3")
+    b = engine.classify(bases, "f32")
+    assert np.abs(a - b).max() <= SCORE_TOL
+    # a window's scores must not depend on its position in the batch or on the batch size
+    c = engine.classify(bases[37:59], "bf16x3")
+    assert np.array_equal(a[37:59], c)
+    assert np.array_equal(engine.classify(bases, "bf16x3"), a)   # run-to-run deterministic
+
+
+def test_fused_edge_windows(engine, synth_weights):
+    wins = [b"", b"ACGT", b"ACGT" * 1500, b"A" * 6000, (b"ACGT" * 700), b"N" * 2999 + b"ACGTACGT"]
+    bases = np.stack([_pad(w) for w in wins])
+    got = engine.classify(bases, "bf16x3")
+    want = igloo_oracle.classify_windows(bases, synth_weights, np.float64)
+    assert np.abs(got - want).max() <= SCORE_TOL
+    assert engine.classify(bases[:0], "bf16x3").shape == (0, 3)
+
+
+def test_single_pass_bf16_is_outside_tolerance_but_sane(engine, oracle16):
+    """GNN_PREC_BF16 exists for roofline experiments; document that it misses the 1e-4 tolerance."""
+    bases, scores64, _ = oracle16
+    got = engine.classify(bases, "bf16")
+    err = np.abs(got - scores64).max()
+    assert 1e-4 < err < 5e-2, f"single-pass bf16 max |dscore| = {err:.3e}"
