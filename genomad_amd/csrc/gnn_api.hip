@@ -68,6 +68,7 @@ static void free_ws(Workspace& ws) {
     f(ws.x[1]);
     f(ws.x[2]);
     f(ws.mp);
+    f(ws.m);
     f(ws.yp);
     f(ws.logits);
     f(ws.alpha);
@@ -91,6 +92,7 @@ static int ensure_ws(gnn_ctx* ctx, int64_t chunk, int64_t x_chunk) {
         };
         int rc;
         if ((rc = re(ws.mp, (size_t)chunk * 2 * NPAIR * sizeof(float)))) return rc;
+        if ((rc = re(ws.m, (size_t)chunk * 2 * NP * sizeof(float)))) return rc;
         if ((rc = re(ws.yp, (size_t)chunk * 2 * POOLED * C * sizeof(float)))) return rc;
         if ((rc = re(ws.logits, (size_t)chunk * 2 * POOLED * sizeof(float)))) return rc;
         if ((rc = re(ws.alpha, (size_t)chunk * 2 * POOLED * sizeof(float)))) return rc;
@@ -288,33 +290,50 @@ int gnn_load_weights(gnn_ctx* ctx, const gnn_weights* w) {
         if ((rc = upload(ctx, cb[i], (size_t)C, &d.conv_b[i]))) return rc;
     }
     const gnn_igloo_weights* ig[2] = {&w->igloo_a, &w->igloo_b};
-    std::vector<float> weff[2];
     for (int h = 0; h < 2; ++h) {
         const gnn_igloo_weights* g = ig[h];
         if (!g->patches || !g->w_mult || !g->w_summer || !g->w_bias || !g->w_qk || !g->w_v) {
             set_error("an IGLOO weight pointer is NULL");
             return GNN_ERR_ARG;
         }
-        // W_eff[p,j,c] = w_mult[0,p,j,c] * w_summer[0, j*128+c, 0]  (igloo.py:195-204 folded)
-        weff[h].resize((size_t)NPAIR * C);
-        std::vector<int32_t> pos(NPAIR);
-        for (int p = 0; p < NP; ++p)
-            for (int j = 0; j < PS; ++j) {
-                const int32_t t = g->patches[p * PS + j];
-                if (t < 0 || t >= T) {
-                    set_error("patch index out of range [0,5997)");
-                    return GNN_ERR_WEIGHTS;
-                }
-                pos[p * PS + j] = t;
-                for (int c = 0; c < C; ++c)
-                    weff[h][((size_t)p * PS + j) * C + c] =
-                        g->w_mult[((size_t)p * PS + j) * C + c] * g->w_summer[j * C + c];
+        // sort the (patch, slot) pairs by position (stable: ties keep pair order)
+        std::vector<int32_t> order(NPAIR);
+        for (int i = 0; i < NPAIR; ++i) {
+            const int32_t t = g->patches[i];
+            if (t < 0 || t >= T) {
+                set_error("patch index out of range [0,5997)");
+                return GNN_ERR_WEIGHTS;
             }
-        if ((rc = upload(ctx, weff[h].data(), weff[h].size(), &d.weff[h]))) return rc;
-        if ((rc = upload(ctx, pos.data(), pos.size(), &d.pair_pos[h]))) return rc;
+            order[i] = i;
+        }
+        std::stable_sort(order.begin(), order.end(),
+                         [&](int32_t a, int32_t b) { return g->patches[a] < g->patches[b]; });
+        // W_eff[p,j,c] = w_mult[0,p,j,c] * w_summer[0, j*128+c, 0]  (igloo.py:195-204 folded)
+        std::vector<float> weff((size_t)NPAIR * C);
+        std::vector<int32_t> pos(NPAIR), slot(NPAIR), ptr(FSTEPS + 1, 0);
+        for (int e = 0; e < NPAIR; ++e) {
+            const int pair = order[e], j = pair % PS;
+            pos[e] = g->patches[pair];
+            slot[pair] = e;
+            ptr[pos[e] / FT + 1] += 1;
+            for (int c = 0; c < C; ++c)
+                weff[(size_t)e * C + c] = g->w_mult[(size_t)pair * C + c] * g->w_summer[j * C + c];
+        }
+        for (int s2 = 0; s2 < FSTEPS; ++s2) ptr[s2 + 1] += ptr[s2];
+        if ((rc = upload(ctx, weff.data(), weff.size(), &d.weff_sorted[h]))) return rc;
+        if ((rc = upload(ctx, pos.data(), pos.size(), &d.pos_sorted[h]))) return rc;
+        if ((rc = upload(ctx, slot.data(), slot.size(), &d.slot[h]))) return rc;
+        if ((rc = upload(ctx, ptr.data(), ptr.size(), &d.bucket_ptr[h]))) return rc;
         if ((rc = upload(ctx, g->w_bias, (size_t)NP, &d.w_bias[h]))) return rc;
         if ((rc = upload(ctx, g->w_qk, (size_t)NP * POOLED, &d.w_qk[h]))) return rc;
         if ((rc = upload(ctx, g->w_v, (size_t)C * C, &d.w_v[h]))) return rc;
+    }
+    {
+        std::vector<float> kz((size_t)KS * (GNN_DEPTH + 1) * C, 0.f);
+        for (int k = 0; k < KS; ++k)
+            std::memcpy(&kz[(size_t)k * (GNN_DEPTH + 1) * C], w->conv1_kernel + (size_t)k * GNN_DEPTH * C,
+                        (size_t)GNN_DEPTH * C * sizeof(float));
+        if ((rc = upload(ctx, kz.data(), kz.size(), &d.conv1_kz))) return rc;
     }
     // Fold BatchNormalization (inference statistics) into the preceding Dense (model.py:28-30, 40-42):
     // y = gamma * (x@K + b - mean) / sqrt(var + eps) + beta = x@(K*s) + ((b - mean)*s + beta)
@@ -333,7 +352,7 @@ int gnn_load_weights(gnn_ctx* ctx, const gnn_weights* w) {
     if ((rc = fold(w->head, HID, &d.d2_k, &d.d2_b))) return rc;
     if ((rc = upload(ctx, w->out_kernel, (size_t)HID * GNN_CLASSES, &d.d3_k))) return rc;
     if ((rc = upload(ctx, w->out_bias, (size_t)GNN_CLASSES, &d.d3_b))) return rc;
-    if ((rc = pack_fused_weights(ctx, w, weff))) return rc;
+    if ((rc = pack_fused_weights(ctx, w))) return rc;
     ctx->has_weights = true;
     return GNN_OK;
 }
@@ -495,21 +514,7 @@ int gnn_debug_forward(gnn_ctx* ctx, const uint8_t* bases_host, int64_t n, int pr
         };
         out2(taps->yp_a, taps->yp_b, ws.yp, (size_t)POOLED * C);
         out2(taps->alpha_a, taps->alpha_b, ws.alpha, (size_t)POOLED);
-        if ((taps->m_a || taps->m_b) && !rc) {
-            // m[p] = w_bias[p] + sum_j mp[p*4+j]  (same order as the backend kernel)
-            std::vector<float> mp((size_t)n * 2 * NPAIR), bias(NP);
-            rc = gnn_memcpy_d2h(ctx, mp.data(), ws.mp, mp.size() * sizeof(float));
-            for (int h = 0; h < 2 && !rc; ++h) {
-                float* dst = h ? taps->m_b : taps->m_a;
-                if (!dst) continue;
-                rc = gnn_memcpy_d2h(ctx, bias.data(), ctx->w.w_bias[h], NP * sizeof(float));
-                for (int64_t i = 0; i < n && !rc; ++i)
-                    for (int p = 0; p < NP; ++p) {
-                        const float* q = &mp[((size_t)i * 2 + h) * NPAIR + (size_t)p * PS];
-                        dst[i * NP + p] = bias[p] + q[0] + q[1] + q[2] + q[3];
-                    }
-            }
-        }
+        out2(taps->m_a, taps->m_b, ws.m, (size_t)NP);
     }
     (void)hipFree(b);
     (void)hipFree(s);

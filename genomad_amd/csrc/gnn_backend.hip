@@ -3,7 +3,7 @@
 // to class scores.  Everything here is f32 (the softmax over 749 pooled positions is driven by a
 // 2100-term dot product and is the precision-sensitive part of the network).
 //
-//   m[p]      = w_bias[p] + sum_j mp[p*4+j]                      igloo.py:204-206
+//   m[p]      = w_bias[p] + sum_j mp[slot[p*4+j]]                igloo.py:204-206  (m_kernel)
 //   logits[q] = sum_p m[p] * w_qk[p,q] ; alpha = softmax(logits)  igloo.py:211-212
 //   feat      = sum_q alpha[q] * yp[q,:]   (both heads, concat)   igloo.py:213-214, :83
 //   h1 = relu(BN(feat@D1+d1)); h2 = relu(BN(h1@D2+d2)); scores = softmax(h2@D3+d3)   model.py:28-44
@@ -12,21 +12,38 @@
 
 namespace gnn {
 
+// m[w][h][p] = w_bias[p] + sum_j mp[w][h][slot[p*4+j]]: one block per (window, head) stages the
+// window's 8400 pair products (written in position order by the front end) in LDS and gathers
+// the four slots of every patch from there, so global traffic stays coalesced.
+__global__ __launch_bounds__(256) void m_kernel(const float* __restrict__ mp, const float* __restrict__ w_bias0,
+                                                const float* __restrict__ w_bias1,
+                                                const int32_t* __restrict__ slot0,
+                                                const int32_t* __restrict__ slot1, float* __restrict__ m) {
+    __shared__ float s[NPAIR];
+    const int wi = blockIdx.x, h = blockIdx.y;
+    const float* w_bias = h ? w_bias1 : w_bias0;
+    const int32_t* slot = h ? slot1 : slot0;
+    const float4* src = reinterpret_cast<const float4*>(mp + ((size_t)wi * 2 + h) * NPAIR);
+    for (int i = threadIdx.x; i < NPAIR / 4; i += 256) reinterpret_cast<float4*>(s)[i] = src[i];
+    __syncthreads();
+    for (int p = threadIdx.x; p < NP; p += 256) {
+        const int4 sl = reinterpret_cast<const int4*>(slot)[p];
+        m[((size_t)wi * 2 + h) * NP + p] = w_bias[p] + s[sl.x] + s[sl.y] + s[sl.z] + s[sl.w];
+    }
+}
+
 // logits[w][h][q] = sum_p m[w][h][p] * w_qk[h][p][q].  Block tile: 32 windows x 64 q, K chunk 32.
 // Each window's sum runs over p in ascending order independent of the batch it is in, so results
 // do not depend on how windows are sharded.
 constexpr int LW = 32, LQ = 64, LK = 32;
 
-__global__ __launch_bounds__(256) void logits_kernel(const float* __restrict__ mp,
-                                                     const float* __restrict__ w_bias0,
-                                                     const float* __restrict__ w_bias1,
+__global__ __launch_bounds__(256) void logits_kernel(const float* __restrict__ m,
                                                      const float* __restrict__ w_qk0,
                                                      const float* __restrict__ w_qk1, int n,
                                                      float* __restrict__ logits) {
     __shared__ float ms[LK][LW + 1];
     __shared__ float qs[LK][LQ];
     const int h = blockIdx.z;
-    const float* w_bias = h ? w_bias1 : w_bias0;
     const float* w_qk = h ? w_qk1 : w_qk0;
     const int w0 = blockIdx.y * LW;
     const int q0 = blockIdx.x * LQ;
@@ -37,13 +54,9 @@ __global__ __launch_bounds__(256) void logits_kernel(const float* __restrict__ m
         // m tile: 32 p x 32 windows (thread -> one (window, p))
         for (int i = threadIdx.x; i < LK * LW; i += 256) {
             const int p = i % LK, w = i / LK;
-            float m = 0.f;
-            if (p0 + p < NP && w0 + w < n) {
-                const float4 v = *reinterpret_cast<const float4*>(
-                    mp + ((size_t)(w0 + w) * 2 + h) * NPAIR + (size_t)(p0 + p) * PS);
-                m = w_bias[p0 + p] + v.x + v.y + v.z + v.w;
-            }
-            ms[p][w] = m;
+            float v = 0.f;
+            if (p0 + p < NP && w0 + w < n) v = m[((size_t)(w0 + w) * 2 + h) * NP + p0 + p];
+            ms[p][w] = v;
         }
         for (int i = threadIdx.x; i < LK * LQ; i += 256) {
             const int q = i % LQ, p = i / LQ;
@@ -196,8 +209,10 @@ __global__ __launch_bounds__(512) void dense_kernel(const float* __restrict__ fe
 int launch_backend(gnn_ctx* ctx, int64_t n, float* scores_dev) {
     const DeviceWeights& d = ctx->w;
     Workspace& ws = ctx->ws;
+    hipLaunchKernelGGL(m_kernel, dim3((unsigned)n, 2), dim3(256), 0, ctx->stream, ws.mp, d.w_bias[0], d.w_bias[1],
+                       d.slot[0], d.slot[1], ws.m);
     hipLaunchKernelGGL(logits_kernel, dim3((POOLED + LQ - 1) / LQ, (unsigned)((n + LW - 1) / LW), 2), dim3(256), 0,
-                       ctx->stream, ws.mp, d.w_bias[0], d.w_bias[1], d.w_qk[0], d.w_qk[1], (int)n, ws.logits);
+                       ctx->stream, ws.m, d.w_qk[0], d.w_qk[1], (int)n, ws.logits);
     hipLaunchKernelGGL(attn_kernel, dim3((unsigned)n, 2), dim3(256), 0, ctx->stream, ws.logits, ws.yp, ws.alpha,
                        ws.feat);
     hipLaunchKernelGGL(dense_kernel, dim3((unsigned)((n + DW - 1) / DW)), dim3(512), 0, ctx->stream, ws.feat,

@@ -44,8 +44,14 @@ struct DeviceWeights {
     float* conv1_b = nullptr;
     float* conv_k[2] = {nullptr, nullptr};   // conv2, conv3 (6,128,128)
     float* conv_b[2] = {nullptr, nullptr};
-    float* weff[2] = {nullptr, nullptr};     // (8400,128)  w_mult * w_summer folded, per head
-    int32_t* pair_pos[2] = {nullptr, nullptr};  // (8400,) position of pair p*4+j
+    // IGLOO (patch, slot) pairs, SORTED BY POSITION ("bucket order"): entry e of head h reads
+    // activation row pos_sorted[e] and weights weff_sorted[e,:]; pair p*4+j lives at e = slot[p*4+j].
+    // bucket_ptr[s] .. bucket_ptr[s+1] are the entries whose position falls into fused step s.
+    float* weff_sorted[2] = {nullptr, nullptr};    // (8400,128)  w_mult * w_summer folded
+    int32_t* pos_sorted[2] = {nullptr, nullptr};   // (8400,)
+    int32_t* slot[2] = {nullptr, nullptr};         // (8400,) pair -> entry
+    int32_t* bucket_ptr[2] = {nullptr, nullptr};   // (FSTEPS+1,)
+    float* conv1_kz = nullptr;  // (6,258,128): conv1 kernel + an all-zero row 257 (position < 0)
     float* w_bias[2] = {nullptr, nullptr};   // (2100,)
     float* w_qk[2] = {nullptr, nullptr};     // (2100,749)
     float* w_v[2] = {nullptr, nullptr};      // (128,128) [in][out]
@@ -58,9 +64,6 @@ struct DeviceWeights {
     // fused path packs (gnn_fused.hip): MFMA fragment order, bf16 hi / lo planes
     uint16_t* conv_frag[2] = {nullptr, nullptr};  // conv2, conv3: [kstep 48][nblk 4][plane 2][lane 64][8]
     uint16_t* wv_frag[2] = {nullptr, nullptr};    // head A, B:   [kstep 8][nblk 4][plane 2][lane 64][8]
-    // pairs bucketed by step: entry = (pair_id << 8) | local_row, CSR over FSTEPS
-    uint32_t* bucket_entries[2] = {nullptr, nullptr};   // (8400,)
-    int32_t* bucket_ptr[2] = {nullptr, nullptr};        // (FSTEPS+1,)
 };
 
 struct Workspace {
@@ -68,7 +71,8 @@ struct Workspace {
     uint16_t* tokens = nullptr; // (chunk, 5997)           f32 path only
     float* x[3] = {nullptr, nullptr, nullptr};  // (chunk,5997,128) each, f32 path only
     int64_t x_chunk = 0;        // windows the x buffers hold
-    float* mp = nullptr;        // (chunk, 2, 8400)
+    float* mp = nullptr;        // (chunk, 2, 8400) pair dot products in bucket order
+    float* m = nullptr;         // (chunk, 2, 2100)  bias + the four pair products of every patch
     float* yp = nullptr;        // (chunk, 2, 749, 128)
     float* logits = nullptr;    // (chunk, 2, 749)
     float* alpha = nullptr;     // (chunk, 2, 749)   (tap)
@@ -109,6 +113,6 @@ int launch_front_fused(gnn_ctx* ctx, const uint8_t* bases, int64_t n, int precis
 int launch_backend(gnn_ctx* ctx, int64_t n, float* scores_dev);              // ws.mp, ws.yp -> scores
 
 // host-side packing for the fused path (gnn_fused.hip)
-int pack_fused_weights(gnn_ctx* ctx, const gnn_weights* w, const std::vector<float> weff[2]);
+int pack_fused_weights(gnn_ctx* ctx, const gnn_weights* w);
 
 }  // namespace gnn

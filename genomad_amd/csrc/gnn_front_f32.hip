@@ -123,13 +123,13 @@ __global__ __launch_bounds__(256) void conv_f32_kernel(const float* __restrict__
 // mp[w][h][pair] = sum_c x[w][pos[pair]][c] * Weff[pair][c]; 32 lanes per pair.
 __global__ __launch_bounds__(256) void mpart_f32_kernel(const float* __restrict__ x,
                                                         const float* __restrict__ weff,
-                                                        const int32_t* __restrict__ pair_pos,
+                                                        const int32_t* __restrict__ pos_sorted,
                                                         float* __restrict__ mp, int head) {
     const int wi = blockIdx.y;
-    const int pair = blockIdx.x * 8 + (threadIdx.x >> 5);
+    const int pair = blockIdx.x * 8 + (threadIdx.x >> 5);   // entry index in bucket order
     const int l = threadIdx.x & 31;
     if (pair >= NPAIR) return;
-    const int t = pair_pos[pair];
+    const int t = pos_sorted[pair];
     const float4 a = *reinterpret_cast<const float4*>(x + ((size_t)wi * T + t) * C + l * 4);
     const float4 b = *reinterpret_cast<const float4*>(weff + (size_t)pair * C + l * 4);
     float s = a.x * b.x;
@@ -158,7 +158,7 @@ int launch_front_f32(gnn_ctx* ctx, const uint8_t* bases, int64_t n) {
     for (int h = 0; h < 2; ++h) {
         const float* xh = h == 0 ? ws.x[0] : ws.x[2];
         hipLaunchKernelGGL(mpart_f32_kernel, dim3(NPAIR / 8, (unsigned)n), dim3(256), 0, ctx->stream, xh,
-                           d.weff[h], d.pair_pos[h], ws.mp, h);
+                           d.weff_sorted[h], d.pos_sorted[h], ws.mp, h);
         hipLaunchKernelGGL((conv_f32_kernel<1, true>), cgrid, dim3(256), 0, ctx->stream, xh, d.w_v[h],
                            (const float*)nullptr, ws.yp + (size_t)h * POOLED * C, 2 * POOLED * C);
     }

@@ -36,7 +36,6 @@ constexpr int BUF_BYTES = BUF_ROWS * ROWB;   // 70224
 constexpr int TOK_OFF = 2 * BUF_BYTES;       // u16 tokens of positions t0-5 .. t0+127
 constexpr int TOK_COUNT = BUF_ROWS;
 constexpr int SMEM_BYTES = TOK_OFF + ((TOK_COUNT * 2 + 15) / 16) * 16;
-constexpr int KSTEPS_CONV = KS * (C / 16);   // 48 k-steps of 16
 constexpr int FRAG_U4 = 64;                  // one fragment = 64 lanes x uint4
 
 __device__ __forceinline__ float lrelu_f(float v) { return v > 0.f ? v : v * LRELU; }
@@ -49,48 +48,89 @@ __device__ __forceinline__ int base_code_f(uint32_t b) {
 // K = NTAPS * 128.  SWAP: D = W^T X^T (columns of D are positions; used by the convs so that a
 // lane ends up with 4 consecutive channels of one position -> 8-byte LDS writes).  !SWAP: D = X W
 // (rows are positions; used by y@w_v so that the 8-row max-pool is 4 registers + one lane swap).
+//
+// Software pipeline (one wave per SIMD, so nothing else hides latency): weight fragments are
+// fetched from L2 two k-steps ahead, activation fragments from LDS one k-step ahead; the
+// sched_barriers keep hipcc from sinking the loads back down to their first use (it otherwise
+// emits load; s_waitcnt vmcnt(0); mfma — every L2 round trip exposed).
+template <int PASSES>
+struct WFrag {
+    uint4 v[PASSES == 3 ? 2 : 1];
+};
+template <int PASSES>
+struct XFrag {
+    uint4 v[4][PASSES == 3 ? 2 : 1];
+};
+
+template <int PASSES>
+__device__ __forceinline__ void load_w(WFrag<PASSES>& f, const uint4* __restrict__ wfrag, int ks) {
+    const uint4* wp = wfrag + (size_t)ks * (4 * 2 * FRAG_U4);
+    f.v[0] = wp[0];
+    if constexpr (PASSES == 3) f.v[1] = wp[FRAG_U4];
+}
+
+template <int PASSES>
+__device__ __forceinline__ void load_x(XFrag<PASSES>& f, const unsigned char* __restrict__ xl, int ks) {
+    const unsigned char* xp = xl + (ks >> 3) * ROWB + (ks & 7) * 32;
+#pragma unroll
+    for (int mb = 0; mb < 4; ++mb) {
+        f.v[mb][0] = *reinterpret_cast<const uint4*>(xp + mb * 32 * ROWB);
+        if constexpr (PASSES == 3) f.v[mb][1] = *reinterpret_cast<const uint4*>(xp + mb * 32 * ROWB + LO_OFF);
+    }
+}
+
+template <bool SWAP, int PASSES>
+__device__ __forceinline__ void mfma_block(const WFrag<PASSES>& w, const XFrag<PASSES>& x, f32x16 (&acc)[4]) {
+    const bf16x8 wh = __builtin_bit_cast(bf16x8, w.v[0]);
+    if constexpr (PASSES == 3) {
+        const bf16x8 wl = __builtin_bit_cast(bf16x8, w.v[1]);
+#pragma unroll
+        for (int mb = 0; mb < 4; ++mb) {
+            const bf16x8 xh = __builtin_bit_cast(bf16x8, x.v[mb][0]);
+            acc[mb] = SWAP ? __builtin_amdgcn_mfma_f32_32x32x16_bf16(wl, xh, acc[mb], 0, 0, 0)
+                           : __builtin_amdgcn_mfma_f32_32x32x16_bf16(xh, wl, acc[mb], 0, 0, 0);
+        }
+#pragma unroll
+        for (int mb = 0; mb < 4; ++mb) {
+            const bf16x8 xl = __builtin_bit_cast(bf16x8, x.v[mb][1]);
+            acc[mb] = SWAP ? __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh, xl, acc[mb], 0, 0, 0)
+                           : __builtin_amdgcn_mfma_f32_32x32x16_bf16(xl, wh, acc[mb], 0, 0, 0);
+        }
+    }
+#pragma unroll
+    for (int mb = 0; mb < 4; ++mb) {
+        const bf16x8 xh = __builtin_bit_cast(bf16x8, x.v[mb][0]);
+        acc[mb] = SWAP ? __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh, xh, acc[mb], 0, 0, 0)
+                       : __builtin_amdgcn_mfma_f32_32x32x16_bf16(xh, wh, acc[mb], 0, 0, 0);
+    }
+}
+
 template <bool SWAP, int NTAPS, int PASSES>
 __device__ __forceinline__ void gemm_tile(const unsigned char* __restrict__ xbuf,   // row of u=0, tap 0
                                           const uint4* __restrict__ wfrag,           // + nblk*2*64 + lane
                                           f32x16 (&acc)[4], int lane) {
+    constexpr int NK = NTAPS * (C / 16);         // k-steps of 16 (even)
     const unsigned char* xl = xbuf + (lane & 31) * ROWB + (lane >> 5) * 16;
+    WFrag<PASSES> w0, w1, wn0, wn1;
+    XFrag<PASSES> xa, xb;
+    load_w(w0, wfrag, 0);
+    load_w(w1, wfrag, 1);
+    load_x(xa, xl, 0);
 #pragma unroll 1
-    for (int kk = 0; kk < NTAPS; ++kk) {
-#pragma unroll
-        for (int g = 0; g < C / 16; ++g) {
-            const uint4* wp = wfrag + (size_t)((kk * (C / 16) + g) * 4 * 2) * FRAG_U4;
-            const uint4 w_hi = wp[0];
-            uint4 w_lo = w_hi;
-            if constexpr (PASSES == 3) w_lo = wp[FRAG_U4];
-            const unsigned char* xp = xl + kk * ROWB + g * 32;
-            uint4 x_hi[4], x_lo[4];
-#pragma unroll
-            for (int mb = 0; mb < 4; ++mb) {
-                x_hi[mb] = *reinterpret_cast<const uint4*>(xp + mb * 32 * ROWB);
-                x_lo[mb] = x_hi[mb];
-                if constexpr (PASSES == 3) x_lo[mb] = *reinterpret_cast<const uint4*>(xp + mb * 32 * ROWB + LO_OFF);
-            }
-#pragma unroll
-            for (int mb = 0; mb < 4; ++mb) {
-                const bf16x8 xh = __builtin_bit_cast(bf16x8, x_hi[mb]);
-                const bf16x8 wh = __builtin_bit_cast(bf16x8, w_hi);
-                if constexpr (PASSES == 3) {
-                    const bf16x8 xlo = __builtin_bit_cast(bf16x8, x_lo[mb]);
-                    const bf16x8 wlo = __builtin_bit_cast(bf16x8, w_lo);
-                    if (SWAP) {
-                        acc[mb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wlo, xh, acc[mb], 0, 0, 0);
-                        acc[mb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh, xlo, acc[mb], 0, 0, 0);
-                    } else {
-                        acc[mb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xh, wlo, acc[mb], 0, 0, 0);
-                        acc[mb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xlo, wh, acc[mb], 0, 0, 0);
-                    }
-                }
-                if (SWAP)
-                    acc[mb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh, xh, acc[mb], 0, 0, 0);
-                else
-                    acc[mb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xh, wh, acc[mb], 0, 0, 0);
-            }
-        }
+    for (int ks = 0; ks < NK; ks += 2) {
+        const int kn = ks + 2 < NK ? ks + 2 : ks;   // clamped: the last prefetch is a harmless re-read
+        load_w(wn0, wfrag, kn);
+        load_w(wn1, wfrag, kn + 1);
+        load_x(xb, xl, ks + 1);
+        __builtin_amdgcn_sched_barrier(0);
+        mfma_block<SWAP, PASSES>(w0, xa, acc);
+        __builtin_amdgcn_sched_barrier(0);
+        load_x(xa, xl, kn);
+        __builtin_amdgcn_sched_barrier(0);
+        mfma_block<SWAP, PASSES>(w1, xb, acc);
+        __builtin_amdgcn_sched_barrier(0);
+        w0 = wn0;
+        w1 = wn1;
     }
 }
 
@@ -137,35 +177,54 @@ __device__ __forceinline__ void wv_pool(const unsigned char* __restrict__ xbuf, 
         }
 }
 
-// pair dot products of this step: 16 lanes per (patch, slot) pair, 8 channels per lane
+// pair dot products of this step (igloo.py:192-204, w_mult*w_summer folded): entries e_begin..e_end
+// of the position-sorted pair list all read rows of the current step.  16 lanes per entry, 8
+// channels per lane; 4 entries per lane group are in flight at once (their loads are independent:
+// weights stream linearly in entry order, rows come from LDS) so the L2 latency is paid once per
+// batch.  Results are written in entry order (contiguous), the back end un-permutes.
 __device__ __forceinline__ void m_partials(const unsigned char* __restrict__ xbuf, const float* __restrict__ weff,
-                                           const uint32_t* __restrict__ entries, int e_begin, int e_end,
+                                           const int32_t* __restrict__ pos, int t0, int e_begin, int e_end,
                                            float* __restrict__ mp_w, int wave, int lane) {
+    constexpr int MB = 4;
     const int sub = lane & 15;
-    // the 16 lanes of a pair share e, so a lane group enters/leaves the loop together and the
+    // the 16 lanes of an entry share e, so a lane group enters/leaves the loop together and the
     // width-16 shuffles below only ever read lanes that are active
-    for (int e = e_begin + wave * 4 + (lane >> 4); e < e_end; e += 16) {
-        const uint32_t ent = entries[e];
-        const int u = ent & 0xFF;
-        const int pair = ent >> 8;
-        const unsigned char* xr = xbuf + (CARRY + u) * ROWB + sub * 16;
-        const uint4 h = *reinterpret_cast<const uint4*>(xr);
-        const uint4 l = *reinterpret_cast<const uint4*>(xr + LO_OFF);
-        const float4 w0 = *reinterpret_cast<const float4*>(weff + (size_t)pair * C + sub * 8);
-        const float4 w1 = *reinterpret_cast<const float4*>(weff + (size_t)pair * C + sub * 8 + 4);
-        const uint32_t hv[4] = {h.x, h.y, h.z, h.w}, lv[4] = {l.x, l.y, l.z, l.w};
-        const float wv[8] = {w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, w1.z, w1.w};
-        float s = 0.f;
+    for (int e = e_begin + wave * 4 + (lane >> 4); e < e_end; e += 16 * MB) {
+        int ei[MB], u[MB];
+        float4 w0[MB], w1[MB];
+        uint4 h[MB], l[MB];
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const float x0 = __uint_as_float(hv[k] << 16) + __uint_as_float(lv[k] << 16);
-            const float x1 = __uint_as_float(hv[k] & 0xFFFF0000u) + __uint_as_float(lv[k] & 0xFFFF0000u);
-            s = fmaf(x0, wv[2 * k], s);
-            s = fmaf(x1, wv[2 * k + 1], s);
+        for (int i = 0; i < MB; ++i) {
+            ei[i] = min(e + 16 * i, e_end - 1);      // clamped duplicates are computed but not stored
+            u[i] = pos[ei[i]] - t0;
         }
 #pragma unroll
-        for (int off = 8; off >= 1; off >>= 1) s += __shfl_xor(s, off, 16);
-        if (sub == 0) mp_w[pair] = s;
+        for (int i = 0; i < MB; ++i) {
+            w0[i] = *reinterpret_cast<const float4*>(weff + (size_t)ei[i] * C + sub * 8);
+            w1[i] = *reinterpret_cast<const float4*>(weff + (size_t)ei[i] * C + sub * 8 + 4);
+        }
+#pragma unroll
+        for (int i = 0; i < MB; ++i) {
+            const unsigned char* xr = xbuf + (CARRY + u[i]) * ROWB + sub * 16;
+            h[i] = *reinterpret_cast<const uint4*>(xr);
+            l[i] = *reinterpret_cast<const uint4*>(xr + LO_OFF);
+        }
+#pragma unroll
+        for (int i = 0; i < MB; ++i) {
+            const uint32_t hv[4] = {h[i].x, h[i].y, h[i].z, h[i].w}, lv[4] = {l[i].x, l[i].y, l[i].z, l[i].w};
+            const float wv[8] = {w0[i].x, w0[i].y, w0[i].z, w0[i].w, w1[i].x, w1[i].y, w1[i].z, w1[i].w};
+            float s = 0.f;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const float x0 = __uint_as_float(hv[k] << 16) + __uint_as_float(lv[k] << 16);
+                const float x1 = __uint_as_float(hv[k] & 0xFFFF0000u) + __uint_as_float(lv[k] & 0xFFFF0000u);
+                s = fmaf(x0, wv[2 * k], s);
+                s = fmaf(x1, wv[2 * k + 1], s);
+            }
+#pragma unroll
+            for (int off = 8; off >= 1; off >>= 1) s += __shfl_xor(s, off, 16);
+            if (sub == 0 && e + 16 * i < e_end) mp_w[e + 16 * i] = s;
+        }
     }
 }
 
@@ -177,7 +236,7 @@ struct FusedArgs {
     const float* conv_b[2];
     const uint4* wv_frag[2];
     const float* weff[2];
-    const uint32_t* bucket_entries[2];
+    const int32_t* pos_sorted[2];
     const int32_t* bucket_ptr[2];
     float* mp;
     float* yp;
@@ -211,7 +270,7 @@ __global__ __launch_bounds__(256, 1) void fused_front_kernel(FusedArgs a) {
         // ---- S0: tokens of positions t0-5 .. t0+127 (sequence.py:170-193, closed form) ----
         if (tid < TOK_COUNT) {
             const int t = t0 - CARRY + tid;
-            uint32_t tok = 0xFFFFu;                       // sentinel: position < 0 (zero pad of the one-hot)
+            uint32_t tok = GNN_DEPTH;                     // position < 0: the all-zero row 257 of conv1_kz
             if (t >= 0) {
                 tok = 0;
                 if (t < T) {
@@ -234,7 +293,7 @@ __global__ __launch_bounds__(256, 1) void fused_front_kernel(FusedArgs a) {
 #pragma unroll
                 for (int k = 0; k < KS; ++k) {
                     const uint32_t tk = toks[u + k];
-                    if (tk != 0xFFFFu) v += *reinterpret_cast<const f32x4*>(a.conv1_k + ((size_t)k * GNN_DEPTH + tk) * C + cq * 4);
+                    v += *reinterpret_cast<const f32x4*>(a.conv1_k + ((size_t)k * (GNN_DEPTH + 1) + tk) * C + cq * 4);
                 }
 #pragma unroll
                 for (int e = 0; e < 4; ++e) v[e] = lrelu_f(v[e]);
@@ -247,7 +306,7 @@ __global__ __launch_bounds__(256, 1) void fused_front_kernel(FusedArgs a) {
         }
         __syncthreads();
         // ---- S2: head A on x1, conv2: x1 -> x2 ----
-        m_partials(bufX, a.weff[0], a.bucket_entries[0], a.bucket_ptr[0][step], a.bucket_ptr[0][step + 1], mp_w[0], wave, lane);
+        m_partials(bufX, a.weff[0], a.pos_sorted[0], t0, a.bucket_ptr[0][step], a.bucket_ptr[0][step + 1], mp_w[0], wave, lane);
         wv_pool<PASSES>(bufX, vfrag[0], yp_w[0], t0, wave, lane);
         {
             f32x16 acc[4];
@@ -280,7 +339,7 @@ __global__ __launch_bounds__(256, 1) void fused_front_kernel(FusedArgs a) {
         }
         __syncthreads();
         // ---- S4: head B on x3 ----
-        m_partials(bufX, a.weff[1], a.bucket_entries[1], a.bucket_ptr[1][step], a.bucket_ptr[1][step + 1], mp_w[1], wave, lane);
+        m_partials(bufX, a.weff[1], a.pos_sorted[1], t0, a.bucket_ptr[1][step], a.bucket_ptr[1][step + 1], mp_w[1], wave, lane);
         wv_pool<PASSES>(bufX, vfrag[1], yp_w[1], t0, wave, lane);
         __syncthreads();          // bufX is rewritten by S1 of the next step
     }
@@ -328,7 +387,7 @@ static int upload_vec(gnn_ctx* ctx, const std::vector<Tp>& v, Tp** dev) {
     return GNN_OK;
 }
 
-int pack_fused_weights(gnn_ctx* ctx, const gnn_weights* w, const std::vector<float>* /*weff*/) {
+int pack_fused_weights(gnn_ctx* ctx, const gnn_weights* w) {
     DeviceWeights& d = ctx->w;
     int rc;
     const float* ck[2] = {w->conv2_kernel, w->conv3_kernel};
@@ -336,21 +395,6 @@ int pack_fused_weights(gnn_ctx* ctx, const gnn_weights* w, const std::vector<flo
     for (int i = 0; i < 2; ++i) {
         if ((rc = upload_vec(ctx, pack_frags(ck[i], KS * C), &d.conv_frag[i]))) return rc;
         if ((rc = upload_vec(ctx, pack_frags(ig[i]->w_v, C), &d.wv_frag[i]))) return rc;
-        // bucket the (patch, slot) pairs by step (positions are static weights, igloo.py:129-135)
-        std::vector<std::vector<uint32_t>> per_step(FSTEPS);
-        for (int pair = 0; pair < NPAIR; ++pair) {
-            const int t = ig[i]->patches[pair];
-            per_step[t / FT].push_back(((uint32_t)pair << 8) | (uint32_t)(t % FT));
-        }
-        std::vector<uint32_t> entries;
-        std::vector<int32_t> ptr(FSTEPS + 1, 0);
-        for (int s = 0; s < FSTEPS; ++s) {
-            ptr[s] = (int32_t)entries.size();
-            entries.insert(entries.end(), per_step[s].begin(), per_step[s].end());
-        }
-        ptr[FSTEPS] = (int32_t)entries.size();
-        if ((rc = upload_vec(ctx, entries, &d.bucket_entries[i]))) return rc;
-        if ((rc = upload_vec(ctx, ptr, &d.bucket_ptr[i]))) return rc;
     }
     return GNN_OK;
 }
@@ -359,14 +403,14 @@ int launch_front_fused(gnn_ctx* ctx, const uint8_t* bases, int64_t n, int precis
     const DeviceWeights& d = ctx->w;
     FusedArgs a;
     a.bases = bases;
-    a.conv1_k = d.conv1_k;
+    a.conv1_k = d.conv1_kz;
     a.conv1_b = d.conv1_b;
     for (int i = 0; i < 2; ++i) {
         a.conv_frag[i] = reinterpret_cast<const uint4*>(d.conv_frag[i]);
         a.conv_b[i] = d.conv_b[i];
         a.wv_frag[i] = reinterpret_cast<const uint4*>(d.wv_frag[i]);
-        a.weff[i] = d.weff[i];
-        a.bucket_entries[i] = d.bucket_entries[i];
+        a.weff[i] = d.weff_sorted[i];
+        a.pos_sorted[i] = d.pos_sorted[i];
         a.bucket_ptr[i] = d.bucket_ptr[i];
     }
     a.mp = ctx->ws.mp;

@@ -1,0 +1,59 @@
+"""Data-parallel sharding of windows across GPUs (one process per GPU).
+
+Windows are independent (every score depends only on its own 6000 bytes and the replicated
+weights), so the path shards with no data-path collective: rank r classifies a contiguous range
+of windows, and the per-window scores (12 B each) are collected on rank 0 with ONE gather at the
+end — ``torch.distributed`` backend "nccl" (= RCCL over xGMI) on GPUs, "gloo" in the CPU tests.
+Contiguous ranges keep every contig on at most two ranks and preserve window order, so the
+per-contig segment mean (nn_classification.py:320) runs on rank 0 over the gathered array and the
+result is bit-identical for any number of ranks (no cross-rank reduction is involved).
+
+torch is imported lazily and only here: it is plumbing (process group, gather), not arithmetic.
+"""
+from typing import List, Tuple
+
+
+def shard_range(n_windows: int, world_size: int, rank: int) -> Tuple[int, int]:
+    """Half-open window range of ``rank``: ceil(n/G) windows per rank, the tail ranks get fewer
+    (possibly zero)."""
+    if world_size < 1 or not (0 <= rank < world_size) or n_windows < 0:
+        raise ValueError("bad shard arguments")
+    per = -(-n_windows // world_size)
+    a = min(rank * per, n_windows)
+    return a, min(a + per, n_windows)
+
+
+def shard_counts(n_windows: int, world_size: int) -> List[int]:
+    return [b - a for a, b in (shard_range(n_windows, world_size, r) for r in range(world_size))]
+
+
+def gather_scores(local_scores, n_windows: int, group=None, dst: int = 0):
+    """Collect the (n_local, 3) float32 score shards of all ranks on ``dst`` in window order.
+
+    ``local_scores`` is a torch tensor (CUDA for nccl, CPU for gloo) holding this rank's shard as
+    produced for :func:`shard_range`.  Shards are padded to ceil(n/G) rows so that a single
+    fixed-size gather suffices.  Returns the (n_windows, 3) tensor on ``dst`` and None elsewhere.
+    """
+    import torch
+    import torch.distributed as dist
+
+    world = dist.get_world_size(group)
+    rank = dist.get_rank(group)
+    per = -(-n_windows // world)
+    a, b = shard_range(n_windows, world, rank)
+    if tuple(local_scores.shape) != (b - a, 3):
+        raise ValueError(f"rank {rank}: expected shard of shape {(b - a, 3)}, got {tuple(local_scores.shape)}")
+    send = local_scores
+    if b - a != per:
+        send = torch.zeros((per, 3), dtype=local_scores.dtype, device=local_scores.device)
+        send[: b - a] = local_scores
+    send = send.contiguous()
+    if world == 1:
+        return send[:n_windows]
+    recv = None
+    if rank == dst:
+        recv = [torch.empty_like(send) for _ in range(world)]
+    dist.gather(send, recv, dst=dst, group=group)
+    if rank != dst:
+        return None
+    return torch.cat(recv, dim=0)[:n_windows]
