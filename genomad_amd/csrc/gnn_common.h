@@ -100,6 +100,7 @@ struct gnn_ctx {
     std::vector<hipEvent_t> event_pool;
     std::vector<void*> owned;   // device allocations to free at destroy
     int cu_count = 0;
+    unsigned long long* phase_cycles = nullptr;   // non-null: fused kernel runs its instrumented build
 };
 
 namespace gnn {

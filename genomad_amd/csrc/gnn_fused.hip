@@ -240,9 +240,20 @@ struct FusedArgs {
     const int32_t* bucket_ptr[2];
     float* mp;
     float* yp;
+    unsigned long long* cycles;   // PROF builds: 10 phase counters (wave 0 of every block, summed)
 };
 
-template <int PASSES>
+// Phase ids of the PROF instrumentation (s_memtime deltas of wave 0, barriers included in the phase
+// they close): 0 tokens, 1 conv1 gather, 2 m-partials A, 3 w_v+pool A, 4 conv2 main loop,
+// 5 conv2 epilogue, 6 conv3 main loop, 7 conv3 epilogue + carries, 8 m-partials B, 9 w_v+pool B.
+#define GNN_TICK(i)                                              \
+    if constexpr (PROF) {                                        \
+        const unsigned long long now_ = __builtin_readcyclecounter(); \
+        cyc[i] += now_ - tick_;                                  \
+        tick_ = now_;                                            \
+    }
+
+template <int PASSES, bool PROF>
 __global__ __launch_bounds__(256, 1) void fused_front_kernel(FusedArgs a) {
     __shared__ __attribute__((aligned(16))) unsigned char smem[SMEM_BYTES];
     unsigned char* bufX = smem;
@@ -264,6 +275,10 @@ __global__ __launch_bounds__(256, 1) void fused_front_kernel(FusedArgs a) {
         reinterpret_cast<uint4*>(bufY)[i] = make_uint4(0, 0, 0, 0);
     }
 
+    unsigned long long cyc[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long tick_ = 0;
+    if constexpr (PROF) tick_ = __builtin_readcyclecounter();
+
 #pragma unroll 1
     for (int step = 0; step < FSTEPS; ++step) {
         const int t0 = step * FT;
@@ -282,6 +297,7 @@ __global__ __launch_bounds__(256, 1) void fused_front_kernel(FusedArgs a) {
             toks[tid] = (uint16_t)tok;
         }
         __syncthreads();
+        GNN_TICK(0)
         // ---- S1: conv1 as a 6-row gather-sum + LeakyReLU -> x1 (bufX rows 5..132) ----
         {
             const int cq = tid & 31;                      // 4 channels
@@ -305,9 +321,12 @@ __global__ __launch_bounds__(256, 1) void fused_front_kernel(FusedArgs a) {
             }
         }
         __syncthreads();
+        GNN_TICK(1)
         // ---- S2: head A on x1, conv2: x1 -> x2 ----
         m_partials(bufX, a.weff[0], a.pos_sorted[0], t0, a.bucket_ptr[0][step], a.bucket_ptr[0][step + 1], mp_w[0], wave, lane);
+        GNN_TICK(2)
         wv_pool<PASSES>(bufX, vfrag[0], yp_w[0], t0, wave, lane);
+        GNN_TICK(3)
         {
             f32x16 acc[4];
 #pragma unroll
@@ -315,9 +334,11 @@ __global__ __launch_bounds__(256, 1) void fused_front_kernel(FusedArgs a) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[mb][r] = 0.f;
             gemm_tile<true, KS, PASSES>(bufX, cfrag[0], acc, lane);
+            GNN_TICK(4)
             conv_epilogue(bufY, a.conv_b[0], acc, wave, lane);
         }
         __syncthreads();
+        GNN_TICK(5)
         // ---- S3: save the x1 carry, conv3: x2 -> x3 (into bufX) ----
         if (tid < CARRY * 32) {   // 5 rows x 512 B
             const int r = tid >> 5, c = tid & 31;
@@ -331,6 +352,7 @@ __global__ __launch_bounds__(256, 1) void fused_front_kernel(FusedArgs a) {
                 for (int r = 0; r < 16; ++r) acc[mb][r] = 0.f;
             gemm_tile<true, KS, PASSES>(bufY, cfrag[1], acc, lane);
             __syncthreads();      // every wave is done reading bufY and the x1 carry rows
+            GNN_TICK(6)
             conv_epilogue(bufX, a.conv_b[1], acc, wave, lane);
         }
         if (tid < CARRY * 32) {   // x2 carry for the next step
@@ -338,10 +360,17 @@ __global__ __launch_bounds__(256, 1) void fused_front_kernel(FusedArgs a) {
             *reinterpret_cast<uint4*>(bufY + r * ROWB + c * 16) = *reinterpret_cast<const uint4*>(bufY + (FT + r) * ROWB + c * 16);
         }
         __syncthreads();
+        GNN_TICK(7)
         // ---- S4: head B on x3 ----
         m_partials(bufX, a.weff[1], a.pos_sorted[1], t0, a.bucket_ptr[1][step], a.bucket_ptr[1][step + 1], mp_w[1], wave, lane);
+        GNN_TICK(8)
         wv_pool<PASSES>(bufX, vfrag[1], yp_w[1], t0, wave, lane);
         __syncthreads();          // bufX is rewritten by S1 of the next step
+        GNN_TICK(9)
+    }
+    if constexpr (PROF) {
+        if (tid == 0)
+            for (int i = 0; i < 10; ++i) atomicAdd(a.cycles + i, cyc[i]);
     }
 }
 
@@ -415,10 +444,15 @@ int launch_front_fused(gnn_ctx* ctx, const uint8_t* bases, int64_t n, int precis
     }
     a.mp = ctx->ws.mp;
     a.yp = ctx->ws.yp;
-    if (precision == GNN_PREC_BF16X3)
-        hipLaunchKernelGGL(fused_front_kernel<3>, dim3((unsigned)n), dim3(256), 0, ctx->stream, a);
-    else
-        hipLaunchKernelGGL(fused_front_kernel<1>, dim3((unsigned)n), dim3(256), 0, ctx->stream, a);
+    a.cycles = ctx->phase_cycles;
+    const bool prof = ctx->phase_cycles != nullptr;
+    if (precision == GNN_PREC_BF16X3) {
+        if (prof) hipLaunchKernelGGL((fused_front_kernel<3, true>), dim3((unsigned)n), dim3(256), 0, ctx->stream, a);
+        else hipLaunchKernelGGL((fused_front_kernel<3, false>), dim3((unsigned)n), dim3(256), 0, ctx->stream, a);
+    } else {
+        if (prof) hipLaunchKernelGGL((fused_front_kernel<1, true>), dim3((unsigned)n), dim3(256), 0, ctx->stream, a);
+        else hipLaunchKernelGGL((fused_front_kernel<1, false>), dim3((unsigned)n), dim3(256), 0, ctx->stream, a);
+    }
     GNN_HIP(hipGetLastError());
     return GNN_OK;
 }

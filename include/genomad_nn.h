@@ -172,6 +172,12 @@ int gnn_profile_reset(gnn_ctx* ctx);
 /* synchronises the stream, then total milliseconds and number of launches of kernel_id */
 int gnn_profile_get(gnn_ctx* ctx, int kernel_id, double* total_ms, int64_t* launches);
 
+/* debug aid: per-phase shader-cycle sums of the fused kernel (instrumented build).  on=1 starts
+ * (zeroes the counters), on=0 stops; out10 (may be NULL) receives the 10 counters collected so far:
+ * tokens, conv1 gather, m-partials A, w_v+pool A, conv2 loop, conv2 epilogue, conv3 loop,
+ * conv3 epilogue, m-partials B, w_v+pool B. */
+int gnn_phase_cycles(gnn_ctx* ctx, int on, unsigned long long* out10);
+
 /* windows the ctx processes per launch of the fused front end (workspace sizing) */
 int gnn_set_chunk(gnn_ctx* ctx, int64_t windows_per_chunk);
 
