@@ -1,12 +1,12 @@
 // Fused front end (GNN_PREC_BF16X3 / GNN_PREC_BF16): bases -> tokens -> conv1 -> conv2 -> conv3
 // and both IGLOO heads' partials, with every activation kept in LDS.
 //
-// One workgroup (4 waves) streams ONE window through time in steps of FT = 128 positions.  The
+// One workgroup (8 waves) streams ONE window through time in steps of FT = 128 positions.  The
 // convolutions are causal (igloo.py:45-47,66: padding="causal"), so step s only needs the last 5
 // rows of the previous step, which stay in LDS ("carry" rows) — no halo recompute.
 //
-//   LDS  bufX : rows 0..4 carry | rows 5..132 = x1 of this step, later overwritten by x3
-//        bufY : rows 0..4 carry | rows 5..132 = x2 of this step
+//   LDS  bufX : rows 0..4 carry | rows 5..132 = x1 of this step
+//        bufY : rows 0..4 x2 carry | rows 5..132 = x2 of this step, later overwritten by x3
 //        row  = 128 ch bf16 hi (256 B) | 128 ch bf16 lo (256 B) | 16 B pad  (528 B stride keeps the
 //               16-lane groups of ds_read_b128 on 16 distinct 16-B slots: 528/4 mod 64 = 4)
 //
@@ -33,8 +33,8 @@ constexpr int LO_OFF = 256;                  // lo plane offset inside a row
 constexpr int CARRY = KS - 1;                // 5 rows carried from the previous step
 constexpr int BUF_ROWS = CARRY + FT;         // 133
 constexpr int BUF_BYTES = BUF_ROWS * ROWB;   // 70224
-constexpr int TOK_OFF = 2 * BUF_BYTES;       // u16 tokens of positions t0-5 .. t0+127
-constexpr int TOK_COUNT = BUF_ROWS;
+constexpr int TOK_OFF = 2 * BUF_BYTES;       // u16 tokens of the whole window, toks[j] = position j-5
+constexpr int TOK_COUNT = ((FSTEPS * FT + CARRY + KS) + 7) / 8 * 8;   // 6032
 constexpr int SMEM_BYTES = TOK_OFF + ((TOK_COUNT * 2 + 15) / 16) * 16;
 constexpr int FRAG_U4 = 64;                  // one fragment = 64 lanes x uint4
 
@@ -105,32 +105,59 @@ __device__ __forceinline__ void mfma_block(const WFrag<PASSES>& w, const XFrag<P
     }
 }
 
+// One k-step region: the MFMAs of k-step k (fragments WCUR, XCUR) with the loads of later k-steps
+// spread between them (activations of k+1 from LDS, weights of k+3 from L2), so that the matrix
+// pipe never waits for a block of loads to issue.  The sched_group_barriers spell the interleave.
+template <bool SWAP, int PASSES>
+__device__ __forceinline__ void gemm_region(const WFrag<PASSES>& wcur, WFrag<PASSES>& wload, const XFrag<PASSES>& xcur,
+                                            XFrag<PASSES>& xload, const unsigned char* __restrict__ xl,
+                                            const uint4* __restrict__ wfrag, int ks_x, int ks_w, f32x16 (&acc)[4]) {
+    load_x(xload, xl, ks_x);
+    load_w(wload, wfrag, ks_w);
+    mfma_block<SWAP, PASSES>(wcur, xcur, acc);
+    if constexpr (PASSES == 3) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);   // 1 MFMA
+            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);   // 1 DS read
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);   // 1 VMEM read
+        }
+        __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+    } else {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+        }
+        __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+}
+
 template <bool SWAP, int NTAPS, int PASSES>
 __device__ __forceinline__ void gemm_tile(const unsigned char* __restrict__ xbuf,   // row of u=0, tap 0
                                           const uint4* __restrict__ wfrag,           // + nblk*2*64 + lane
                                           f32x16 (&acc)[4], int lane) {
-    constexpr int NK = NTAPS * (C / 16);         // k-steps of 16 (even)
+    constexpr int NK = NTAPS * (C / 16);         // k-steps of 16, a multiple of 4
     const unsigned char* xl = xbuf + (lane & 31) * ROWB + (lane >> 5) * 16;
-    WFrag<PASSES> w0, w1, wn0, wn1;
-    XFrag<PASSES> xa, xb;
+    WFrag<PASSES> w0, w1, w2, w3;                // ring: W(k) lives in w[k%4], loaded 3 k-steps ahead
+    XFrag<PASSES> xa, xb;                        // X(k) lives in x[k%2], loaded 1 k-step ahead
     load_w(w0, wfrag, 0);
     load_w(w1, wfrag, 1);
+    load_w(w2, wfrag, 2);
     load_x(xa, xl, 0);
+    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll 1
-    for (int ks = 0; ks < NK; ks += 2) {
-        const int kn = ks + 2 < NK ? ks + 2 : ks;   // clamped: the last prefetch is a harmless re-read
-        load_w(wn0, wfrag, kn);
-        load_w(wn1, wfrag, kn + 1);
-        load_x(xb, xl, ks + 1);
-        __builtin_amdgcn_sched_barrier(0);
-        mfma_block<SWAP, PASSES>(w0, xa, acc);
-        __builtin_amdgcn_sched_barrier(0);
-        load_x(xa, xl, kn);
-        __builtin_amdgcn_sched_barrier(0);
-        mfma_block<SWAP, PASSES>(w1, xb, acc);
-        __builtin_amdgcn_sched_barrier(0);
-        w0 = wn0;
-        w1 = wn1;
+    for (int ks = 0; ks < NK; ks += 4) {
+        // clamped indices: the prefetches past the end are harmless re-reads
+        gemm_region<SWAP, PASSES>(w0, w3, xa, xb, xl, wfrag, ks + 1, min(ks + 3, NK - 1), acc);
+        gemm_region<SWAP, PASSES>(w1, w0, xb, xa, xl, wfrag, ks + 2, min(ks + 4, NK - 1), acc);
+        gemm_region<SWAP, PASSES>(w2, w1, xa, xb, xl, wfrag, ks + 3, min(ks + 5, NK - 1), acc);
+        gemm_region<SWAP, PASSES>(w3, w2, xb, xa, xl, wfrag, min(ks + 4, NK - 1), min(ks + 6, NK - 1), acc);
     }
 }
 
@@ -230,7 +257,7 @@ __device__ __forceinline__ void m_partials(const unsigned char* __restrict__ xbu
 
 struct FusedArgs {
     const uint8_t* bases;
-    const float* conv1_k;
+    const float* conv1_k;        // (6,258,128) f32, row 257 of every tap is zero
     const float* conv1_b;
     const uint4* conv_frag[2];
     const float* conv_b[2];
@@ -240,21 +267,59 @@ struct FusedArgs {
     const int32_t* bucket_ptr[2];
     float* mp;
     float* yp;
-    unsigned long long* cycles;   // PROF builds: 10 phase counters (wave 0 of every block, summed)
+    unsigned long long* cycles;   // PROF builds: 10 phase counters, summed over workgroups
 };
 
-// Phase ids of the PROF instrumentation (s_memtime deltas of wave 0, barriers included in the phase
-// they close): 0 tokens, 1 conv1 gather, 2 m-partials A, 3 w_v+pool A, 4 conv2 main loop,
-// 5 conv2 epilogue, 6 conv3 main loop, 7 conv3 epilogue + carries, 8 m-partials B, 9 w_v+pool B.
-#define GNN_TICK(i)                                              \
-    if constexpr (PROF) {                                        \
+// PROF instrumentation: s_memtime deltas, MFMA wave 0 -> counters 0..7, helper wave 4 -> 8, 9:
+// 0 w_v+pool A, 1 conv2 loop, 2 wait B1, 3 conv2 epilogue+B2, 4 conv3 loop, 5 wait B3,
+// 6 conv3 epilogue+B4, 7 w_v+pool B + wait B0, 8 helper m-partials (B+A), 9 helper conv1 gather.
+#define GNN_TICK(i)                                                   \
+    if constexpr (PROF) {                                             \
         const unsigned long long now_ = __builtin_readcyclecounter(); \
-        cyc[i] += now_ - tick_;                                  \
-        tick_ = now_;                                            \
+        cyc[i] += now_ - tick_;                                       \
+        tick_ = now_;                                                 \
     }
 
+// conv1 (6-row gather-sum of the f32 kernel, model.py:11 + igloo.py:45-48) + LeakyReLU for the 128
+// positions starting at t0, split to bf16 hi/lo, into rows 5..132 of xbuf.  256 helper threads:
+// thread = 4 channels x 16 positions.  toks[j] is the token of position j-5.
+__device__ __forceinline__ void conv1_gather(unsigned char* __restrict__ xbuf, const uint16_t* __restrict__ toks,
+                                             const float* __restrict__ k1, const float* __restrict__ b1,
+                                             int t0, int ht) {
+    const int cq = ht & 31;
+    const f32x4 b = *reinterpret_cast<const f32x4*>(b1 + cq * 4);
+#pragma unroll 4
+    for (int it = 0; it < FT / 8; ++it) {
+        const int u = (ht >> 5) + it * 8;
+        f32x4 v = b;
+#pragma unroll
+        for (int k = 0; k < KS; ++k) {
+            const uint32_t tk = toks[t0 + u + k];
+            v += *reinterpret_cast<const f32x4*>(k1 + ((size_t)k * (GNN_DEPTH + 1) + tk) * C + cq * 4);
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = lrelu_f(v[e]);
+        const bf16x4 h = __builtin_convertvector(v, bf16x4);
+        const bf16x4 l = __builtin_convertvector(v - __builtin_convertvector(h, f32x4), bf16x4);
+        unsigned char* o = xbuf + (CARRY + u) * ROWB + cq * 8;
+        *reinterpret_cast<uint2*>(o) = __builtin_bit_cast(uint2, h);
+        *reinterpret_cast<uint2*>(o + LO_OFF) = __builtin_bit_cast(uint2, l);
+    }
+}
+
+// Warp-specialised workgroup of 8 waves streaming one window through 47 steps of 128 positions:
+//   waves 0-3 ("MFMA waves", one per SIMD): y@w_v + pool of head A, conv2, conv3, y@w_v + pool of head B
+//   waves 4-7 ("helpers", the second wave of each SIMD): everything that is memory-latency bound —
+//     the conv1 gather of the NEXT step and the IGLOO pair dot products of both heads — so that it
+//     overlaps with the MFMA waves instead of serialising with them.
+// Per step (B0..B4 = workgroup barriers):
+//   B0  MFMA: w_v A, conv2 loop  [read bufX]      helpers: m-partials B(s-1) [bufY], m-partials A(s) [bufX]
+//   B1  MFMA: conv2 epilogue -> bufY (x2)          helpers: x1 carry rows -> bufX rows 0..4
+//   B2  MFMA: conv3 loop [read bufY]               helpers: conv1 gather of step s+1 -> bufX rows 5..132
+//   B3  MFMA: conv3 epilogue -> bufY (x3)          helpers: x2 carry rows -> bufY rows 0..4
+//   B4  MFMA: w_v B [read bufY]
 template <int PASSES, bool PROF>
-__global__ __launch_bounds__(256, 1) void fused_front_kernel(FusedArgs a) {
+__global__ __launch_bounds__(512, 2) void fused_front_kernel(FusedArgs a) {
     __shared__ __attribute__((aligned(16))) unsigned char smem[SMEM_BYTES];
     unsigned char* bufX = smem;
     unsigned char* bufY = smem + BUF_BYTES;
@@ -262,115 +327,107 @@ __global__ __launch_bounds__(256, 1) void fused_front_kernel(FusedArgs a) {
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const bool helper = wave >= 4;
+    const int hw = wave & 3;                 // index within the role
+    const int ht = tid & 255;
     const int64_t wi = blockIdx.x;
     const uint8_t* bases = a.bases + wi * W;
     float* mp_w[2] = {a.mp + (wi * 2 + 0) * NPAIR, a.mp + (wi * 2 + 1) * NPAIR};
     float* yp_w[2] = {a.yp + (wi * 2 + 0) * (size_t)POOLED * C, a.yp + (wi * 2 + 1) * (size_t)POOLED * C};
-    const uint4* cfrag[2] = {a.conv_frag[0] + wave * 2 * FRAG_U4 + lane, a.conv_frag[1] + wave * 2 * FRAG_U4 + lane};
-    const uint4* vfrag[2] = {a.wv_frag[0] + wave * 2 * FRAG_U4 + lane, a.wv_frag[1] + wave * 2 * FRAG_U4 + lane};
+    const uint4* cfrag[2] = {a.conv_frag[0] + hw * 2 * FRAG_U4 + lane, a.conv_frag[1] + hw * 2 * FRAG_U4 + lane};
+    const uint4* vfrag[2] = {a.wv_frag[0] + hw * 2 * FRAG_U4 + lane, a.wv_frag[1] + hw * 2 * FRAG_U4 + lane};
 
     // causal zero padding: carry rows of both buffers start at zero
-    for (int i = tid; i < CARRY * ROWB / 16; i += 256) {
+    for (int i = tid; i < CARRY * ROWB / 16; i += 512) {
         reinterpret_cast<uint4*>(bufX)[i] = make_uint4(0, 0, 0, 0);
         reinterpret_cast<uint4*>(bufY)[i] = make_uint4(0, 0, 0, 0);
     }
+    // tokens of the whole window (sequence.py:170-193, closed form): toks[j] = token of position j-5;
+    // positions < 0 select the all-zero row 257 of conv1_kz, positions >= 5997 (tail of the last
+    // step, never used by a valid output) get token 0
+    for (int j = tid; j < TOK_COUNT; j += 512) {
+        const int t = j - CARRY;
+        uint32_t tok = GNN_DEPTH;
+        if (t >= 0) {
+            tok = 0;
+            if (t < T) {
+                const int c0 = base_code_f(bases[t]), c1 = base_code_f(bases[t + 1]),
+                          c2 = base_code_f(bases[t + 2]), c3 = base_code_f(bases[t + 3]);
+                if ((c0 | c1 | c2 | c3) >= 0) tok = 1u + (uint32_t)(c0 * 64 + c1 * 16 + c2 * 4 + c3);
+            }
+        }
+        toks[j] = (uint16_t)tok;
+    }
+    __syncthreads();
+    if (helper) conv1_gather(bufX, toks, a.conv1_k, a.conv1_b, 0, ht);
+    else __builtin_amdgcn_s_setprio(2);      // the matrix waves win issue arbitration on their SIMD
 
     unsigned long long cyc[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     unsigned long long tick_ = 0;
-    if constexpr (PROF) tick_ = __builtin_readcyclecounter();
 
 #pragma unroll 1
     for (int step = 0; step < FSTEPS; ++step) {
         const int t0 = step * FT;
-        // ---- S0: tokens of positions t0-5 .. t0+127 (sequence.py:170-193, closed form) ----
-        if (tid < TOK_COUNT) {
-            const int t = t0 - CARRY + tid;
-            uint32_t tok = GNN_DEPTH;                     // position < 0: the all-zero row 257 of conv1_kz
-            if (t >= 0) {
-                tok = 0;
-                if (t < T) {
-                    const int c0 = base_code_f(bases[t]), c1 = base_code_f(bases[t + 1]),
-                              c2 = base_code_f(bases[t + 2]), c3 = base_code_f(bases[t + 3]);
-                    if ((c0 | c1 | c2 | c3) >= 0) tok = 1u + (uint32_t)(c0 * 64 + c1 * 16 + c2 * 4 + c3);
-                }
-            }
-            toks[tid] = (uint16_t)tok;
-        }
-        __syncthreads();
-        GNN_TICK(0)
-        // ---- S1: conv1 as a 6-row gather-sum + LeakyReLU -> x1 (bufX rows 5..132) ----
-        {
-            const int cq = tid & 31;                      // 4 channels
-            const f32x4 b = *reinterpret_cast<const f32x4*>(a.conv1_b + cq * 4);
-#pragma unroll 4
-            for (int it = 0; it < FT / 8; ++it) {
-                const int u = (tid >> 5) + it * 8;
-                f32x4 v = b;
-#pragma unroll
-                for (int k = 0; k < KS; ++k) {
-                    const uint32_t tk = toks[u + k];
-                    v += *reinterpret_cast<const f32x4*>(a.conv1_k + ((size_t)k * (GNN_DEPTH + 1) + tk) * C + cq * 4);
-                }
-#pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] = lrelu_f(v[e]);
-                const bf16x4 h = __builtin_convertvector(v, bf16x4);
-                const bf16x4 l = __builtin_convertvector(v - __builtin_convertvector(h, f32x4), bf16x4);
-                unsigned char* o = bufX + (CARRY + u) * ROWB + cq * 8;
-                *reinterpret_cast<uint2*>(o) = __builtin_bit_cast(uint2, h);
-                *reinterpret_cast<uint2*>(o + LO_OFF) = __builtin_bit_cast(uint2, l);
-            }
-        }
-        __syncthreads();
-        GNN_TICK(1)
-        // ---- S2: head A on x1, conv2: x1 -> x2 ----
-        m_partials(bufX, a.weff[0], a.pos_sorted[0], t0, a.bucket_ptr[0][step], a.bucket_ptr[0][step + 1], mp_w[0], wave, lane);
-        GNN_TICK(2)
-        wv_pool<PASSES>(bufX, vfrag[0], yp_w[0], t0, wave, lane);
-        GNN_TICK(3)
-        {
+        __syncthreads();                                                         // ---- B0
+        if constexpr (PROF) tick_ = step == 0 ? __builtin_readcyclecounter() : tick_;
+        if (!helper) {
+            GNN_TICK(7)
+            wv_pool<PASSES>(bufX, vfrag[0], yp_w[0], t0, hw, lane);
+            GNN_TICK(0)
             f32x16 acc[4];
 #pragma unroll
             for (int mb = 0; mb < 4; ++mb)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[mb][r] = 0.f;
             gemm_tile<true, KS, PASSES>(bufX, cfrag[0], acc, lane);
-            GNN_TICK(4)
-            conv_epilogue(bufY, a.conv_b[0], acc, wave, lane);
-        }
-        __syncthreads();
-        GNN_TICK(5)
-        // ---- S3: save the x1 carry, conv3: x2 -> x3 (into bufX) ----
-        if (tid < CARRY * 32) {   // 5 rows x 512 B
-            const int r = tid >> 5, c = tid & 31;
-            *reinterpret_cast<uint4*>(bufX + r * ROWB + c * 16) = *reinterpret_cast<const uint4*>(bufX + (FT + r) * ROWB + c * 16);
-        }
-        {
-            f32x16 acc[4];
+            GNN_TICK(1)
+            __syncthreads();                                                     // ---- B1
+            GNN_TICK(2)
+            conv_epilogue(bufY, a.conv_b[0], acc, hw, lane);
+            __syncthreads();                                                     // ---- B2
+            GNN_TICK(3)
 #pragma unroll
             for (int mb = 0; mb < 4; ++mb)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[mb][r] = 0.f;
             gemm_tile<true, KS, PASSES>(bufY, cfrag[1], acc, lane);
-            __syncthreads();      // every wave is done reading bufY and the x1 carry rows
+            GNN_TICK(4)
+            __syncthreads();                                                     // ---- B3
+            GNN_TICK(5)
+            conv_epilogue(bufY, a.conv_b[1], acc, hw, lane);
+            __syncthreads();                                                     // ---- B4
             GNN_TICK(6)
-            conv_epilogue(bufX, a.conv_b[1], acc, wave, lane);
+            wv_pool<PASSES>(bufY, vfrag[1], yp_w[1], t0, hw, lane);
+        } else {
+            if (step > 0)
+                m_partials(bufY, a.weff[1], a.pos_sorted[1], t0 - FT, a.bucket_ptr[1][step - 1], a.bucket_ptr[1][step],
+                           mp_w[1], hw, lane);
+            m_partials(bufX, a.weff[0], a.pos_sorted[0], t0, a.bucket_ptr[0][step], a.bucket_ptr[0][step + 1], mp_w[0], hw, lane);
+            uint4 carry = make_uint4(0, 0, 0, 0);
+            const int cr = ht >> 5, cc = ht & 31;        // 5 rows x 32 chunks of 16 B (hi+lo = 512 B)
+            if (ht < CARRY * 32) carry = *reinterpret_cast<const uint4*>(bufX + (FT + cr) * ROWB + cc * 16);
+            GNN_TICK(8)
+            __syncthreads();                                                     // ---- B1
+            if (ht < CARRY * 32) *reinterpret_cast<uint4*>(bufX + cr * ROWB + cc * 16) = carry;
+            __syncthreads();                                                     // ---- B2
+            if constexpr (PROF) tick_ = __builtin_readcyclecounter();
+            if (step + 1 < FSTEPS) conv1_gather(bufX, toks, a.conv1_k, a.conv1_b, t0 + FT, ht);
+            if (ht < CARRY * 32) carry = *reinterpret_cast<const uint4*>(bufY + (FT + cr) * ROWB + cc * 16);
+            GNN_TICK(9)
+            __syncthreads();                                                     // ---- B3
+            if (ht < CARRY * 32) *reinterpret_cast<uint4*>(bufY + cr * ROWB + cc * 16) = carry;
+            __syncthreads();                                                     // ---- B4
+            if constexpr (PROF) tick_ = __builtin_readcyclecounter();
         }
-        if (tid < CARRY * 32) {   // x2 carry for the next step
-            const int r = tid >> 5, c = tid & 31;
-            *reinterpret_cast<uint4*>(bufY + r * ROWB + c * 16) = *reinterpret_cast<const uint4*>(bufY + (FT + r) * ROWB + c * 16);
-        }
-        __syncthreads();
-        GNN_TICK(7)
-        // ---- S4: head B on x3 ----
-        m_partials(bufX, a.weff[1], a.pos_sorted[1], t0, a.bucket_ptr[1][step], a.bucket_ptr[1][step + 1], mp_w[1], wave, lane);
-        GNN_TICK(8)
-        wv_pool<PASSES>(bufX, vfrag[1], yp_w[1], t0, wave, lane);
-        __syncthreads();          // bufX is rewritten by S1 of the next step
-        GNN_TICK(9)
     }
+    if (helper)
+        m_partials(bufY, a.weff[1], a.pos_sorted[1], (FSTEPS - 1) * FT, a.bucket_ptr[1][FSTEPS - 1], a.bucket_ptr[1][FSTEPS],
+                   mp_w[1], hw, lane);
     if constexpr (PROF) {
         if (tid == 0)
-            for (int i = 0; i < 10; ++i) atomicAdd(a.cycles + i, cyc[i]);
+            for (int i = 0; i < 8; ++i) atomicAdd(a.cycles + i, cyc[i]);
+        if (tid == 256)
+            for (int i = 8; i < 10; ++i) atomicAdd(a.cycles + i, cyc[i]);
     }
 }
 
@@ -447,11 +504,11 @@ int launch_front_fused(gnn_ctx* ctx, const uint8_t* bases, int64_t n, int precis
     a.cycles = ctx->phase_cycles;
     const bool prof = ctx->phase_cycles != nullptr;
     if (precision == GNN_PREC_BF16X3) {
-        if (prof) hipLaunchKernelGGL((fused_front_kernel<3, true>), dim3((unsigned)n), dim3(256), 0, ctx->stream, a);
-        else hipLaunchKernelGGL((fused_front_kernel<3, false>), dim3((unsigned)n), dim3(256), 0, ctx->stream, a);
+        if (prof) hipLaunchKernelGGL((fused_front_kernel<3, true>), dim3((unsigned)n), dim3(512), 0, ctx->stream, a);
+        else hipLaunchKernelGGL((fused_front_kernel<3, false>), dim3((unsigned)n), dim3(512), 0, ctx->stream, a);
     } else {
-        if (prof) hipLaunchKernelGGL((fused_front_kernel<1, true>), dim3((unsigned)n), dim3(256), 0, ctx->stream, a);
-        else hipLaunchKernelGGL((fused_front_kernel<1, false>), dim3((unsigned)n), dim3(256), 0, ctx->stream, a);
+        if (prof) hipLaunchKernelGGL((fused_front_kernel<1, true>), dim3((unsigned)n), dim3(512), 0, ctx->stream, a);
+        else hipLaunchKernelGGL((fused_front_kernel<1, false>), dim3((unsigned)n), dim3(512), 0, ctx->stream, a);
     }
     GNN_HIP(hipGetLastError());
     return GNN_OK;
