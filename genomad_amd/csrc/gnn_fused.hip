@@ -288,7 +288,10 @@ __device__ __forceinline__ void conv1_gather(unsigned char* __restrict__ xbuf, c
                                              int t0, int ht) {
     const int cq = ht & 31;
     const f32x4 b = *reinterpret_cast<const f32x4*>(b1 + cq * 4);
-#pragma unroll 4
+#ifndef GNN_GATHER_UNROLL
+#define GNN_GATHER_UNROLL 4
+#endif
+#pragma unroll GNN_GATHER_UNROLL
     for (int it = 0; it < FT / 8; ++it) {
         const int u = (ht >> 5) + it * 8;
         f32x4 v = b;
@@ -360,7 +363,9 @@ __global__ __launch_bounds__(512, 2) void fused_front_kernel(FusedArgs a) {
     }
     __syncthreads();
     if (helper) conv1_gather(bufX, toks, a.conv1_k, a.conv1_b, 0, ht);
+#ifndef GNN_NO_SETPRIO
     else __builtin_amdgcn_s_setprio(2);      // the matrix waves win issue arbitration on their SIMD
+#endif
 
     unsigned long long cyc[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     unsigned long long tick_ = 0;

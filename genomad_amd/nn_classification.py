@@ -1,0 +1,299 @@
+"""Drop-in replacement for ``genomad.modules.nn_classification`` on MI355X.
+
+    genomad_amd.nn_classification.main(input_path, output_path, single_window, batch_size,
+                                       restart, threads, verbose, cleanup)
+
+has the signature, the on-disk outputs, the resume rules and the error behaviour of the
+reference's ``main`` (genomad/modules/nn_classification.py:21-427); ``install()`` rebinds
+``genomad.nn_classification`` / ``genomad.modules.nn_classification`` so that ``genomad
+nn-classification`` and ``genomad end-to-end`` (cli.py:772, :1367-1376) pick it up unchanged.
+
+What differs inside: windows are tokenised and classified by libgenomad_nn_hip.so (no TensorFlow,
+no TFRecord round trip).  ``<prefix>_encoded_sequences/`` holds ``<prefix>_seq_window_id.npz``
+(same keys as the reference) and the padded windows as ``<n>.win.npy`` instead of ``*.tfrec``.
+``threads`` is accepted and ignored (it only sized TensorFlow's pools, :39-40); ``batch_size``
+bounds the windows per GPU launch (results do not depend on it).
+
+Weights: ``$GENOMAD_AMD_WEIGHTS`` or ``<genomad data dir>/nn_classifier.npz`` in the schema of
+genomad_amd/weights.py.  With WORLD_SIZE > 1 (torch.distributed.run, one process per GPU) the
+windows are sharded across ranks and rank 0 writes the files.
+"""
+import hashlib
+import io
+import json
+import os
+import shutil
+import sys
+from datetime import datetime, timezone
+from pathlib import Path
+
+import numpy as np
+
+from . import sequence
+
+MODULE_NAME = "nn_classification"   # utils.write_execution_info("nn_classification", ...) :207-212
+TSV_HEADER = "seq_name\tchromosome_score\tplasmid_score\tvirus_score\n"   # :345
+
+
+class Outputs:
+    """File naming contract, genomad/_paths.py:188-236 (+ the find-proviruses files that
+    utils.check_provirus_execution reads, utils.py:280-297)."""
+
+    def __init__(self, prefix: str, output_dir: Path):
+        o, p = Path(output_dir), prefix
+        self.nn_classification_log = o / f"{p}_nn_classification.log"
+        d = self.nn_classification_dir = o / f"{p}_nn_classification"
+        self.nn_classification_execution_info = d / f"{p}_nn_classification.json"
+        self.encoded_sequences_dir = d / f"{p}_encoded_sequences"
+        self.seq_window_id_output = self.encoded_sequences_dir / f"{p}_seq_window_id.npz"
+        self.nn_classification_output = d / f"{p}_nn_classification.tsv"
+        self.nn_classification_npz_output = d / f"{p}_nn_classification.npz"
+        self.encoded_proviruses_dir = d / f"{p}_encoded_proviruses"
+        self.provirus_window_id_output = self.encoded_proviruses_dir / f"{p}_provirus_window_id.npz"
+        self.provirus_nn_classification_output = d / f"{p}_provirus_nn_classification.tsv"
+        self.provirus_nn_classification_npz_output = d / f"{p}_provirus_nn_classification.npz"
+        f = o / f"{p}_find_proviruses"
+        self.find_proviruses_execution_info = f / f"{p}_find_proviruses.json"
+        self.find_proviruses_output = f / f"{p}_provirus.tsv"
+        self.find_proviruses_nucleotide_output = f / f"{p}_provirus.fna"
+        self.find_proviruses_proteins_output = f / f"{p}_provirus_proteins.faa"
+        self.find_proviruses_genes_output = f / f"{p}_provirus_genes.tsv"
+
+
+class Console:
+    """Minimal stand-in for utils.HybridConsole (utils.py:42-123): messages go to stdout (unless
+    quiet) and are appended to the log file, which is deleted at construction if it exists."""
+
+    def __init__(self, output_file=None, verbose=True):
+        self.output_file, self.verbose = output_file, verbose
+        if output_file and Path(output_file).exists():
+            Path(output_file).unlink()
+
+    def _emit(self, msg, stream):
+        line = f"[{datetime.now().strftime('%X')}] {msg}"
+        if stream is not None:
+            print(line, file=stream, flush=True)
+        if self.output_file:
+            with open(self.output_file, "a") as fout:
+                fout.write(line + "\n")
+
+    def log(self, msg, **_):
+        self._emit(msg, sys.stdout if self.verbose else None)
+
+    def error(self, msg, **_):
+        self._emit(msg, sys.stderr)
+
+
+def get_md5(path, size=io.DEFAULT_BUFFER_SIZE) -> str:   # utils.py:216-223
+    m = hashlib.md5()
+    with open(path, "rb") as fin:
+        for block in iter(lambda: fin.read(size), b""):
+            m.update(block)
+    return m.hexdigest()
+
+
+def write_execution_info(module_name, input_file: Path, parameters: dict, output_file: Path):
+    """utils.py:238-254, byte for byte (indent=4, trailing newline, local-tz ISO start time)."""
+    dump = json.dumps({"module": module_name, "input": Path(input_file).name,
+                       "input_md5": get_md5(input_file),
+                       "start_time": datetime.now(timezone.utc).astimezone().isoformat(),
+                       "parameters": parameters}, indent=4)
+    with open(output_file, "w") as fout:
+        fout.write(f"{dump}\n")
+
+
+def compare_executions(input_file, parameters, execution_info_file) -> bool:   # utils.py:266-277
+    with open(execution_info_file) as fin:
+        info = json.load(fin)
+    return parameters == info["parameters"] and get_md5(input_file) == info["input_md5"]
+
+
+def check_provirus_execution(outputs: Outputs, input_file) -> bool:   # utils.py:280-297
+    if not outputs.find_proviruses_execution_info.exists():
+        return False
+    with open(outputs.find_proviruses_execution_info) as fin:
+        if get_md5(input_file) != json.load(fin)["input_md5"]:
+            return False
+    required = [outputs.find_proviruses_output, outputs.find_proviruses_nucleotide_output,
+                outputs.find_proviruses_proteins_output, outputs.find_proviruses_genes_output]
+    if not all(p.exists() for p in required):
+        return False
+    with sequence.open_text(outputs.find_proviruses_output) as fin:
+        next(fin, None)
+        return sum(1 for _ in fin) > 0
+
+
+def write_tsv(path, names, predictions):
+    """nn_classification.py:344-348: '%.4f' columns joined by tabs, no trailing tab."""
+    with open(path, "w") as fout:
+        fout.write(TSV_HEADER)
+        for name, scores in zip(names, predictions):
+            row = "".join(map(lambda x: f"{x:.4f}\t", scores)).strip()
+            fout.write(f"{name}\t{row}\n")
+
+
+def find_weights() -> Path:
+    cand = []
+    if os.environ.get("GENOMAD_AMD_WEIGHTS"):
+        cand.append(Path(os.environ["GENOMAD_AMD_WEIGHTS"]))
+    try:
+        from genomad._paths import GenomadData   # only when the reference package is installed
+        cand.append(Path(GenomadData.nn_model_file).with_suffix(".npz"))
+    except Exception:  # noqa: BLE001
+        pass
+    for c in cand:
+        if c.is_file():
+            return c
+    raise FileNotFoundError(
+        "nn classifier weights not found: set GENOMAD_AMD_WEIGHTS to an .npz in the schema of "
+        "genomad_amd/weights.py (the reference's nn_classifier.h5 must be converted once)")
+
+
+_ENGINE = None
+
+
+def _engine():
+    """One engine per process (the reference builds its Keras model twice, :309 and :379; here the
+    weights are uploaded once and reused for the provirus pass)."""
+    global _ENGINE
+    if _ENGINE is None:
+        from . import weights as W
+        from .engine import NNEngine
+        # the reference module sets CUDA_VISIBLE_DEVICES=-1 at import (nn_classification.py:8), which
+        # HIP honours; undo it before the HIP runtime is initialised
+        if os.environ.get("CUDA_VISIBLE_DEVICES") == "-1":
+            del os.environ["CUDA_VISIBLE_DEVICES"]
+        device = int(os.environ.get("GENOMAD_AMD_DEVICE", os.environ.get("LOCAL_RANK", "0")))
+        _ENGINE = NNEngine(device, W.load_npz(find_weights()))
+    return _ENGINE
+
+
+class GpuBackend:
+    """Scores windows and averages them per contig on the GPU (libgenomad_nn_hip.so)."""
+
+    def __init__(self, batch_size: int):
+        self.eng = _engine()
+        self.chunk = max(int(batch_size), 4096)
+        self.precision = os.environ.get("GENOMAD_AMD_PRECISION", "bf16x3")
+
+    def score(self, windows: np.ndarray) -> np.ndarray:
+        out = [self.eng.classify(windows[a:a + self.chunk], self.precision)
+               for a in range(0, len(windows), self.chunk)]
+        return np.concatenate(out) if out else np.zeros((0, 3), np.float32)
+
+    def segment_mean(self, scores, ids, n_segments) -> np.ndarray:
+        return self.eng.segment_mean(scores, ids, n_segments)
+
+
+def classify_windows(windows: np.ndarray, contig_ids: np.ndarray, n_contigs: int, backend):
+    """Window scores -> per-contig mean (nn_classification.py:316-320), sharded over ranks when
+    torch.distributed is initialised (rank 0 gets the result, other ranks None)."""
+    from . import sharding
+    scores = sharding.classify_sharded(windows, backend.score)
+    if scores is None:
+        return None
+    return backend.segment_mean(scores, contig_ids, n_contigs)
+
+
+def _encode(fasta_path, enc_dir: Path, window_id_path: Path, single_window: bool, names_key: str, ids_key: str):
+    names, ids, windows = sequence.encode_fasta(fasta_path, single_window)
+    np.save(enc_dir / f"{len(windows)}.win.npy", windows)
+    np.savez_compressed(window_id_path, **{names_key: names, ids_key: ids})
+    return names, ids, windows
+
+
+def main(input_path, output_path, single_window, batch_size, restart, threads, verbose, cleanup,
+         _backend=None):
+    """``_backend`` (tests only) replaces the GPU engine with an object offering score() and
+    segment_mean(); the product path always builds a :class:`GpuBackend` and fails without a GPU."""
+    input_path, output_path = Path(input_path), Path(output_path)
+    rank0 = int(os.environ.get("RANK", "0")) == 0
+    if not output_path.is_dir():
+        output_path.mkdir(exist_ok=True)
+    prefix = sequence.prefix_of(input_path)
+    outputs = Outputs(prefix, output_path)
+    console = Console(output_file=outputs.nn_classification_log if rank0 else None, verbose=verbose and rank0)
+    parameter_dict = {"single_window": single_window}
+    classify_proviruses = check_provirus_execution(outputs, input_path)
+    output_files = [outputs.nn_classification_execution_info, outputs.encoded_sequences_dir,
+                    outputs.nn_classification_output, outputs.nn_classification_npz_output]
+    if classify_proviruses:
+        output_files += [outputs.encoded_proviruses_dir, outputs.provirus_nn_classification_output,
+                         outputs.provirus_nn_classification_npz_output]
+    console.log(f"Executing geNomad nn-classification (genomad_amd, MI355X). Outputs in {outputs.nn_classification_dir}.")
+
+    if not sequence.check_fasta(input_path):                                   # :164-170
+        console.error(f"{input_path} is either empty or contains multiple entries with the same identifier. "
+                      "Please check your input FASTA file and execute genomad nn-classification again.")
+        sys.exit(1)
+
+    skip = False                                                               # :175-197
+    if (outputs.nn_classification_execution_info.exists() and any(p.exists() for p in output_files) and not restart):
+        if compare_executions(input_path, parameter_dict, outputs.nn_classification_execution_info):
+            skip = True
+            console.log("Previous execution detected. Steps will be skipped unless their outputs are not found. "
+                        "Use the --restart option to force the execution of all the steps again.")
+        else:
+            console.log("The input file or the parameters changed since the last execution. "
+                        "Previous outputs will be overwritten.")
+    if rank0:
+        outputs.nn_classification_dir.mkdir(exist_ok=True)
+        write_execution_info(MODULE_NAME, input_path, parameter_dict, outputs.nn_classification_execution_info)
+
+    def stage(fasta, enc_dir, wid_path, npz_path, tsv_path, names_key, ids_key, what):
+        windows = None
+        if skip and wid_path.exists() and len(list(enc_dir.glob("*.win.npy"))):      # :215-225
+            console.log(f"{enc_dir.name} was found. Skipping {what} encoding.")
+            z = np.load(wid_path)
+            names, ids = z[names_key], z[ids_key]
+        else:
+            if rank0:
+                if enc_dir.is_dir():
+                    shutil.rmtree(enc_dir)
+                enc_dir.mkdir()
+                names, ids, windows = _encode(fasta, enc_dir, wid_path, single_window, names_key, ids_key)
+            else:
+                names, ids, windows = sequence.encode_fasta(fasta, single_window)
+            console.log(f"Encoded {what} data written to {enc_dir.name}.")
+        if skip and npz_path.exists():                                               # :284-292
+            console.log(f"{npz_path.name} was found. Skipping {what} classification.")
+            z = np.load(npz_path)
+            names, predictions = z[names_key], z["predictions"]
+        else:
+            if windows is None:
+                files = sorted(enc_dir.glob("*.win.npy"))
+                windows = np.concatenate([np.load(f) for f in files]) if files else np.zeros((0, 6000), np.uint8)
+            if not len(windows):                                                     # :297-299
+                console.error("No sequences were found. Please check your input FASTA.")
+                sys.exit(1)
+            backend = _backend if _backend is not None else GpuBackend(batch_size)
+            predictions = classify_windows(windows, ids, len(names), backend)
+            console.log(f"{what.capitalize()}s classified.")
+            if rank0:
+                np.savez_compressed(npz_path, **{names_key: names, "predictions": predictions})   # :326-330
+        if cleanup and rank0 and enc_dir.is_dir():                                   # :335-337
+            console.log(f"Deleting encoded {what} data.")
+            shutil.rmtree(enc_dir)
+        if rank0:
+            write_tsv(tsv_path, names, predictions)                                  # :340-352 (always rewritten)
+
+    stage(input_path, outputs.encoded_sequences_dir, outputs.seq_window_id_output,
+          outputs.nn_classification_npz_output, outputs.nn_classification_output,
+          "contig_names", "contig_ids", "sequence")
+    if classify_proviruses:                                                          # :248-281, :355-425
+        stage(outputs.find_proviruses_nucleotide_output, outputs.encoded_proviruses_dir,
+              outputs.provirus_window_id_output, outputs.provirus_nn_classification_npz_output,
+              outputs.provirus_nn_classification_output, "provirus_names", "provirus_ids", "provirus")
+    console.log("geNomad nn-classification finished!")
+
+
+def install():
+    """Make the reference CLI use this module: ``genomad.nn_classification`` is looked up at call
+    time (cli.py:772, :1367), so rebinding the attribute is enough."""
+    import genomad
+    import genomad.modules
+    this = sys.modules[__name__]
+    genomad.nn_classification = this
+    genomad.modules.nn_classification = this
+    sys.modules["genomad.modules.nn_classification"] = this
+    return this

@@ -1,0 +1,145 @@
+"""Host-side FASTA -> padded 6 kbp windows, mirroring the reference's data preparation.
+
+Mirrors (same rules, same order, same error behaviour):
+  genomad/sequence.py:96-121   read_fasta(filepath, strip_n=True)
+  genomad/sequence.py:124-131  check_fasta
+  genomad/sequence.py:150-167  seq_windows(seq, 6000, 2500, max_windows)
+  genomad/modules/nn_classification.py:54-82  generate_data (window filter, upper-casing, ljust)
+without the per-window Python objects and the TFRecord round trip: a contig is turned into rows of
+one (n_windows, 6000) uint8 array with numpy slicing.  Tokenising and everything after it happens
+on the GPU (libgenomad_nn_hip.so).
+"""
+import bz2
+import gzip
+import lzma
+import sys
+from pathlib import Path
+from typing import Iterator, List, Tuple
+
+import numpy as np
+
+WINDOW = 6000
+MIN_TAIL = 2500
+MAX_N = 4000
+
+
+def compression_of(path) -> str:
+    """Magic-byte sniffing, genomad/utils.py:126-149: 'gzip' | 'bzip2' | 'xz' | 'zstd' | 'uncompressed'."""
+    with open(path, "rb") as fin:
+        sig = fin.read(8)
+    if sig[:2] == b"\x1f\x8b":
+        return "gzip"
+    if sig[:3] == b"\x42\x5a\x68":
+        return "bzip2"
+    if sig[:7] == b"\xfd\x37\x7a\x58\x5a\x00\x00":
+        return "xz"
+    if sig[:4] == b"\x28\xb5\x2f\xfd":
+        return "zstd"
+    return "uncompressed"
+
+
+def open_text(path):
+    """genomad/utils.py:152-168 (zstd only on Python >= 3.14, like the reference)."""
+    kind = compression_of(path)
+    if kind == "gzip":
+        return gzip.open(path, "rt")
+    if kind == "bzip2":
+        return bz2.open(path, "rt")
+    if kind == "xz":
+        return lzma.open(path, "rt")
+    if kind == "zstd" and sys.version_info >= (3, 14):
+        from compression import zstd  # type: ignore
+        return zstd.open(path, "rt")
+    return open(path, "r")
+
+
+def read_fasta(path, strip_n: bool = False) -> Iterator[Tuple[str, str]]:
+    """Yield (header, sequence).  Text before the first '>' is skipped, only the trailing newline
+    of every line is removed, ``strip_n`` strips leading/trailing n/N, empty records are dropped."""
+    with open_text(path) as fin:
+        header, chunks = None, []
+
+        def flush():
+            s = "".join(chunks)
+            if strip_n:
+                s = s.strip("nN")
+            return s
+
+        for line in fin:
+            if line[0] == ">":
+                if header is not None:
+                    s = flush()
+                    if len(s):
+                        yield header, s
+                header, chunks = line.removesuffix("\n")[1:], []
+            elif header is not None:
+                chunks.append(line.removesuffix("\n"))
+        if header is not None:
+            s = flush()
+            if len(s):
+                yield header, s
+
+
+def accession(header: str) -> str:
+    return header.split()[0]   # genomad/sequence.py:24-25
+
+
+def check_fasta(path) -> bool:
+    """False if the file has no record or two records share an accession (sequence.py:124-131)."""
+    acc = [accession(h) for h, _ in read_fasta(path)]
+    return bool(acc) and len(acc) == len(set(acc))
+
+
+def window_spans(length: int, single_window: bool = False) -> List[Tuple[int, int]]:
+    """seq_windows(seq, 6000, 2500, max_windows=1 if single_window else None) as (start, end)."""
+    spans, win = [], 0
+    while win * WINDOW < length:
+        a, b = win * WINDOW, min((win + 1) * WINDOW, length)
+        if b - a < MIN_TAIL:
+            if win == 0:
+                spans.append((a, b))
+            break
+        spans.append((a, b))
+        win += 1
+        if single_window and win == 1:
+            break
+    return spans
+
+
+def contig_windows(seq: str, single_window: bool = False) -> np.ndarray:
+    """(n, 6000) uint8: the windows generate_data keeps for one contig, upper-cased, 'N'-padded.
+
+    The skip rule counts literal upper-case 'N' on the RAW sequence (Sequence.count,
+    sequence.py:38-39) and never applies to window 0 (nn_classification.py:70-71).
+    """
+    raw = np.frombuffer(seq.encode("ascii"), dtype=np.uint8)
+    spans = window_spans(len(raw), single_window)
+    keep = [(a, b) for i, (a, b) in enumerate(spans)
+            if i == 0 or int(np.count_nonzero(raw[a:b] == 78)) <= MAX_N]
+    out = np.full((len(keep), WINDOW), 78, dtype=np.uint8)
+    if keep:
+        up = np.frombuffer(seq.upper().encode("ascii"), dtype=np.uint8)
+        for i, (a, b) in enumerate(keep):
+            out[i, :b - a] = up[a:b]
+    return out
+
+
+def encode_fasta(path, single_window: bool = False):
+    """(contig_names, contig_ids, windows) like generate_data (nn_classification.py:54-82): names are
+    accessions of the records that survive strip_n, ids index into them, one id per kept window."""
+    names, ids, wins = [], [], []
+    for cid, (header, seq) in enumerate(read_fasta(path, strip_n=True)):
+        names.append(accession(header))
+        w = contig_windows(seq, single_window)
+        wins.append(w)
+        ids.extend([cid] * len(w))
+    windows = np.concatenate(wins) if wins else np.zeros((0, WINDOW), dtype=np.uint8)
+    return np.array(names), np.array(ids, dtype=np.int64), windows
+
+
+def prefix_of(input_path: Path) -> str:
+    """nn_classification.py:106-108: stem, minus one more extension if the file is compressed."""
+    prefix = Path(input_path).stem
+    if compression_of(input_path) != "uncompressed":
+        prefix = prefix.rsplit(".", 1)[0]
+    return prefix

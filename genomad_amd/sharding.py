@@ -57,3 +57,25 @@ def gather_scores(local_scores, n_windows: int, group=None, dst: int = 0):
     if rank != dst:
         return None
     return torch.cat(recv, dim=0)[:n_windows]
+
+
+def classify_sharded(windows, score_fn):
+    """Score ``windows`` (n, 6000) with ``score_fn`` on this rank's contiguous shard and collect the
+    (n, 3) scores on rank 0 (returns None on the other ranks).  Without an initialised process group
+    this is just ``score_fn(windows)``."""
+    import numpy as np
+    try:
+        import torch.distributed as dist
+        distributed = dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+    except ImportError:
+        distributed = False
+    if not distributed:
+        return np.ascontiguousarray(score_fn(windows), dtype=np.float32)
+    import torch
+    world, rank = dist.get_world_size(), dist.get_rank()
+    a, b = shard_range(len(windows), world, rank)
+    local = torch.from_numpy(np.ascontiguousarray(score_fn(windows[a:b]), dtype=np.float32).reshape(b - a, 3))
+    if dist.get_backend() == "nccl":
+        local = local.cuda()
+    out = gather_scores(local, len(windows))
+    return None if out is None else out.cpu().numpy()

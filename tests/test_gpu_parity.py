@@ -209,3 +209,31 @@ def test_single_pass_bf16_is_outside_tolerance_but_sane(engine, oracle16):
     got = engine.classify(bases, "bf16")
     err = np.abs(got - scores64).max()
     assert 1e-4 < err < 5e-2, f"single-pass bf16 max |dscore| = {err:.3e}"
+
+
+# ------------------------------------------------------------------ drop-in entry point on the GPU
+def test_main_end_to_end_on_gpu(engine, synth_weights, tmp_path, monkeypatch):
+    """genomad_amd.nn_classification.main on a small FASTA: NPZ/TSV written, per-contig scores within
+    1e-4 of the oracle chain (reference windowing rules -> fp32 forward -> segment mean)."""
+    from genomad_amd import nn_classification as nnc
+    from genomad_amd import weights as W
+    rng = np.random.default_rng(9)
+    recs = [("ctgA", "".join(rng.choice(list("ACGT"), 20000))),
+            ("ctgB desc", "nn" + "".join(rng.choice(list("ACGTN"), 9000, p=[.24, .24, .24, .24, .04])) + "N"),
+            ("ctgC", "".join(rng.choice(list("acgt"), 2000)))]
+    fa = tmp_path / "mini.fna"
+    fa.write_text("".join(f">{n}\n{s}\n" for n, s in recs))
+    wpath = tmp_path / "w.npz"
+    W.save_npz(wpath, synth_weights)
+    monkeypatch.setenv("GENOMAD_AMD_WEIGHTS", str(wpath))
+    monkeypatch.setattr(nnc, "_ENGINE", engine)          # reuse the session engine (same weights)
+    out = tmp_path / "out"
+    nnc.main(fa, out, False, 128, False, 4, False, True)
+    z = np.load(out / "mini_nn_classification" / "mini_nn_classification.npz")
+    names, ids, wins = sequence_oracle.encode_fasta(fa)
+    want = sequence_oracle.segment_mean(igloo_oracle.classify_windows(wins, synth_weights, np.float32), ids)
+    assert list(z["contig_names"]) == list(names) == ["ctgA", "ctgB", "ctgC"]
+    assert np.abs(z["predictions"] - want).max() <= SCORE_TOL
+    tsv = (out / "mini_nn_classification" / "mini_nn_classification.tsv").read_text().splitlines()
+    assert tsv[1].split("\t")[1:] == [f"{x:.4f}" for x in z["predictions"][0]]
+    assert not (out / "mini_nn_classification" / "mini_encoded_sequences").exists()   # --cleanup

@@ -1,0 +1,198 @@
+"""CPU tests of the host side: FASTA/windowing mirror vs the reference goldens, the drop-in
+main() file contract (JSON / NPZ / TSV / resume / errors) with a fake scoring backend, sharding
+logic and the world_size-2 gloo gather."""
+import gzip
+import hashlib
+import json
+import os
+import sys
+
+import numpy as np
+import pytest
+
+from genomad_amd import nn_classification as nnc
+from genomad_amd import sequence, sharding
+from oracle import sequence_oracle
+
+
+class FakeBackend:
+    """Deterministic stand-in for the GPU (tests only): score = f(window bytes)."""
+
+    def score(self, windows):
+        w = np.asarray(windows, dtype=np.float64)
+        s = np.stack([(w == c).mean(axis=1) for c in (65, 67, 71)], axis=1) + 0.01
+        return (s / s.sum(axis=1, keepdims=True)).astype(np.float32)
+
+    def segment_mean(self, scores, ids, n):
+        out = sequence_oracle.segment_mean(np.asarray(scores, np.float32), np.asarray(ids))
+        return np.concatenate([out, np.zeros((n - len(out), 3), np.float32)])
+
+
+def test_encode_fasta_matches_reference_golden(golden_dir):
+    g = json.load(open(os.path.join(golden_dir, "fasta_golden.json")))
+    path = os.path.join(golden_dir, "fasta_fixture.fna.gz")
+    assert sequence.check_fasta(path) == g["check_fasta"]
+    assert sequence.prefix_of(path) == "fasta_fixture"
+    for key, single in (("all", False), ("single", True)):
+        names, ids, wins = sequence.encode_fasta(path, single)
+        assert list(names) == g[key]["contig_names"] and list(ids) == g[key]["contig_ids"]
+        toks = sequence_oracle.tokenize_closed_form(wins).astype("<u2")
+        dig = [hashlib.sha256(w.tobytes()).hexdigest()[:16] + ":" + hashlib.sha256(t.tobytes()).hexdigest()[:16]
+               for w, t in zip(wins, toks)]
+        assert dig == g[key]["window_digests"]
+
+
+def test_window_spans_match_reference_golden(golden_dir):
+    g = json.load(open(os.path.join(golden_dir, "windowing_golden.json")))["window_lengths"]
+    for L, want in g.items():
+        assert [b - a for a, b in sequence.window_spans(int(L))] == want["all"]
+        assert [b - a for a, b in sequence.window_spans(int(L), True)] == want["single"]
+
+
+def _write_fasta(path, recs, gz=False):
+    text = "".join(f">{n}\n{s}\n" for n, s in recs)
+    if gz:
+        with gzip.open(path, "wt") as f:
+            f.write(text)
+    else:
+        path.write_text(text)
+
+
+def test_main_file_contract_and_resume(tmp_path):
+    rng = np.random.default_rng(5)
+    recs = [("c1 some description", "".join(rng.choice(list("ACGT"), 13000))),
+            ("c2", "NN" + "".join(rng.choice(list("ACGT"), 2600)) + "nn"),
+            ("c3", "N" * 50)]
+    fa = tmp_path / "sample.fna.gz"
+    _write_fasta(fa, recs, gz=True)
+    out = tmp_path / "out"
+    nnc.main(fa, out, False, 128, False, 1, False, False, _backend=FakeBackend())
+    d = out / "sample_nn_classification"
+    info = json.loads((d / "sample_nn_classification.json").read_text())
+    assert list(info) == ["module", "input", "input_md5", "start_time", "parameters"]
+    assert info["module"] == "nn_classification" and info["input"] == "sample.fna.gz"
+    assert info["parameters"] == {"single_window": False}
+    assert info["input_md5"] == hashlib.md5(fa.read_bytes()).hexdigest()
+    assert (d / "sample_nn_classification.json").read_text().endswith("}\n")
+    z = np.load(d / "sample_nn_classification.npz")
+    assert list(z["contig_names"]) == ["c1", "c2"]                 # the all-N record is dropped
+    assert z["predictions"].shape == (2, 3) and z["predictions"].dtype == np.float32
+    wid = np.load(d / "sample_encoded_sequences" / "sample_seq_window_id.npz")
+    assert list(wid["contig_ids"]) == [0, 0, 1]                    # 13000 -> 6000+6000(+1000 dropped); 2600 -> 1
+    lines = (d / "sample_nn_classification.tsv").read_text().splitlines()
+    assert lines[0] == "seq_name\tchromosome_score\tplasmid_score\tvirus_score"
+    name, *vals = lines[1].split("\t")
+    assert name == "c1" and len(vals) == 3 and all(len(v.split(".")[1]) == 4 for v in vals)
+    assert vals == [f"{x:.4f}" for x in z["predictions"][0]]
+    assert (out / "sample_nn_classification.log").exists()
+    # per-contig mean of window scores
+    _, ids, wins = sequence.encode_fasta(fa)
+    fb = FakeBackend()
+    assert np.allclose(z["predictions"], fb.segment_mean(fb.score(wins), ids, 2))
+
+    # resume: same input+params -> classification skipped (a backend that must not be called)
+    class Boom:
+        def score(self, w):
+            raise AssertionError("classification should have been skipped")
+        segment_mean = FakeBackend.segment_mean
+    nnc.main(fa, out, False, 128, False, 1, False, False, _backend=Boom())
+    # changed parameter -> recomputed; --cleanup removes the encoded directory
+    nnc.main(fa, out, True, 128, False, 1, False, True, _backend=FakeBackend())
+    assert not (d / "sample_encoded_sequences").exists()
+    assert json.loads((d / "sample_nn_classification.json").read_text())["parameters"] == {"single_window": True}
+    # restart forces recomputation even if nothing changed
+    with pytest.raises(AssertionError, match="skipped"):
+        nnc.main(fa, out, True, 128, True, 1, False, False, _backend=Boom())
+
+
+def test_main_errors_exit_1(tmp_path, capsys):
+    dup = tmp_path / "dup.fna"
+    _write_fasta(dup, [("a", "ACGT" * 10), ("a", "ACGT" * 10)])
+    with pytest.raises(SystemExit) as e:
+        nnc.main(dup, tmp_path / "o1", False, 128, False, 1, False, False, _backend=FakeBackend())
+    assert e.value.code == 1
+    empty = tmp_path / "empty.fna"
+    empty.write_text("")
+    with pytest.raises(SystemExit) as e:
+        nnc.main(empty, tmp_path / "o2", False, 128, False, 1, False, False, _backend=FakeBackend())
+    assert e.value.code == 1
+    alln = tmp_path / "alln.fna"                                   # passes check_fasta, yields no window
+    _write_fasta(alln, [("a", "N" * 100)])
+    with pytest.raises(SystemExit) as e:
+        nnc.main(alln, tmp_path / "o3", False, 128, False, 1, False, False, _backend=FakeBackend())
+    assert e.value.code == 1
+    assert "No sequences were found" in capsys.readouterr().err
+
+
+def test_provirus_pass_runs_when_find_proviruses_outputs_exist(tmp_path):
+    fa = tmp_path / "g.fna"
+    _write_fasta(fa, [("c1", "ACGT" * 2000)])
+    out = tmp_path / "out"
+    fp = out / "g_find_proviruses"
+    fp.mkdir(parents=True)
+    (fp / "g_find_proviruses.json").write_text(json.dumps({"input_md5": nnc.get_md5(fa), "module": "x", "parameters": {}}))
+    (fp / "g_provirus.tsv").write_text("h\nc1|provirus_1_4000\n")
+    _write_fasta(fp / "g_provirus.fna", [("c1|provirus_1_4000", "ACGT" * 1000)])
+    (fp / "g_provirus_proteins.faa").write_text("")
+    (fp / "g_provirus_genes.tsv").write_text("")
+    nnc.main(fa, out, False, 128, False, 1, False, False, _backend=FakeBackend())
+    z = np.load(out / "g_nn_classification" / "g_provirus_nn_classification.npz")
+    assert list(z["provirus_names"]) == ["c1|provirus_1_4000"] and z["predictions"].shape == (1, 3)
+    assert (out / "g_nn_classification" / "g_provirus_nn_classification.tsv").exists()
+
+
+def test_product_path_fails_loudly_without_gpu_or_weights(tmp_path, monkeypatch):
+    monkeypatch.delenv("GENOMAD_AMD_WEIGHTS", raising=False)
+    monkeypatch.setattr(nnc, "_ENGINE", None)
+    fa = tmp_path / "g.fna"
+    _write_fasta(fa, [("c1", "ACGT" * 2000)])
+    with pytest.raises((FileNotFoundError, RuntimeError)):
+        nnc.main(fa, tmp_path / "out", False, 128, False, 1, False, False)
+
+
+def test_shard_ranges_cover_and_order():
+    for n in (0, 1, 7, 8, 9, 1000, 1_000_000):
+        for g in (1, 2, 3, 8):
+            r = [sharding.shard_range(n, g, k) for k in range(g)]
+            assert r[0][0] == 0 and r[-1][1] == n
+            assert all(r[i][1] == r[i + 1][0] for i in range(g - 1))
+            assert sum(sharding.shard_counts(n, g)) == n
+    with pytest.raises(ValueError):
+        sharding.shard_range(10, 2, 2)
+
+
+def _gloo_worker(rank, world, port, n, q):
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    rng = np.random.default_rng(0)
+    windows = rng.integers(65, 85, (n, 6000), dtype=np.uint8)
+    out = sharding.classify_sharded(windows, FakeBackend().score)
+    if rank == 0:
+        q.put(out)
+    else:
+        assert out is None
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("n", [11, 4])
+def test_gloo_world_size_2_gather_equals_single_process(n):
+    """N>1 path on CPU: two ranks shard the windows, rank 0 gathers; result must equal the
+    single-process scores bit for bit (no cross-rank reduction is involved)."""
+    mp = pytest.importorskip("torch.multiprocessing")
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_gloo_worker, args=(r, 2, port, n, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = q.get(timeout=120)
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    rng = np.random.default_rng(0)
+    windows = rng.integers(65, 85, (n, 6000), dtype=np.uint8)
+    assert np.array_equal(got, FakeBackend().score(windows))
