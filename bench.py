@@ -198,7 +198,10 @@ def main():
         traffic = None
         tpath = os.path.join(ROOT, "profiles", "hbm_traffic.json")
         if os.path.exists(tpath):
-            traffic = json.load(open(tpath)).get(args.precision)
+            # measured in separate rocprofv3 --pmc passes of this command (profiles/README.md); per launch
+            per_window = json.load(open(tpath)).get("bytes_per_window", {}).get(args.precision)
+            if per_window is not None:
+                traffic = int(per_window * win_per_launch)
         out["roofline"] = {
             "bound": "mfma", "achieved": round(tflops, 2), "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
             "frac": round(tflops / MFMA_PEAK_TFLOPS, 4), "traffic": traffic,
