@@ -329,11 +329,36 @@ int gnn_load_weights(gnn_ctx* ctx, const gnn_weights* w) {
         if ((rc = upload(ctx, g->w_v, (size_t)C * C, &d.w_v[h]))) return rc;
     }
     {
-        std::vector<float> kz((size_t)KS * (GNN_DEPTH + 1) * C, 0.f);
-        for (int k = 0; k < KS; ++k)
-            std::memcpy(&kz[(size_t)k * (GNN_DEPTH + 1) * C], w->conv1_kernel + (size_t)k * GNN_DEPTH * C,
-                        (size_t)GNN_DEPTH * C * sizeof(float));
-        if ((rc = upload(ctx, kz.data(), kz.size(), &d.conv1_kz))) return rc;
+        // conv1 pair tables.  conv1 on the one-hot input is sum_k W1[k][tok[t-5+k]] (model.py:11 +
+        // igloo.py:45-47).  Tokens of adjacent positions share 3 bases, so the pair (tok[s], tok[s+1])
+        // has only 1795 possible values (PAIR_ROWS, see pair_row() in gnn_fused.hip); tabulating
+        // W1[2j][a] + W1[2j+1][b] for the three tap pairs j halves the rows the fused kernel gathers.
+        const float* k1 = w->conv1_kernel;
+        std::vector<float> pt((size_t)3 * PAIR_ROWS * C, 0.f);
+        auto row = [&](int j, int r) { return &pt[((size_t)j * PAIR_ROWS + r) * C]; };
+        auto add = [&](float* dst, int k, int tok) {
+            const float* src = k1 + ((size_t)k * GNN_DEPTH + tok) * C;
+            for (int c = 0; c < C; ++c) dst[c] += src[c];
+        };
+        for (int j = 0; j < 3; ++j) {
+            for (int code5 = 0; code5 < 1024; ++code5) {          // both 4-mers valid: a 5-mer
+                add(row(j, code5), 2 * j, 1 + (code5 >> 2));
+                add(row(j, code5), 2 * j + 1, 1 + (code5 & 255));
+            }
+            for (int b = 1; b <= 256; ++b) {                       // first 4-mer has an N (token 0)
+                add(row(j, 1024 + b - 1), 2 * j, 0);
+                add(row(j, 1024 + b - 1), 2 * j + 1, b);
+            }
+            for (int a = 1; a <= 256; ++a) {                       // second 4-mer has an N
+                add(row(j, 1280 + a - 1), 2 * j, a);
+                add(row(j, 1280 + a - 1), 2 * j + 1, 0);
+            }
+            add(row(j, 1536), 2 * j, 0);                           // both have an N
+            add(row(j, 1536), 2 * j + 1, 0);
+            // row 1537: both positions before the window start (causal zero padding) -> zeros
+            for (int b = 0; b <= 256; ++b) add(row(j, 1538 + b), 2 * j + 1, b);   // only the first is absent
+        }
+        if ((rc = upload(ctx, pt.data(), pt.size(), &d.conv1_pairs))) return rc;
     }
     // Fold BatchNormalization (inference statistics) into the preceding Dense (model.py:28-30, 40-42):
     // y = gamma * (x@K + b - mean) / sqrt(var + eps) + beta = x@(K*s) + ((b - mean)*s + beta)

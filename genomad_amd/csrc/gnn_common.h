@@ -25,6 +25,9 @@ constexpr float BN_EPS = 1e-3f;           // Keras BatchNormalization default
 // ---- fused front end geometry (gnn_fused.hip) ----
 constexpr int FT = 128;                   // rows (token positions) per step of a workgroup
 constexpr int FSTEPS = (T + FT - 1) / FT; // 47 steps per window
+// rows of a conv1 pair table: 1024 five-mers | 256 (N, 4-mer) | 256 (4-mer, N) | (N, N) | (absent,
+// absent) | 257 (absent, token) — see pair_row() in gnn_fused.hip
+constexpr int PAIR_ROWS = 1024 + 256 + 256 + 1 + 1 + 257;   // 1795
 
 void set_error(const std::string& msg);
 
@@ -51,7 +54,7 @@ struct DeviceWeights {
     int32_t* pos_sorted[2] = {nullptr, nullptr};   // (8400,)
     int32_t* slot[2] = {nullptr, nullptr};         // (8400,) pair -> entry
     int32_t* bucket_ptr[2] = {nullptr, nullptr};   // (FSTEPS+1,)
-    float* conv1_kz = nullptr;  // (6,258,128): conv1 kernel + an all-zero row 257 (position < 0)
+    float* conv1_pairs = nullptr;  // (3, PAIR_ROWS, 128): W1[2j][a] + W1[2j+1][b] per token pair
     float* w_bias[2] = {nullptr, nullptr};   // (2100,)
     float* w_qk[2] = {nullptr, nullptr};     // (2100,749)
     float* w_v[2] = {nullptr, nullptr};      // (128,128) [in][out]

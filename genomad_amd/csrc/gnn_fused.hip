@@ -257,7 +257,7 @@ __device__ __forceinline__ void m_partials(const unsigned char* __restrict__ xbu
 
 struct FusedArgs {
     const uint8_t* bases;
-    const float* conv1_k;        // (6,258,128) f32, row 257 of every tap is zero
+    const float* conv1_k;        // (3, PAIR_ROWS, 128) f32 conv1 pair tables
     const float* conv1_b;
     const uint4* conv_frag[2];
     const float* conv_b[2];
@@ -280,11 +280,35 @@ struct FusedArgs {
         tick_ = now_;                                                 \
     }
 
-// conv1 (6-row gather-sum of the f32 kernel, model.py:11 + igloo.py:45-48) + LeakyReLU for the 128
-// positions starting at t0, split to bf16 hi/lo, into rows 5..132 of xbuf.  256 helper threads:
-// thread = 4 channels x 16 positions.  toks[j] is the token of position j-5.
-__device__ __forceinline__ void conv1_gather(unsigned char* __restrict__ xbuf, const uint16_t* __restrict__ toks,
-                                             const float* __restrict__ k1, const float* __restrict__ b1,
+// Token state of position t: -1 = before the window start (zero padding of the one-hot input),
+// 0 = the 4-mer touches a non-ACGT byte (or lies past the last token), 1..256 = 4-mer code + 1
+// (sequence.py:170-193, closed form).
+__device__ __forceinline__ int token_state(const uint8_t* __restrict__ bases, int t) {
+    if (t < 0) return -1;
+    if (t >= T) return 0;
+    const int c0 = base_code_f(bases[t]), c1 = base_code_f(bases[t + 1]), c2 = base_code_f(bases[t + 2]),
+              c3 = base_code_f(bases[t + 3]);
+    return (c0 | c1 | c2 | c3) < 0 ? 0 : 1 + c0 * 64 + c1 * 16 + c2 * 4 + c3;
+}
+
+// Row of the conv1 pair tables for the tokens (a, b) of two adjacent positions (layout built by
+// gnn_load_weights): adjacent 4-mers overlap in 3 bases, so a valid pair is a 5-mer.
+__device__ __forceinline__ uint32_t pair_row(int a, int b) {
+    if (a > 0 && b > 0) return (uint32_t)((a - 1) * 4 + ((b - 1) & 3));
+    if (a == 0 && b > 0) return 1024u + (uint32_t)(b - 1);
+    if (a > 0 && b == 0) return 1280u + (uint32_t)(a - 1);
+    if (a == 0) return 1536u;            // (N, N)
+    if (b < 0) return 1537u;             // both before the window start: zero row
+    return 1538u + (uint32_t)b;          // only the first one is before the window start
+}
+
+// conv1 + LeakyReLU for the 128 positions starting at t0, split to bf16 hi/lo, into rows 5..132 of
+// xbuf.  conv1 on a one-hot input is a 6-row gather-sum of its kernel (model.py:11 + igloo.py:45-48);
+// with the pair tables it is 3 rows: taps (0,1), (2,3), (4,5) of position t read the pairs starting
+// at t-5, t-3, t-1.  prow[j] is the pair row of positions (j-5, j-4).  256 helper threads:
+// thread = 4 channels x 16 positions.
+__device__ __forceinline__ void conv1_gather(unsigned char* __restrict__ xbuf, const uint16_t* __restrict__ prow,
+                                             const float* __restrict__ pt, const float* __restrict__ b1,
                                              int t0, int ht) {
     const int cq = ht & 31;
     const f32x4 b = *reinterpret_cast<const f32x4*>(b1 + cq * 4);
@@ -296,9 +320,9 @@ __device__ __forceinline__ void conv1_gather(unsigned char* __restrict__ xbuf, c
         const int u = (ht >> 5) + it * 8;
         f32x4 v = b;
 #pragma unroll
-        for (int k = 0; k < KS; ++k) {
-            const uint32_t tk = toks[t0 + u + k];
-            v += *reinterpret_cast<const f32x4*>(k1 + ((size_t)k * (GNN_DEPTH + 1) + tk) * C + cq * 4);
+        for (int j = 0; j < 3; ++j) {
+            const uint32_t r = prow[t0 + u + 2 * j];
+            v += *reinterpret_cast<const f32x4*>(pt + ((size_t)j * PAIR_ROWS + r) * C + cq * 4);
         }
 #pragma unroll
         for (int e = 0; e < 4; ++e) v[e] = lrelu_f(v[e]);
@@ -345,21 +369,10 @@ __global__ __launch_bounds__(512, 2) void fused_front_kernel(FusedArgs a) {
         reinterpret_cast<uint4*>(bufX)[i] = make_uint4(0, 0, 0, 0);
         reinterpret_cast<uint4*>(bufY)[i] = make_uint4(0, 0, 0, 0);
     }
-    // tokens of the whole window (sequence.py:170-193, closed form): toks[j] = token of position j-5;
-    // positions < 0 select the all-zero row 257 of conv1_kz, positions >= 5997 (tail of the last
-    // step, never used by a valid output) get token 0
+    // pair rows of the whole window: toks[j] = conv1 pair-table row of positions (j-5, j-4)
     for (int j = tid; j < TOK_COUNT; j += 512) {
         const int t = j - CARRY;
-        uint32_t tok = GNN_DEPTH;
-        if (t >= 0) {
-            tok = 0;
-            if (t < T) {
-                const int c0 = base_code_f(bases[t]), c1 = base_code_f(bases[t + 1]),
-                          c2 = base_code_f(bases[t + 2]), c3 = base_code_f(bases[t + 3]);
-                if ((c0 | c1 | c2 | c3) >= 0) tok = 1u + (uint32_t)(c0 * 64 + c1 * 16 + c2 * 4 + c3);
-            }
-        }
-        toks[j] = (uint16_t)tok;
+        toks[j] = (uint16_t)pair_row(token_state(bases, t), token_state(bases, t + 1));
     }
     __syncthreads();
     if (helper) conv1_gather(bufX, toks, a.conv1_k, a.conv1_b, 0, ht);
@@ -494,7 +507,7 @@ int launch_front_fused(gnn_ctx* ctx, const uint8_t* bases, int64_t n, int precis
     const DeviceWeights& d = ctx->w;
     FusedArgs a;
     a.bases = bases;
-    a.conv1_k = d.conv1_kz;
+    a.conv1_k = d.conv1_pairs;
     a.conv1_b = d.conv1_b;
     for (int i = 0; i < 2; ++i) {
         a.conv_frag[i] = reinterpret_cast<const uint4*>(d.conv_frag[i]);
