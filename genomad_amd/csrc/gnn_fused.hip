@@ -193,15 +193,26 @@ __device__ __forceinline__ void wv_pool(const unsigned char* __restrict__ xbuf, 
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[mb][r] = 0.f;
     gemm_tile<false, 1, PASSES>(xbuf + CARRY * ROWB, wfrag, acc, lane);
+    // rows 8rg..8rg+3 of a 32-row block sit in lanes 0-31, rows 8rg+4..8rg+7 in lanes 32-63: the
+    // 8-row max is 4 registers + one exchange with lane^32 (v_permlane32_swap, no LDS round trip).
+    // All 16 pooled values are reduced first, then stored under one predicate.
+    float m[16];
 #pragma unroll
-    for (int mb = 0; mb < 4; ++mb)
+    for (int i = 0; i < 16; ++i) {
+        const int mb = i >> 2, rg = i & 3;
+        const float v = fmaxf(fmaxf(acc[mb][rg * 4], acc[mb][rg * 4 + 1]), fmaxf(acc[mb][rg * 4 + 2], acc[mb][rg * 4 + 3]));
+        const unsigned bits = __float_as_uint(v);
+        const auto sw = __builtin_amdgcn_permlane32_swap(bits, bits, false, false);
+        m[i] = fmaxf(v, __uint_as_float(lane < 32 ? sw[1] : sw[0]));
+    }
+    const int q0 = t0 / GNN_POOL;
+    const int nq = min(16, POOLED - q0);              // pooled rows of this step that exist (q < 749)
+    if (lane < 32) {
+        float* dst = yp_w + (size_t)q0 * C + wave * 32 + lane;
 #pragma unroll
-        for (int rg = 0; rg < 4; ++rg) {
-            float m = fmaxf(fmaxf(acc[mb][rg * 4], acc[mb][rg * 4 + 1]), fmaxf(acc[mb][rg * 4 + 2], acc[mb][rg * 4 + 3]));
-            m = fmaxf(m, __shfl_xor(m, 32, 64));
-            const int q = t0 / GNN_POOL + mb * 4 + rg;
-            if (lane < 32 && q < POOLED) yp_w[(size_t)q * C + wave * 32 + lane] = m;
-        }
+        for (int i = 0; i < 16; ++i)
+            if (i < nq) dst[(size_t)i * C] = m[i];
+    }
 }
 
 // pair dot products of this step (igloo.py:192-204, w_mult*w_summer folded): entries e_begin..e_end
@@ -307,6 +318,7 @@ __device__ __forceinline__ uint32_t pair_row(int a, int b) {
 // with the pair tables it is 3 rows: taps (0,1), (2,3), (4,5) of position t read the pairs starting
 // at t-5, t-3, t-1.  prow[j] is the pair row of positions (j-5, j-4).  256 helper threads:
 // thread = 4 channels x 16 positions.
+template <int IT0, int IT1>   // iterations IT0..IT1 of 16 (8 positions each)
 __device__ __forceinline__ void conv1_gather(unsigned char* __restrict__ xbuf, const uint16_t* __restrict__ prow,
                                              const float* __restrict__ pt, const float* __restrict__ b1,
                                              int t0, int ht) {
@@ -315,8 +327,11 @@ __device__ __forceinline__ void conv1_gather(unsigned char* __restrict__ xbuf, c
 #ifndef GNN_GATHER_UNROLL
 #define GNN_GATHER_UNROLL 4
 #endif
+#ifndef GNN_GATHER_EARLY
+#define GNN_GATHER_EARLY 4      // iterations of the next step's gather done between B1 and B2
+#endif
 #pragma unroll GNN_GATHER_UNROLL
-    for (int it = 0; it < FT / 8; ++it) {
+    for (int it = IT0; it < IT1; ++it) {
         const int u = (ht >> 5) + it * 8;
         f32x4 v = b;
 #pragma unroll
@@ -375,7 +390,7 @@ __global__ __launch_bounds__(512, 2) void fused_front_kernel(FusedArgs a) {
         toks[j] = (uint16_t)pair_row(token_state(bases, t), token_state(bases, t + 1));
     }
     __syncthreads();
-    if (helper) conv1_gather(bufX, toks, a.conv1_k, a.conv1_b, 0, ht);
+    if (helper) conv1_gather<0, FT / 8>(bufX, toks, a.conv1_k, a.conv1_b, 0, ht);
 #ifndef GNN_NO_SETPRIO
     else __builtin_amdgcn_s_setprio(2);      // the matrix waves win issue arbitration on their SIMD
 #endif
@@ -427,9 +442,12 @@ __global__ __launch_bounds__(512, 2) void fused_front_kernel(FusedArgs a) {
             GNN_TICK(8)
             __syncthreads();                                                     // ---- B1
             if (ht < CARRY * 32) *reinterpret_cast<uint4*>(bufX + cr * ROWB + cc * 16) = carry;
+            // bufX is free from B1 on: the first part of the next step's gather runs while the matrix
+            // waves are in their conv2 epilogue (no MFMA traffic to compete with), the rest beside conv3
+            if (step + 1 < FSTEPS) conv1_gather<0, GNN_GATHER_EARLY>(bufX, toks, a.conv1_k, a.conv1_b, t0 + FT, ht);
             __syncthreads();                                                     // ---- B2
             if constexpr (PROF) tick_ = __builtin_readcyclecounter();
-            if (step + 1 < FSTEPS) conv1_gather(bufX, toks, a.conv1_k, a.conv1_b, t0 + FT, ht);
+            if (step + 1 < FSTEPS) conv1_gather<GNN_GATHER_EARLY, FT / 8>(bufX, toks, a.conv1_k, a.conv1_b, t0 + FT, ht);
             if (ht < CARRY * 32) carry = *reinterpret_cast<const uint4*>(bufY + (FT + cr) * ROWB + cc * 16);
             GNN_TICK(9)
             __syncthreads();                                                     // ---- B3
