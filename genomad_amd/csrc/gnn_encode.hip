@@ -88,39 +88,60 @@ __global__ __launch_bounds__(256) void tokenize_kernel(const uint8_t* __restrict
     }
 }
 
-// Stand-alone encoder.  The output (n, 5997, 257) is treated as one flat array of elements;
-// each thread produces VEC consecutive elements = one 16-byte store (u8: 16, bf16: 8, f32: 4), so
-// a wave writes 1 KiB contiguous.  A 16-byte group spans at most two one-hot rows (257 > 16).
-template <typename OutT, int VEC>
-__global__ __launch_bounds__(256) void onehot_kernel(const uint8_t* __restrict__ bases, int64_t n,
-                                                     OutT* __restrict__ out, OutT one) {
-    const int64_t total = n * (int64_t)T * GNN_DEPTH;
-    const int64_t e0 = ((int64_t)blockIdx.x * 256 + threadIdx.x) * VEC;
-    if (e0 >= total) return;
-    const int64_t row = e0 / GNN_DEPTH;                // global row = window * 5997 + t
-    const int d0 = (int)(e0 - row * GNN_DEPTH);
-    const int64_t wi = row / T;
-    const int t = (int)(row - wi * T);
-    const uint32_t tok0 = token_at(bases + wi * W, t);
-    uint32_t tok1 = 0;
-    if (d0 + VEC > GNN_DEPTH) {                        // group spills into the next row
-        const int64_t row1 = row + 1;
-        if (row1 < n * (int64_t)T) {
-            const int64_t w1 = row1 / T;
-            tok1 = token_at(bases + w1 * W, (int)(row1 - w1 * T));
+// Stand-alone encoder (HBM-write bound).  The output (n, 5997, 257) is one flat array; a block owns
+// RB = 64 consecutive one-hot rows, i.e. 64*257*sizeof(OutT) bytes = a whole number of 16-byte
+// chunks starting on a 16-byte boundary.  The block first puts its 65 tokens into LDS (one 64-bit
+// division per token, not per chunk), then every thread produces 16-byte chunks with 32-bit index
+// math: a chunk is all zero except at most two elements (257 > 16: it touches at most two rows), so
+// it is built as four dwords with at most two OR-ed in, and written with one coalesced 16-byte store
+// (a wave writes 1 KiB contiguous).
+constexpr int RB = 64;
+
+template <int ISZ>   // element size in bytes: 1 (u8), 2 (bf16), 4 (f32); `one` is the element's bit pattern
+__global__ __launch_bounds__(256) void onehot_kernel(const uint8_t* __restrict__ bases, int64_t n_rows,
+                                                     uint4* __restrict__ out, uint32_t one) {
+    constexpr int VEC = 16 / ISZ;                            // elements per 16-byte chunk
+    constexpr int CHUNKS = RB * GNN_DEPTH * ISZ / 16;        // chunks per full block (1028 / 2056 / 4112)
+    __shared__ uint32_t tok[RB + 1];
+    const int64_t row0 = (int64_t)blockIdx.x * RB;
+    if (threadIdx.x <= RB) {
+        const int64_t row = row0 + threadIdx.x;              // global row = window * 5997 + t
+        uint32_t v = 0xFFFFu;                                // past the end: matches no column
+        if (row < n_rows) {
+            const int64_t wi = row / T;
+            v = token_at(bases + wi * W, (int)(row - wi * T));
         }
+        tok[threadIdx.x] = v;
     }
-    OutT v[VEC];
+    __syncthreads();
+    const int rows_here = (int)min((int64_t)RB, n_rows - row0);
+    const int elems_here = rows_here * GNN_DEPTH;
+    uint4* dst = out + (size_t)blockIdx.x * CHUNKS;
+    for (int c = threadIdx.x; c * VEC < elems_here; c += 256) {
+        const int e0 = c * VEC;                              // element offset inside the block
+        const int lrow = (int)(((uint32_t)e0 * 65281u) >> 24);   // e0 / 257 for e0 < 2^16 (65281 = ceil(2^24/257))
+        const int d0 = e0 - lrow * GNN_DEPTH;
+        // element index (inside this chunk) of the hot column of row lrow and of row lrow+1
+        const int p0 = (int)tok[lrow] - d0;
+        const int p1 = (int)tok[lrow + 1] + GNN_DEPTH - d0;
+        uint32_t dw[4] = {0u, 0u, 0u, 0u};
 #pragma unroll
-    for (int k = 0; k < VEC; ++k) {
-        const int d = d0 + k;
-        const bool hit = d < GNN_DEPTH ? ((uint32_t)d == tok0) : ((uint32_t)(d - GNN_DEPTH) == tok1);
-        v[k] = hit ? one : (OutT)0;
-    }
-    if (e0 + VEC <= total) {
-        *reinterpret_cast<uint4*>(out + e0) = *reinterpret_cast<const uint4*>(v);
-    } else {
-        for (int k = 0; k < VEC && e0 + k < total; ++k) out[e0 + k] = v[k];
+        for (int h = 0; h < 2; ++h) {
+            const int p = h ? p1 : p0;
+            if (p >= 0 && p < VEC) {
+                const int byte = p * ISZ;
+                const uint32_t val = one << ((byte & 3) * 8);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) dw[i] |= (byte >> 2) == i ? val : 0u;
+            }
+        }
+        if (e0 + VEC <= elems_here) {
+            dst[c] = make_uint4(dw[0], dw[1], dw[2], dw[3]);
+        } else {                                             // ragged tail of the very last block
+            const unsigned char* src = reinterpret_cast<const unsigned char*>(dw);
+            unsigned char* o = reinterpret_cast<unsigned char*>(dst + c);
+            for (int k = 0; k < (elems_here - e0) * ISZ; ++k) o[k] = src[k];
+        }
     }
 }
 
@@ -142,20 +163,15 @@ int launch_tokenize(gnn_ctx* ctx, const uint8_t* bases, int64_t n, uint16_t* tok
 }
 
 int launch_onehot(gnn_ctx* ctx, const uint8_t* bases, int64_t n, int dtype, void* out) {
-    const int64_t total = n * (int64_t)T * GNN_DEPTH;
-    if (dtype == GNN_OH_U8) {
-        const int64_t blocks = ((total + 15) / 16 + 255) / 256;
-        hipLaunchKernelGGL((onehot_kernel<uint8_t, 16>), dim3((unsigned)blocks), dim3(256), 0, ctx->stream,
-                           bases, n, (uint8_t*)out, (uint8_t)1);
-    } else if (dtype == GNN_OH_BF16) {
-        const int64_t blocks = ((total + 7) / 8 + 255) / 256;
-        hipLaunchKernelGGL((onehot_kernel<uint16_t, 8>), dim3((unsigned)blocks), dim3(256), 0, ctx->stream,
-                           bases, n, (uint16_t*)out, (uint16_t)0x3F80);   // bf16 1.0
-    } else {
-        const int64_t blocks = ((total + 3) / 4 + 255) / 256;
-        hipLaunchKernelGGL((onehot_kernel<uint32_t, 4>), dim3((unsigned)blocks), dim3(256), 0, ctx->stream,
-                           bases, n, (uint32_t*)out, (uint32_t)0x3F800000);  // f32 1.0
-    }
+    const int64_t n_rows = n * (int64_t)T;
+    const unsigned blocks = (unsigned)((n_rows + RB - 1) / RB);
+    uint4* o = reinterpret_cast<uint4*>(out);
+    if (dtype == GNN_OH_U8)
+        hipLaunchKernelGGL((onehot_kernel<1>), dim3(blocks), dim3(256), 0, ctx->stream, bases, n_rows, o, 1u);
+    else if (dtype == GNN_OH_BF16)
+        hipLaunchKernelGGL((onehot_kernel<2>), dim3(blocks), dim3(256), 0, ctx->stream, bases, n_rows, o, 0x3F80u);
+    else
+        hipLaunchKernelGGL((onehot_kernel<4>), dim3(blocks), dim3(256), 0, ctx->stream, bases, n_rows, o, 0x3F800000u);
     GNN_HIP(hipGetLastError());
     return GNN_OK;
 }
