@@ -75,6 +75,8 @@ def main():
     ap.add_argument("--kernel", default="classify", choices=["classify", "encoder"],
                     help="'encoder' benches the stand-alone byte->one-hot HBM kernel instead")
     ap.add_argument("--onehot-dtype", default="u8", choices=["u8", "bf16", "f32"])
+    ap.add_argument("--force-dist", action="store_true",
+                    help="initialise the nccl (RCCL) process group and run the barrier/gather path even with one rank")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -95,8 +97,10 @@ def main():
 
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    use_dist = world > 1 or args.force_dist
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     weights = synthetic.synth_weights()
@@ -106,7 +110,7 @@ def main():
     def barrier():
         eng.sync()
         torch.cuda.synchronize()
-        if world > 1:
+        if use_dist:
             dist.barrier()
 
     wps, K = args.windows_per_step, args.steps
@@ -165,10 +169,10 @@ def main():
     for k in range(K):
         step(k)
     eng.sync()
-    gathered = sharding.gather_scores(scores, n_local * world) if world > 1 else scores
+    gathered = sharding.gather_scores(scores, n_local * world) if use_dist else scores
     barrier()
     dt = time.perf_counter() - t0
-    if world > 1:
+    if use_dist:
         tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
@@ -219,7 +223,7 @@ def main():
             out["max_abs_dscore"] = float(np.abs(gpu_first - cpu_scores).max())
             out["dscore_tolerance"] = 1e-4
         print(json.dumps(out))
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 
