@@ -546,6 +546,85 @@ int gnn_debug_forward(gnn_ctx* ctx, const uint8_t* bases_host, int64_t n, int pr
     return rc;
 }
 
+// Copy the span table to the device; checks every span against the rules of the caller's contract.
+static int upload_spans(gnn_ctx* ctx, const int64_t* starts_host, const int32_t* lens_host, int64_t n,
+                        int64_t** starts_dev, int32_t** lens_dev) {
+    for (int64_t i = 0; i < n; ++i)
+        if (starts_host[i] < 0 || lens_host[i] < 0 || lens_host[i] > W) {
+            set_error("span " + std::to_string(i) + " has a negative start or a length outside [0, 6000]");
+            return GNN_ERR_ARG;
+        }
+    void *ps = nullptr, *pl = nullptr;
+    int rc = dev_buffer(ctx, (size_t)n * sizeof(int64_t), &ps);
+    if (rc) return rc;
+    if ((rc = dev_buffer(ctx, (size_t)n * sizeof(int32_t), &pl))) {
+        (void)hipFree(ps);
+        return rc;
+    }
+    rc = gnn_memcpy_h2d(ctx, ps, starts_host, (size_t)n * sizeof(int64_t));
+    if (!rc) rc = gnn_memcpy_h2d(ctx, pl, lens_host, (size_t)n * sizeof(int32_t));
+    if (rc) {
+        (void)hipFree(ps);
+        (void)hipFree(pl);
+        return rc;
+    }
+    *starts_dev = static_cast<int64_t*>(ps);
+    *lens_dev = static_cast<int32_t*>(pl);
+    return GNN_OK;
+}
+
+int gnn_span_byte_count(gnn_ctx* ctx, const uint8_t* seq_dev, const int64_t* starts_host, const int32_t* lens_host,
+                        int64_t n, int byte, int32_t* counts_host) {
+    int rc = check_ctx(ctx);
+    if (rc) return rc;
+    if (n < 0 || byte < 0 || byte > 255 || (n > 0 && (!seq_dev || !starts_host || !lens_host || !counts_host))) {
+        set_error("bad argument to gnn_span_byte_count");
+        return GNN_ERR_ARG;
+    }
+    if (n == 0) return GNN_OK;
+    int64_t* ds = nullptr;
+    int32_t* dl = nullptr;
+    if ((rc = upload_spans(ctx, starts_host, lens_host, n, &ds, &dl))) return rc;
+    void* dc = nullptr;
+    rc = dev_buffer(ctx, (size_t)n * sizeof(int32_t), &dc);
+    if (!rc) rc = launch_span_count(ctx, seq_dev, ds, dl, n, byte, (int32_t*)dc);
+    if (!rc) rc = gnn_memcpy_d2h(ctx, counts_host, dc, (size_t)n * sizeof(int32_t));
+    (void)hipFree(ds);
+    (void)hipFree(dl);
+    if (dc) (void)hipFree(dc);
+    return rc;
+}
+
+int gnn_classify_spans(gnn_ctx* ctx, const uint8_t* seq_dev, const int64_t* starts_host, const int32_t* lens_host,
+                       int64_t n, int precision, float* scores_host) {
+    int rc = check_ctx(ctx);
+    if (rc) return rc;
+    if (n < 0 || (n > 0 && (!seq_dev || !starts_host || !lens_host || !scores_host))) {
+        set_error("bad argument to gnn_classify_spans");
+        return GNN_ERR_ARG;
+    }
+    if (n == 0) return GNN_OK;
+    int64_t* ds = nullptr;
+    int32_t* dl = nullptr;
+    if ((rc = upload_spans(ctx, starts_host, lens_host, n, &ds, &dl))) return rc;
+    // windows are materialised one slab at a time (6 KB each), never the whole table
+    const int64_t slab = std::min<int64_t>(n, 4 * std::max<int64_t>(ctx->chunk_fused, 1));
+    void *db = nullptr, *dsc = nullptr;
+    rc = dev_buffer(ctx, (size_t)slab * W, &db);
+    if (!rc) rc = dev_buffer(ctx, (size_t)n * GNN_CLASSES * sizeof(float), &dsc);
+    for (int64_t a = 0; a < n && !rc; a += slab) {
+        const int64_t m = std::min(slab, n - a);
+        rc = launch_materialize(ctx, seq_dev, ds + a, dl + a, m, (uint8_t*)db);
+        if (!rc) rc = classify_chunks(ctx, (const uint8_t*)db, m, precision, (float*)dsc + a * GNN_CLASSES);
+    }
+    if (!rc) rc = gnn_memcpy_d2h(ctx, scores_host, dsc, (size_t)n * GNN_CLASSES * sizeof(float));
+    (void)hipFree(ds);
+    (void)hipFree(dl);
+    if (db) (void)hipFree(db);
+    if (dsc) (void)hipFree(dsc);
+    return rc;
+}
+
 int gnn_profile_enable(gnn_ctx* ctx, int on) {
     if (!ctx) {
         set_error("ctx is NULL");

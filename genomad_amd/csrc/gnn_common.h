@@ -112,6 +112,10 @@ namespace gnn {
 int launch_tokenize(gnn_ctx* ctx, const uint8_t* bases, int64_t n, uint16_t* tokens);
 int launch_onehot(gnn_ctx* ctx, const uint8_t* bases, int64_t n, int dtype, void* out);
 int launch_synth(gnn_ctx* ctx, uint64_t seed, int64_t first, int64_t n, uint8_t* bases);
+int launch_span_count(gnn_ctx* ctx, const uint8_t* seq, const int64_t* starts, const int32_t* lens, int64_t n,
+                      int byte, int32_t* counts);
+int launch_materialize(gnn_ctx* ctx, const uint8_t* seq, const int64_t* starts, const int32_t* lens, int64_t n,
+                       uint8_t* bases);
 int launch_front_f32(gnn_ctx* ctx, const uint8_t* bases, int64_t n);         // -> ws.mp, ws.yp (+ ws.x)
 int launch_front_fused(gnn_ctx* ctx, const uint8_t* bases, int64_t n, int precision);  // -> ws.mp, ws.yp
 int launch_backend(gnn_ctx* ctx, int64_t n, float* scores_dev);              // ws.mp, ws.yp -> scores

@@ -145,6 +145,67 @@ __global__ __launch_bounds__(256) void onehot_kernel(const uint8_t* __restrict__
     }
 }
 
+// Contig front end: a window is a span (start, len <= 6000) of one packed buffer of raw contig bytes.
+// One wave per span counts the bytes equal to `byte` (the reference counts literal upper-case "N" on
+// the raw string, sequence.py:38-39 / nn_classification.py:70-71).
+__global__ __launch_bounds__(256) void span_count_kernel(const uint8_t* __restrict__ seq,
+                                                         const int64_t* __restrict__ starts,
+                                                         const int32_t* __restrict__ lens, int64_t n,
+                                                         uint32_t byte, int32_t* __restrict__ counts) {
+    const int64_t i = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (i >= n) return;
+    const int lane = threadIdx.x & 63;
+    const uint8_t* p = seq + starts[i];
+    const int len = lens[i];
+    int c = 0;
+    for (int k = lane; k < len; k += 64) c += p[k] == byte;
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) c += __shfl_xor(c, off, 64);
+    if (lane == 0) counts[i] = c;
+}
+
+// Span -> padded window: upper-case (Sequence.seq_ascii, sequence.py:35-36) and right-pad with 'N' to
+// 6000 bytes (nn_classification.py:72).  One thread per 4 output bytes.
+__global__ __launch_bounds__(256) void materialize_kernel(const uint8_t* __restrict__ seq,
+                                                          const int64_t* __restrict__ starts,
+                                                          const int32_t* __restrict__ lens, int64_t n,
+                                                          uint32_t* __restrict__ out) {
+    const int64_t g = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (g >= n * (W / 4)) return;
+    const int64_t wi = g / (W / 4);
+    const int p0 = (int)(g - wi * (W / 4)) * 4;
+    const uint8_t* p = seq + starts[wi];
+    const int len = lens[wi];
+    uint32_t word = 0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        uint32_t ch = 'N';
+        if (p0 + k < len) {
+            ch = p[p0 + k];
+            if (ch >= 'a' && ch <= 'z') ch -= 32;      // str.upper() on ASCII
+        }
+        word |= ch << (8 * k);
+    }
+    out[g] = word;
+}
+
+int launch_span_count(gnn_ctx* ctx, const uint8_t* seq, const int64_t* starts, const int32_t* lens, int64_t n,
+                      int byte, int32_t* counts) {
+    hipLaunchKernelGGL(span_count_kernel, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, ctx->stream, seq, starts, lens,
+                       n, (uint32_t)byte, counts);
+    GNN_HIP(hipGetLastError());
+    return GNN_OK;
+}
+
+int launch_materialize(gnn_ctx* ctx, const uint8_t* seq, const int64_t* starts, const int32_t* lens, int64_t n,
+                       uint8_t* bases) {
+    const int64_t groups = n * (W / 4);
+    hipLaunchKernelGGL(materialize_kernel, dim3((unsigned)((groups + 255) / 256)), dim3(256), 0, ctx->stream, seq,
+                       starts, lens, n, reinterpret_cast<uint32_t*>(bases));
+    GNN_HIP(hipGetLastError());
+    return GNN_OK;
+}
+
 int launch_synth(gnn_ctx* ctx, uint64_t seed, int64_t first, int64_t n, uint8_t* bases) {
     const int64_t groups = n * (W / 4);
     const int64_t blocks = (groups + 255) / 256;

@@ -149,6 +149,43 @@ class NNEngine:
                                          scores.ctypes.data, C.byref(t)))
         return scores, arrays
 
+    def classify_contigs(self, seq: np.ndarray, offsets: np.ndarray, single_window: bool = False,
+                         precision="bf16x3"):
+        """Contig front end: packed raw contig bytes -> per-contig scores.
+
+        Does what generate_data + the predict loop + segment_mean do (nn_classification.py:54-82,
+        :316-320) without per-window host objects: the packed buffer is uploaded once, candidate
+        windows are spans computed with numpy, the N-content rule is evaluated by a device kernel on
+        the raw bytes, kept spans are upper-cased/padded/tokenised/classified on the device and
+        averaged per contig on the device.  Returns (contig_scores (n_contigs,3), contig_ids of the
+        kept windows).
+        """
+        from . import sequence as S
+        seq = np.ascontiguousarray(seq, dtype=np.uint8)
+        offsets = np.ascontiguousarray(offsets, dtype=np.int64)
+        n_contigs = len(offsets) - 1
+        starts, lens, ids, window_n = S.candidate_spans(offsets, single_window)
+        if not len(starts):
+            return np.zeros((n_contigs, _lib.CLASSES), np.float32), ids
+        buf = self.alloc(max(seq.nbytes, 1))
+        try:
+            buf.upload(seq)
+            later = np.flatnonzero(window_n > 0)              # window 0 is never skipped (:70)
+            keep = np.ones(len(starts), dtype=bool)
+            if len(later):
+                st, ln = np.ascontiguousarray(starts[later]), np.ascontiguousarray(lens[later])
+                counts = np.empty(len(later), dtype=np.int32)
+                check(self.lib.gnn_span_byte_count(self.ctx, buf.ptr, st.ctypes.data, ln.ctypes.data, len(later),
+                                                   ord("N"), counts.ctypes.data))
+                keep[later[counts > S.MAX_N]] = False
+            starts, lens, ids = (np.ascontiguousarray(a[keep]) for a in (starts, lens, ids))
+            scores = np.empty((len(starts), _lib.CLASSES), dtype=np.float32)
+            check(self.lib.gnn_classify_spans(self.ctx, buf.ptr, starts.ctypes.data, lens.ctypes.data, len(starts),
+                                              _lib.PRECISIONS[precision], scores.ctypes.data))
+        finally:
+            buf.free()
+        return self.segment_mean(scores, ids, n_contigs), ids
+
     def segment_mean(self, scores, ids, n_segments=None) -> np.ndarray:
         """tf.math.segment_mean(scores, ids) (nn_classification.py:320); ids sorted ascending."""
         s = np.ascontiguousarray(scores, dtype=np.float32)

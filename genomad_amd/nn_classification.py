@@ -277,13 +277,42 @@ def main(input_path, output_path, single_window, batch_size, restart, threads, v
         if rank0:
             write_tsv(tsv_path, names, predictions)                                  # :340-352 (always rewritten)
 
-    stage(input_path, outputs.encoded_sequences_dir, outputs.seq_window_id_output,
-          outputs.nn_classification_npz_output, outputs.nn_classification_output,
-          "contig_names", "contig_ids", "sequence")
+    def stage_device(fasta, enc_dir, wid_path, npz_path, tsv_path, names_key, ids_key, what):
+        """Single-process product path: the contig front end (NNEngine.classify_contigs) does
+        windowing, the N rule, tokenising, classification and the per-contig mean on the GPU, so
+        encoding and classification are one step; ``<prefix>_seq_window_id.npz`` is still written."""
+        if skip and npz_path.exists():                                               # :284-292
+            console.log(f"{npz_path.name} was found. Skipping {what} classification.")
+            z = np.load(npz_path)
+            names, predictions = z[names_key], z["predictions"]
+        else:
+            names, seq, offsets = sequence.read_fasta_packed(fasta, strip_n=True)
+            precision = os.environ.get("GENOMAD_AMD_PRECISION", "bf16x3")
+            predictions, ids = _engine().classify_contigs(seq, offsets, single_window, precision)
+            if not len(ids):                                                         # :297-299
+                console.error("No sequences were found. Please check your input FASTA.")
+                sys.exit(1)
+            if enc_dir.is_dir():
+                shutil.rmtree(enc_dir)
+            enc_dir.mkdir()
+            np.savez_compressed(wid_path, **{names_key: names, ids_key: ids})
+            console.log(f"{what.capitalize()}s classified ({len(ids)} windows).")
+            np.savez_compressed(npz_path, **{names_key: names, "predictions": predictions})
+        if cleanup and enc_dir.is_dir():
+            console.log(f"Deleting encoded {what} data.")
+            shutil.rmtree(enc_dir)
+        write_tsv(tsv_path, names, predictions)
+
+    device_front_end = (_backend is None and int(os.environ.get("WORLD_SIZE", "1")) == 1
+                        and os.environ.get("GENOMAD_AMD_FRONT_END", "device") == "device")
+    run = stage_device if device_front_end else stage
+    run(input_path, outputs.encoded_sequences_dir, outputs.seq_window_id_output,
+        outputs.nn_classification_npz_output, outputs.nn_classification_output,
+        "contig_names", "contig_ids", "sequence")
     if classify_proviruses:                                                          # :248-281, :355-425
-        stage(outputs.find_proviruses_nucleotide_output, outputs.encoded_proviruses_dir,
-              outputs.provirus_window_id_output, outputs.provirus_nn_classification_npz_output,
-              outputs.provirus_nn_classification_output, "provirus_names", "provirus_ids", "provirus")
+        run(outputs.find_proviruses_nucleotide_output, outputs.encoded_proviruses_dir,
+            outputs.provirus_window_id_output, outputs.provirus_nn_classification_npz_output,
+            outputs.provirus_nn_classification_output, "provirus_names", "provirus_ids", "provirus")
     console.log("geNomad nn-classification finished!")
 
 

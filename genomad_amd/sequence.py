@@ -137,6 +137,59 @@ def encode_fasta(path, single_window: bool = False):
     return np.array(names), np.array(ids, dtype=np.int64), windows
 
 
+def read_fasta_packed(path, strip_n: bool = True):
+    """(names, seq, offsets): every record that ``read_fasta(path, strip_n)`` yields, packed into ONE
+    uint8 buffer of raw (case-preserved) sequence bytes; contig i is seq[offsets[i]:offsets[i+1]].
+
+    Same record rules as :func:`read_fasta` (header = a line starting with '>', only '\\n' is
+    removed, leading/trailing n/N stripped, empty records dropped) but the per-line work is done by
+    bytes.split/replace, so it runs at C speed on metagenome-sized inputs.
+    """
+    kind = compression_of(path)
+    opener = {"gzip": gzip.open, "bzip2": bz2.open, "xz": lzma.open}.get(kind)
+    if kind == "zstd" and sys.version_info >= (3, 14):
+        from compression import zstd  # type: ignore
+        opener = zstd.open
+    with (opener(path, "rb") if opener else open(path, "rb")) as fin:
+        data = fin.read()
+    # the reference reads in text mode (utils.py:152-168): universal newlines
+    if b"\r" in data:
+        data = data.replace(b"\r\n", b"\n").replace(b"\r", b"\n")
+    records = (b"\n" + data).split(b"\n>")[1:]            # text before the first header line is dropped
+    names, chunks, lengths = [], [], []
+    for rec in records:
+        header, _, body = rec.partition(b"\n")
+        s = body.replace(b"\n", b"")
+        if strip_n:
+            s = s.strip(b"nN")
+        if len(s):
+            names.append(accession(header.decode("ascii")))
+            chunks.append(s)
+            lengths.append(len(s))
+    offsets = np.zeros(len(lengths) + 1, dtype=np.int64)
+    np.cumsum(np.asarray(lengths, dtype=np.int64), out=offsets[1:])
+    seq = np.frombuffer(b"".join(chunks), dtype=np.uint8) if chunks else np.zeros(0, dtype=np.uint8)
+    return np.array(names), seq, offsets
+
+
+def candidate_spans(offsets: np.ndarray, single_window: bool = False):
+    """Vectorised seq_windows(seq, 6000, 2500, max_windows) over all contigs (sequence.py:150-167):
+    returns (starts int64, lens int32, contig_ids int64, window_n int32) of every candidate window,
+    before the N-content rule."""
+    lengths = np.diff(offsets)
+    nfull, rem = lengths // WINDOW, lengths % WINDOW
+    nwin = nfull + (rem >= MIN_TAIL)
+    nwin = np.where((lengths > 0) & (nwin == 0), 1, nwin)          # window 0 is always yielded
+    if single_window:
+        nwin = np.minimum(nwin, 1)
+    ids = np.repeat(np.arange(len(lengths), dtype=np.int64), nwin)
+    first = np.cumsum(nwin) - nwin
+    window_n = (np.arange(int(nwin.sum()), dtype=np.int64) - np.repeat(first, nwin)).astype(np.int32)
+    starts = offsets[:-1][ids] + window_n.astype(np.int64) * WINDOW
+    lens = np.minimum(WINDOW, offsets[1:][ids] - starts).astype(np.int32)
+    return starts, lens, ids, window_n
+
+
 def prefix_of(input_path: Path) -> str:
     """nn_classification.py:106-108: stem, minus one more extension if the file is compressed."""
     prefix = Path(input_path).stem

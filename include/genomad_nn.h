@@ -152,6 +152,18 @@ int gnn_classify_dev(gnn_ctx* ctx, const uint8_t* bases_dev, int64_t n_windows, 
 int gnn_segment_mean(gnn_ctx* ctx, const float* scores_host, const int64_t* ids_host, int64_t n,
                      int64_t n_segments, float* out_host);
 
+/* ---- contig front end: windows are spans of one packed contig buffer ------ */
+/* counts[i] = number of bytes equal to `byte` in seq_dev[starts[i] .. starts[i]+lens[i]); used for the
+ * window skip rule `window_n > 0 and seq_window.count("N") > 4000` (nn_classification.py:70-71, counted
+ * on the raw, not upper-cased, sequence: sequence.py:38-39). */
+int gnn_span_byte_count(gnn_ctx* ctx, const uint8_t* seq_dev, const int64_t* starts_host,
+                        const int32_t* lens_host, int64_t n_spans, int byte, int32_t* counts_host);
+/* replaces seq_window.seq_ascii.ljust(6000, b"N") + tokenize + predict for windows given as spans
+ * (start, len <= 6000) of the raw contig buffer on the device (nn_classification.py:72-73, :316-317):
+ * each span is upper-cased (sequence.py:35-36) and right-padded with 'N' on the device. */
+int gnn_classify_spans(gnn_ctx* ctx, const uint8_t* seq_dev, const int64_t* starts_host,
+                       const int32_t* lens_host, int64_t n_spans, int precision, float* scores_host);
+
 /* same forward as gnn_classify, also copying intermediates out (parity tests). */
 int gnn_debug_forward(gnn_ctx* ctx, const uint8_t* bases_host, int64_t n_windows, int precision,
                       float* scores_host, const gnn_taps* taps);

@@ -284,3 +284,23 @@ def test_config3_1m_windows_sharding_and_determinism(engine):
     # when classified on their own
     sub = _classify_resident(engine, 777_000, 512, "bf16x3")
     assert np.array_equal(one[777_000:777_512], sub)
+
+
+# ------------------------------------------------------------------ contig front end
+def test_contig_front_end_equals_window_path(engine, synth_weights, golden_dir):
+    """classify_contigs (device-side upper-casing/padding/N rule/segment mean on spans of the packed
+    buffer) == reference windowing rules (golden FASTA fixture) + classify + segment mean."""
+    from genomad_amd import sequence
+    path = os.path.join(golden_dir, "fasta_fixture.fna.gz")
+    names, seq, offsets = sequence.read_fasta_packed(path)
+    g = json.load(open(os.path.join(golden_dir, "fasta_golden.json")))
+    for single, key in ((False, "all"), (True, "single")):
+        contig_scores, ids = engine.classify_contigs(seq, offsets, single, "bf16x3")
+        assert list(ids) == g[key]["contig_ids"]                 # N rule evaluated on the device
+        _, ids_h, wins = sequence.encode_fasta(path, single)
+        want = engine.segment_mean(engine.classify(wins, "bf16x3"), ids_h, len(names))
+        assert np.array_equal(contig_scores, want)               # same windows -> same bits
+        oracle = sequence_oracle.segment_mean(igloo_oracle.classify_windows(wins, synth_weights, np.float32), ids_h)
+        assert np.abs(contig_scores - oracle).max() <= SCORE_TOL
+    empty, ids = engine.classify_contigs(np.zeros(0, np.uint8), np.zeros(1, np.int64))
+    assert empty.shape == (0, 3) and len(ids) == 0

@@ -196,3 +196,33 @@ def test_gloo_world_size_2_gather_equals_single_process(n):
     rng = np.random.default_rng(0)
     windows = rng.integers(65, 85, (n, 6000), dtype=np.uint8)
     assert np.array_equal(got, FakeBackend().score(windows))
+
+
+def test_packed_reader_and_candidate_spans_match_reference_rules(golden_dir, tmp_path):
+    """read_fasta_packed + candidate_spans (the host half of the contig front end) reproduce what the
+    reference's read_fasta / seq_windows yield (goldens generated from the reference itself)."""
+    g = json.load(open(os.path.join(golden_dir, "fasta_golden.json")))
+    path = os.path.join(golden_dir, "fasta_fixture.fna.gz")
+    names, seq, offsets = sequence.read_fasta_packed(path)
+    assert list(names) == g["all"]["contig_names"]
+    ref = list(sequence.read_fasta(path, strip_n=True))
+    assert [len(s) for _, s in ref] == list(np.diff(offsets))
+    assert bytes(seq) == "".join(s for _, s in ref).encode()
+    for single, key in ((False, "all"), (True, "single")):
+        starts, lens, ids, window_n = sequence.candidate_spans(offsets, single)
+        # apply the N rule on the host here (the product does it on the device) and compare
+        keep = [(wn == 0) or (int(np.count_nonzero(seq[a:a + ln] == 78)) <= 4000)
+                for a, ln, wn in zip(starts, lens, window_n)]
+        assert list(ids[keep]) == g[key]["contig_ids"]
+        wins = sequence.encode_fasta(path, single)[2]
+        got = [bytes(seq[a:a + ln]).upper().ljust(6000, b"N") for a, ln, k in zip(starts, lens, keep) if k]
+        assert got == [bytes(w) for w in wins]
+    # CRLF line ends, text before the first header, '>' inside a line (not a header)
+    p = tmp_path / "crlf.fna"
+    p.write_bytes(b"junk\r\n>a x\r\nACGT\r\nAC>GT\r\n>b\r\nNNACGTNN\r\n")
+    names, seq, offsets = sequence.read_fasta_packed(p)
+    assert list(names) == ["a", "b"] and bytes(seq) == b"ACGTAC>GTACGT" and list(offsets) == [0, 9, 13]
+    assert [(h, s) for h, s in sequence.read_fasta(p, strip_n=True)] == [("a x", "ACGTAC>GT"), ("b", "ACGT")]
+    for L in (1, 2499, 2500, 6000, 8499, 8500, 14499, 14500, 20500):
+        st, ln, _, _ = sequence.candidate_spans(np.array([0, L]))
+        assert list(ln) == [b - a for a, b in sequence.window_spans(L)]
