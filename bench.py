@@ -216,6 +216,16 @@ def main():
             "note": "achieved counts ALGORITHMIC flops (2.763 GFLOP/window); bf16x3 issues 3 MFMA passes "
                     "per product, so issued-MFMA utilisation is 3x frac",
             "backend_ms_total": round(back_ms, 2), "front_ms_total": round(front_ms, 2)}
+        if args.precision != "f32":
+            # context for `frac`: what this power-managed chip sustains on the same MFMA instruction
+            # with nothing else running (outside the timed region, ~200 ms)
+            import ctypes
+            probe = ctypes.c_double()
+            _lib.check(eng.lib.gnn_mfma_probe(eng.ctx, 200, ctypes.byref(probe)))
+            passes = out["roofline"]["mfma_passes"]
+            out["roofline"]["issued_mfma_tflops"] = round(tflops * passes, 1)
+            out["roofline"]["mfma_probe_sustained_tflops"] = round(probe.value, 1)
+            out["roofline"]["issued_vs_probe"] = round(tflops * passes / probe.value, 4)
         if world == 1 and args.cpu_sample > 0:
             base, cpu_scores = cpu_baseline(weights, args.cpu_sample)
             gpu_first = gathered[:args.cpu_sample].cpu().numpy()

@@ -75,6 +75,7 @@ SIGNATURES = {
     "gnn_profile_get": (_int, [_vp, _int, C.POINTER(C.c_double), C.POINTER(_i64)]),
     "gnn_set_chunk": (_int, [_vp, _i64]),
     "gnn_phase_cycles": (_int, [_vp, _int, C.POINTER(C.c_uint64)]),
+    "gnn_mfma_probe": (_int, [_vp, _int, C.POINTER(C.c_double)]),
 }
 
 _lib = None

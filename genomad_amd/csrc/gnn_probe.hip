@@ -1,0 +1,95 @@
+// MFMA ceiling probe (measurement aid, not on the hot path): what does this chip sustain on
+// v_mfma_f32_32x32x16_bf16 when nothing but the matrix pipe is busy?  The chip is power-managed, so
+// the sustained figure on random operands is well below the 2.5 PFLOP/s datasheet peak; bench.py
+// reports it next to the fused kernel's issued-MFMA rate.
+//
+// Geometry mirrors the fused kernel's matrix waves: one wave per SIMD (4 per CU, 256 workgroups per
+// round), 4 independent 32x32 accumulators per wave, operands in registers (loaded once from a
+// random buffer so nothing constant-folds).
+#include "gnn_common.h"
+
+namespace gnn {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+__global__ __launch_bounds__(256, 1) void mfma_probe_kernel(const uint4* __restrict__ operands, int iters,
+                                                            float* __restrict__ sink) {
+    const int lane = threadIdx.x & 63;
+    bf16x8 a[4], b[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        a[i] = __builtin_bit_cast(bf16x8, operands[(i * 2 + 0) * 64 + lane]);
+        b[i] = __builtin_bit_cast(bf16x8, operands[(i * 2 + 1) * 64 + lane]);
+    }
+    f32x16 acc[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+#pragma unroll 1
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int rep = 0; rep < 3; ++rep)          // 12 MFMAs per iteration, like one k-step of the fused kernel
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[(i + rep) & 3], b[i], acc[i], 0, 0, 0);
+    }
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) s += acc[i][r];
+    if (s == 12345.678f) sink[0] = s;               // keeps the accumulators live
+}
+
+}  // namespace gnn
+
+using namespace gnn;
+
+// Runs the probe for roughly `ms_target` milliseconds (after a calibration launch) and returns the
+// sustained dense bf16 MFMA rate in TFLOP/s.
+extern "C" int gnn_mfma_probe(gnn_ctx* ctx, int ms_target, double* tflops_out) {
+    if (!ctx || !tflops_out || ms_target < 1) {
+        set_error("bad argument to gnn_mfma_probe");
+        return GNN_ERR_ARG;
+    }
+    GNN_HIP(hipSetDevice(ctx->device));
+    const int blocks = ctx->cu_count > 0 ? ctx->cu_count : 256;
+    std::vector<uint16_t> host(8 * 64 * 8);
+    uint32_t x = 0x12345u;
+    for (auto& v : host) {                          // random bf16 in roughly [-2, 2)
+        x = x * 1664525u + 1013904223u;
+        const uint32_t sign = (x >> 31) << 15, exp = 126u + ((x >> 29) & 1u), man = (x >> 8) & 0x7Fu;
+        v = (uint16_t)(sign | (exp << 7) | man);
+    }
+    void *dop = nullptr, *dsink = nullptr;
+    GNN_HIP(hipMalloc(&dop, host.size() * 2));
+    GNN_HIP(hipMalloc(&dsink, 16));
+    GNN_HIP(hipMemcpy(dop, host.data(), host.size() * 2, hipMemcpyHostToDevice));
+    hipEvent_t e0, e1;
+    GNN_HIP(hipEventCreate(&e0));
+    GNN_HIP(hipEventCreate(&e1));
+    auto run = [&](int iters, float* ms) -> int {
+        GNN_HIP(hipEventRecord(e0, ctx->stream));
+        hipLaunchKernelGGL(mfma_probe_kernel, dim3(blocks), dim3(256), 0, ctx->stream, (const uint4*)dop, iters,
+                           (float*)dsink);
+        GNN_HIP(hipEventRecord(e1, ctx->stream));
+        GNN_HIP(hipEventSynchronize(e1));
+        GNN_HIP(hipEventElapsedTime(ms, e0, e1));
+        return GNN_OK;
+    };
+    float ms = 0.f;
+    int rc = run(20000, &ms);                       // calibration (also warms the clocks)
+    int iters = 20000;
+    if (!rc) {
+        iters = (int)std::min<double>(2.0e9, std::max(20000.0, 20000.0 * ms_target / std::max(ms, 1e-3f)));
+        rc = run(iters, &ms);
+    }
+    if (!rc) *tflops_out = (double)blocks * 4 /*waves*/ * iters * 12.0 * 32768.0 / (ms * 1e-3) / 1e12;
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    (void)hipFree(dop);
+    (void)hipFree(dsink);
+    return rc;
+}

@@ -190,6 +190,11 @@ int gnn_profile_get(gnn_ctx* ctx, int kernel_id, double* total_ms, int64_t* laun
  * conv3 epilogue, m-partials B, w_v+pool B. */
 int gnn_phase_cycles(gnn_ctx* ctx, int on, unsigned long long* out10);
 
+/* measurement aid: sustained dense bf16 rate (TFLOP/s) of v_mfma_f32_32x32x16_bf16 with one wave per
+ * SIMD and register operands, run for about ms_target milliseconds — the practical MFMA ceiling of
+ * this (power-managed) chip, reported by bench.py beside the fused kernel's issued-MFMA rate. */
+int gnn_mfma_probe(gnn_ctx* ctx, int ms_target, double* tflops_out);
+
 /* windows the ctx processes per launch of the fused front end (workspace sizing) */
 int gnn_set_chunk(gnn_ctx* ctx, int64_t windows_per_chunk);
 
