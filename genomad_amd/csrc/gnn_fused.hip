@@ -38,7 +38,8 @@ constexpr int TOK_COUNT = ((FSTEPS * FT + CARRY + KS) + 7) / 8 * 8;   // 6032
 constexpr int SMEM_BYTES = TOK_OFF + ((TOK_COUNT * 2 + 15) / 16) * 16;
 constexpr int FRAG_U4 = 64;                  // one fragment = 64 lanes x uint4
 
-__device__ __forceinline__ float lrelu_f(float v) { return v > 0.f ? v : v * LRELU; }
+// LeakyReLU(0.1) = max(v, 0.1 v) since the slope is < 1: two VALU ops instead of mul + compare + select
+__device__ __forceinline__ float lrelu_f(float v) { return fmaxf(v, v * LRELU); }
 
 __device__ __forceinline__ int base_code_f(uint32_t b) {
     return b == 65 ? 0 : (b == 67 ? 1 : (b == 71 ? 2 : (b == 84 ? 3 : -1)));
@@ -317,35 +318,47 @@ __device__ __forceinline__ uint32_t pair_row(int a, int b) {
 // xbuf.  conv1 on a one-hot input is a 6-row gather-sum of its kernel (model.py:11 + igloo.py:45-48);
 // with the pair tables it is 3 rows: taps (0,1), (2,3), (4,5) of position t read the pairs starting
 // at t-5, t-3, t-1.  prow[j] is the pair row of positions (j-5, j-4).  256 helper threads:
-// thread = 4 channels x 16 positions.
-template <int IT0, int IT1>   // iterations IT0..IT1 of 16 (8 positions each)
+// thread = 4 channels x 16 CONSECUTIVE positions, so the 20 pair rows it needs are 40 contiguous
+// bytes of LDS, fetched with three wide reads up front: the LDS pipe is busy feeding the matrix
+// waves, and per-position index reads in the dependency chain of every load batch were what made
+// the gather 4x slower beside the MFMA loops than alone.  Positions P0..P1 (of 16) are produced.
+#ifndef GNN_GATHER_EARLY
+#define GNN_GATHER_EARLY 4      // positions (of 16 per thread) of the next step's gather done between B1 and B2
+#endif
+template <int P0, int P1>
 __device__ __forceinline__ void conv1_gather(unsigned char* __restrict__ xbuf, const uint16_t* __restrict__ prow,
                                              const float* __restrict__ pt, const float* __restrict__ b1,
                                              int t0, int ht) {
-    const int cq = ht & 31;
+    const int cq = ht & 31, ug = ht >> 5;
     const f32x4 b = *reinterpret_cast<const f32x4*>(b1 + cq * 4);
-#ifndef GNN_GATHER_UNROLL
-#define GNN_GATHER_UNROLL 4
-#endif
-#ifndef GNN_GATHER_EARLY
-#define GNN_GATHER_EARLY 4      // iterations of the next step's gather done between B1 and B2
-#endif
-#pragma unroll GNN_GATHER_UNROLL
-    for (int it = IT0; it < IT1; ++it) {
-        const int u = (ht >> 5) + it * 8;
-        f32x4 v = b;
+    const unsigned char* pr = reinterpret_cast<const unsigned char*>(prow + t0 + ug * 16);   // 32-B aligned
+    const uint4 r0 = *reinterpret_cast<const uint4*>(pr), r1 = *reinterpret_cast<const uint4*>(pr + 16);
+    const uint2 r2 = *reinterpret_cast<const uint2*>(pr + 32);
+    const uint32_t rw[10] = {r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, r1.z, r1.w, r2.x, r2.y};
+    const float* ptc = pt + cq * 4;
 #pragma unroll
-        for (int j = 0; j < 3; ++j) {
-            const uint32_t r = prow[t0 + u + 2 * j];
-            v += *reinterpret_cast<const f32x4*>(pt + ((size_t)j * PAIR_ROWS + r) * C + cq * 4);
+    for (int i0 = P0; i0 < P1; i0 += 4) {
+        f32x4 v[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            v[i] = b;
+#pragma unroll
+            for (int j = 0; j < 3; ++j) {
+                const int e = i0 + i + 2 * j;                           // static after unrolling
+                const uint32_t r = (rw[e >> 1] >> ((e & 1) * 16)) & 0xFFFFu;
+                v[i] += *reinterpret_cast<const f32x4*>(ptc + ((size_t)j * PAIR_ROWS + r) * C);
+            }
         }
 #pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] = lrelu_f(v[e]);
-        const bf16x4 h = __builtin_convertvector(v, bf16x4);
-        const bf16x4 l = __builtin_convertvector(v - __builtin_convertvector(h, f32x4), bf16x4);
-        unsigned char* o = xbuf + (CARRY + u) * ROWB + cq * 8;
-        *reinterpret_cast<uint2*>(o) = __builtin_bit_cast(uint2, h);
-        *reinterpret_cast<uint2*>(o + LO_OFF) = __builtin_bit_cast(uint2, l);
+        for (int i = 0; i < 4; ++i) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[i][e] = fmaxf(v[i][e], v[i][e] * LRELU);   // LeakyReLU(0.1)
+            const bf16x4 h = __builtin_convertvector(v[i], bf16x4);
+            const bf16x4 l = __builtin_convertvector(v[i] - __builtin_convertvector(h, f32x4), bf16x4);
+            unsigned char* o = xbuf + (CARRY + ug * 16 + i0 + i) * ROWB + cq * 8;
+            *reinterpret_cast<uint2*>(o) = __builtin_bit_cast(uint2, h);
+            *reinterpret_cast<uint2*>(o + LO_OFF) = __builtin_bit_cast(uint2, l);
+        }
     }
 }
 
