@@ -1,0 +1,218 @@
+"""Read the reference's trained weights (Keras legacy HDF5, ``genomad/data/nn_classifier.h5``)
+into this repo's weight schema — SURVEY.md §8f rank 2.
+
+The blob is NOT in the reference checkout (.MISSING_LARGE_BLOBS), so the exact group nesting of
+the file could not be inspected.  The reader is therefore nesting-agnostic: it walks every dataset
+with libhdf5 (through ctypes; h5py is not required), keeps those whose leaf name is one of the
+Keras weight names of model.py:14-45 / igloo.py:129-188, and assigns them by NAME + SHAPE:
+
+  kernel (6,257,128) -> conv1; the two (6,128,128) kernels -> conv2, conv3 in natural order of their
+  layer paths (conv1d_1 < conv1d_2); the IGLOO tensors are grouped by parent path, first group = head
+  A (igloo.py:54-62), second = head B (:73-81); Dense kernels by shape (256,512)/(512,512)/(512,3);
+  BatchNormalization groups in natural order (encoder's first, model.py:29, then the head's, :41);
+  biases are taken from the group of their kernel.
+
+Every schema tensor must be filled exactly once, otherwise a ValueError lists what is missing or
+ambiguous.  ``convert(h5_path, npz_path)`` writes the schema ``.npz`` that ``main()`` loads.
+"""
+import ctypes as C
+import ctypes.util
+import os
+import re
+
+import numpy as np
+
+from . import weights as W
+
+_hid = C.c_int64
+_H5F_ACC_RDONLY, _H5F_ACC_TRUNC, _H5P_DEFAULT = 0, 2, 0
+_H5I_DATASET = 5
+_H5T_INTEGER, _H5T_FLOAT = 0, 1
+_LEAVES = {"kernel", "bias", "gamma", "beta", "moving_mean", "moving_variance", "random_patches",
+           "w_mult", "w_summer", "w_bias", "w_qk", "w_v"}
+
+_lib = None
+
+
+def _h5():
+    global _lib
+    if _lib is not None:
+        return _lib
+    cands = [os.environ.get("GENOMAD_AMD_LIBHDF5"), ctypes.util.find_library("hdf5"),
+             "/opt/conda/lib/libhdf5.so", "libhdf5.so", "libhdf5_serial.so"]
+    for c in cands:
+        if not c:
+            continue
+        try:
+            lib = C.CDLL(c)
+            break
+        except OSError:
+            continue
+    else:
+        raise RuntimeError("libhdf5 not found (set GENOMAD_AMD_LIBHDF5); it is only needed to convert "
+                           "nn_classifier.h5 once")
+    sig = {
+        "H5open": (C.c_int, []), "H5Fopen": (_hid, [C.c_char_p, C.c_uint, _hid]),
+        "H5Fcreate": (_hid, [C.c_char_p, C.c_uint, _hid, _hid]), "H5Fclose": (C.c_int, [_hid]),
+        "H5Gcreate2": (_hid, [_hid, C.c_char_p, _hid, _hid, _hid]), "H5Gclose": (C.c_int, [_hid]),
+        "H5Oopen": (_hid, [_hid, C.c_char_p, _hid]), "H5Oclose": (C.c_int, [_hid]),
+        "H5Iget_type": (C.c_int, [_hid]), "H5Dget_space": (_hid, [_hid]), "H5Dget_type": (_hid, [_hid]),
+        "H5Tget_class": (C.c_int, [_hid]), "H5Tclose": (C.c_int, [_hid]), "H5Sclose": (C.c_int, [_hid]),
+        "H5Sget_simple_extent_ndims": (C.c_int, [_hid]),
+        "H5Sget_simple_extent_dims": (C.c_int, [_hid, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
+        "H5Dread": (C.c_int, [_hid, _hid, _hid, _hid, _hid, C.c_void_p]),
+        "H5Screate_simple": (_hid, [C.c_int, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
+        "H5Dcreate2": (_hid, [_hid, C.c_char_p, _hid, _hid, _hid, _hid, _hid]),
+        "H5Dwrite": (C.c_int, [_hid, _hid, _hid, _hid, _hid, C.c_void_p]), "H5Dclose": (C.c_int, [_hid]),
+        "H5Lexists": (C.c_int, [_hid, C.c_char_p, _hid]),
+    }
+    for name, (res, args) in sig.items():
+        fn = getattr(lib, name)
+        fn.restype, fn.argtypes = res, args
+    lib.H5open()
+    _lib = lib
+    return lib
+
+
+_VISIT_CB = C.CFUNCTYPE(C.c_int, _hid, C.c_char_p, C.c_void_p, C.c_void_p)
+
+
+def read_datasets(path) -> dict:
+    """{dataset path: numpy array} for every float / integer dataset of an HDF5 file."""
+    h = _h5()
+    fid = h.H5Fopen(str(path).encode(), _H5F_ACC_RDONLY, _H5P_DEFAULT)
+    if fid < 0:
+        raise OSError(f"cannot open HDF5 file {path}")
+    names = []
+    h.H5Lvisit.restype = C.c_int
+    h.H5Lvisit.argtypes = [_hid, C.c_int, C.c_int, _VISIT_CB, C.c_void_p]
+    cb = _VISIT_CB(lambda g, name, info, data: names.append(name.decode()) or 0)
+    if h.H5Lvisit(fid, 0, 0, cb, None) < 0:      # H5_INDEX_NAME, H5_ITER_INC
+        h.H5Fclose(fid)
+        raise OSError(f"cannot walk {path}")
+    out = {}
+    f32 = _hid.in_dll(h, "H5T_NATIVE_FLOAT_g").value
+    i32 = _hid.in_dll(h, "H5T_NATIVE_INT32_g").value
+    for name in names:
+        oid = h.H5Oopen(fid, name.encode(), _H5P_DEFAULT)
+        if oid < 0:
+            continue
+        if h.H5Iget_type(oid) == _H5I_DATASET:
+            sid, tid = h.H5Dget_space(oid), h.H5Dget_type(oid)
+            nd = h.H5Sget_simple_extent_ndims(sid)
+            dims = (C.c_uint64 * max(nd, 1))()
+            if nd > 0:
+                h.H5Sget_simple_extent_dims(sid, dims, None)
+            shape = tuple(int(d) for d in dims[:nd])
+            cls = h.H5Tget_class(tid)
+            if cls in (_H5T_INTEGER, _H5T_FLOAT):
+                arr = np.empty(shape, dtype=np.float32 if cls == _H5T_FLOAT else np.int32)
+                if h.H5Dread(oid, f32 if cls == _H5T_FLOAT else i32, 0, 0, _H5P_DEFAULT, arr.ctypes.data) >= 0:
+                    out[name] = arr
+            h.H5Tclose(tid)
+            h.H5Sclose(sid)
+        h.H5Oclose(oid)
+    h.H5Fclose(fid)
+    return out
+
+
+def write_datasets(path, datasets: dict) -> None:
+    """Write {dataset path: array} (float32 / int32) creating intermediate groups — used by the tests
+    to build Keras-shaped fixtures; not part of the product path."""
+    h = _h5()
+    fid = h.H5Fcreate(str(path).encode(), _H5F_ACC_TRUNC, _H5P_DEFAULT, _H5P_DEFAULT)
+    if fid < 0:
+        raise OSError(f"cannot create {path}")
+    f32 = _hid.in_dll(h, "H5T_NATIVE_FLOAT_g").value
+    i32 = _hid.in_dll(h, "H5T_NATIVE_INT32_g").value
+    for name, arr in datasets.items():
+        parts = name.strip("/").split("/")
+        for i in range(1, len(parts)):
+            g = "/".join(parts[:i]).encode()
+            if h.H5Lexists(fid, g, _H5P_DEFAULT) <= 0:
+                h.H5Gclose(h.H5Gcreate2(fid, g, _H5P_DEFAULT, _H5P_DEFAULT, _H5P_DEFAULT))
+        a = np.ascontiguousarray(arr, dtype=np.int32 if np.asarray(arr).dtype.kind in "iu" else np.float32)
+        dims = (C.c_uint64 * max(a.ndim, 1))(*a.shape)
+        sid = h.H5Screate_simple(a.ndim, dims, None)
+        t = i32 if a.dtype == np.int32 else f32
+        did = h.H5Dcreate2(fid, name.strip("/").encode(), t, sid, _H5P_DEFAULT, _H5P_DEFAULT, _H5P_DEFAULT)
+        h.H5Dwrite(did, t, 0, 0, _H5P_DEFAULT, a.ctypes.data)
+        h.H5Dclose(did)
+        h.H5Sclose(sid)
+    h.H5Fclose(fid)
+
+
+def _natural(s):
+    return [int(t) if t.isdigit() else t for t in re.split(r"(\d+)", s)]
+
+
+def assign(datasets: dict) -> dict:
+    """Map {h5 path: array} to the repo's weight schema by leaf name + shape (see module docstring)."""
+    items = []
+    for path, arr in datasets.items():
+        leaf = path.rsplit("/", 1)[-1].split(":")[0]
+        if leaf in _LEAVES:
+            items.append((path.rsplit("/", 1)[0] if "/" in path else "", leaf, arr))
+
+    def pick(leaf, shape):
+        # order by LAYER name (last group component: conv1d_1 < conv1d_2, batch_normalization <
+        # batch_normalization_1), not by full path: the encoder's layers may sit in a nested group
+        return sorted([(g, a) for g, l, a in items if l == leaf and tuple(a.shape) == shape],
+                      key=lambda x: (_natural(x[0].rsplit("/", 1)[-1]), _natural(x[0])))
+
+    def one(leaf, shape, what):
+        c = pick(leaf, shape)
+        if len(c) != 1:
+            raise ValueError(f"{what}: expected exactly one '{leaf}' of shape {shape}, found {len(c)}")
+        return c[0]
+
+    def in_group(group, leaf, shape, what):
+        c = [a for g, l, a in items if g == group and l == leaf and tuple(a.shape) == shape]
+        if len(c) != 1:
+            raise ValueError(f"{what}: expected one '{leaf}' {shape} in group '{group}', found {len(c)}")
+        return c[0]
+
+    out = {}
+    g1, out["conv1_kernel"] = one("kernel", (6, 257, 128), "conv1")
+    out["conv1_bias"] = in_group(g1, "bias", (128,), "conv1")
+    convs = pick("kernel", (6, 128, 128))
+    if len(convs) != 2:
+        raise ValueError(f"expected two (6,128,128) conv kernels (conv2, conv3), found {len(convs)}")
+    for name, (g, a) in zip(("conv2", "conv3"), convs):
+        out[f"{name}_kernel"], out[f"{name}_bias"] = a, in_group(g, "bias", (128,), name)
+    heads = pick("w_qk", (2100, 749))
+    if len(heads) != 2:
+        raise ValueError(f"expected two IGLOO heads (w_qk of shape (2100,749)), found {len(heads)}")
+    for name, (g, a) in zip(("iglooA", "iglooB"), heads):
+        out[f"{name}_w_qk"] = a
+        out[f"{name}_patches"] = in_group(g, "random_patches", (2100, 4, 1), name)
+        out[f"{name}_w_mult"] = in_group(g, "w_mult", (1, 2100, 4, 128), name)
+        out[f"{name}_w_summer"] = in_group(g, "w_summer", (1, 512, 1), name)
+        out[f"{name}_w_bias"] = in_group(g, "w_bias", (1, 2100), name)
+        out[f"{name}_w_v"] = in_group(g, "w_v", (1, 128, 128), name)
+    for name, shape, nb in (("enc_dense", (256, 512), 512), ("head_dense", (512, 512), 512), ("out_dense", (512, 3), 3)):
+        g, a = one("kernel", shape, name)
+        out[f"{name}_kernel"], out[f"{name}_bias"] = a, in_group(g, "bias", (nb,), name)
+    bns = pick("gamma", (512,))
+    if len(bns) != 2:
+        raise ValueError(f"expected two BatchNormalization layers, found {len(bns)}")
+    for name, (g, a) in zip(("enc_bn", "head_bn"), bns):
+        out[f"{name}_gamma"] = a
+        out[f"{name}_beta"] = in_group(g, "beta", (512,), name)
+        out[f"{name}_mean"] = in_group(g, "moving_mean", (512,), name)
+        out[f"{name}_var"] = in_group(g, "moving_variance", (512,), name)
+    return W.validate(out)
+
+
+def load_h5(path) -> dict:
+    return assign(read_datasets(path))
+
+
+def convert(h5_path, npz_path) -> None:
+    W.save_npz(npz_path, load_h5(h5_path))
+
+
+if __name__ == "__main__":
+    import sys
+    convert(sys.argv[1], sys.argv[2])
+    print(f"wrote {sys.argv[2]}")

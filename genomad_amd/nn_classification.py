@@ -139,6 +139,7 @@ def find_weights() -> Path:
     try:
         from genomad._paths import GenomadData   # only when the reference package is installed
         cand.append(Path(GenomadData.nn_model_file).with_suffix(".npz"))
+        cand.append(Path(GenomadData.nn_model_file))          # the reference's own Keras HDF5 blob
     except Exception:  # noqa: BLE001
         pass
     for c in cand:
@@ -146,7 +147,17 @@ def find_weights() -> Path:
             return c
     raise FileNotFoundError(
         "nn classifier weights not found: set GENOMAD_AMD_WEIGHTS to an .npz in the schema of "
-        "genomad_amd/weights.py (the reference's nn_classifier.h5 must be converted once)")
+        "genomad_amd/weights.py, or to the reference's nn_classifier.h5 (read through libhdf5, "
+        "see genomad_amd/h5weights.py)")
+
+
+def load_weights_file(path: Path) -> dict:
+    """``.npz`` in the repo schema, or the reference's Keras HDF5 (genomad/data/nn_classifier.h5)."""
+    from . import weights as W
+    if Path(path).suffix.lower() in (".h5", ".hdf5"):
+        from . import h5weights
+        return h5weights.load_h5(path)
+    return W.load_npz(path)
 
 
 _ENGINE = None
@@ -157,14 +168,13 @@ def _engine():
     weights are uploaded once and reused for the provirus pass)."""
     global _ENGINE
     if _ENGINE is None:
-        from . import weights as W
         from .engine import NNEngine
         # the reference module sets CUDA_VISIBLE_DEVICES=-1 at import (nn_classification.py:8), which
         # HIP honours; undo it before the HIP runtime is initialised
         if os.environ.get("CUDA_VISIBLE_DEVICES") == "-1":
             del os.environ["CUDA_VISIBLE_DEVICES"]
         device = int(os.environ.get("GENOMAD_AMD_DEVICE", os.environ.get("LOCAL_RANK", "0")))
-        _ENGINE = NNEngine(device, W.load_npz(find_weights()))
+        _ENGINE = NNEngine(device, load_weights_file(find_weights()))
     return _ENGINE
 
 

@@ -226,3 +226,51 @@ def test_packed_reader_and_candidate_spans_match_reference_rules(golden_dir, tmp
     for L in (1, 2499, 2500, 6000, 8499, 8500, 14499, 14500, 20500):
         st, ln, _, _ = sequence.candidate_spans(np.array([0, L]))
         assert list(ln) == [b - a for a, b in sequence.window_spans(L)]
+
+
+def test_keras_h5_weight_ingestion_roundtrip(synth_weights, tmp_path):
+    """a Keras-legacy-shaped HDF5 file (layer groups, ':0' suffixes, nested encoder
+    model, an optimizer group that must be ignored) is read back into the repo schema by name + shape."""
+    h5 = pytest.importorskip("genomad_amd.h5weights")
+    try:
+        h5._h5()
+    except RuntimeError as exc:
+        pytest.skip(str(exc))
+    w = synth_weights
+    enc = "model_weights/functional_1"          # the frozen encoder is a nested model (model.py:34-38)
+    layout = {}
+
+    def put(group, **tensors):
+        for k, v in tensors.items():
+            layout[f"{group}/{k}:0"] = v
+    put(f"{enc}/conv1d/conv1d", kernel=w["conv1_kernel"], bias=w["conv1_bias"])
+    put(f"{enc}/conv1d_1/conv1d_1", kernel=w["conv2_kernel"], bias=w["conv2_bias"])
+    put(f"{enc}/conv1d_2/conv1d_2", kernel=w["conv3_kernel"], bias=w["conv3_bias"])
+    for g, hname in ((f"{enc}/igloo1d_kernel/igloo1d_kernel", "iglooA"), (f"{enc}/igloo1d_kernel_1/igloo1d_kernel_1", "iglooB")):
+        put(g, random_patches=w[f"{hname}_patches"], w_mult=w[f"{hname}_w_mult"], w_summer=w[f"{hname}_w_summer"],
+            w_bias=w[f"{hname}_w_bias"], w_qk=w[f"{hname}_w_qk"], w_v=w[f"{hname}_w_v"])
+    put(f"{enc}/dense/dense", kernel=w["enc_dense_kernel"], bias=w["enc_dense_bias"])
+    put(f"{enc}/batch_normalization/batch_normalization", gamma=w["enc_bn_gamma"], beta=w["enc_bn_beta"],
+        moving_mean=w["enc_bn_mean"], moving_variance=w["enc_bn_var"])
+    put("model_weights/dense_1/dense_1", kernel=w["head_dense_kernel"], bias=w["head_dense_bias"])
+    put("model_weights/batch_normalization_1/batch_normalization_1", gamma=w["head_bn_gamma"], beta=w["head_bn_beta"],
+        moving_mean=w["head_bn_mean"], moving_variance=w["head_bn_var"])
+    put("model_weights/dense_2/dense_2", kernel=w["out_dense_kernel"], bias=w["out_dense_bias"])
+    layout["optimizer_weights/adam/iteration:0"] = np.array([7], dtype=np.int32)
+    layout["optimizer_weights/adam/dense_2_kernel_momentum:0"] = np.zeros((512, 3), np.float32)
+    path = tmp_path / "nn_classifier.h5"
+    h5.write_datasets(path, layout)
+    got = h5.load_h5(path)
+    assert set(got) == set(w)
+    for k in w:
+        assert np.array_equal(got[k], w[k]), k
+    h5.convert(path, tmp_path / "w.npz")
+    from genomad_amd import weights as W
+    back = W.load_npz(tmp_path / "w.npz")
+    assert all(np.array_equal(back[k], w[k]) for k in w)
+    # a file with a missing tensor is rejected with a message, not silently accepted
+    bad = dict(layout)
+    del bad[f"{enc}/conv1d_2/conv1d_2/kernel:0"]
+    h5.write_datasets(tmp_path / "bad.h5", bad)
+    with pytest.raises(ValueError, match="conv"):
+        h5.load_h5(tmp_path / "bad.h5")
