@@ -76,6 +76,7 @@ SIGNATURES = {
     "gnn_set_chunk": (_int, [_vp, _i64]),
     "gnn_phase_cycles": (_int, [_vp, _int, C.POINTER(C.c_uint64)]),
     "gnn_mfma_probe": (_int, [_vp, _int, C.POINTER(C.c_double)]),
+    "gnn_crc32c": (C.c_uint32, [_vp, _sz]),
 }
 
 _lib = None

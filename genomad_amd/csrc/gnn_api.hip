@@ -171,6 +171,38 @@ const char* gnn_last_error(void) { return g_last_error.c_str(); }
 
 int gnn_version(void) { return 100; }
 
+// CRC-32C (Castagnoli, reflected polynomial 0x82F63B78) of a host buffer — the checksum of the
+// TFRecord framing the reference writes its encoded windows with (nn_classification.py:43-52).
+// Host-only utility (slicing-by-8); no GPU involved.
+uint32_t gnn_crc32c(const void* data, size_t n) {
+    static uint32_t tab[8][256];
+    static bool init = false;
+    if (!init) {
+        for (uint32_t i = 0; i < 256; ++i) {
+            uint32_t c = i;
+            for (int k = 0; k < 8; ++k) c = (c >> 1) ^ (0x82F63B78u & (0u - (c & 1u)));
+            tab[0][i] = c;
+        }
+        for (uint32_t i = 0; i < 256; ++i)
+            for (int t = 1; t < 8; ++t) tab[t][i] = (tab[t - 1][i] >> 8) ^ tab[0][tab[t - 1][i] & 0xFF];
+        init = true;
+    }
+    const unsigned char* p = static_cast<const unsigned char*>(data);
+    uint32_t c = 0xFFFFFFFFu;
+    while (n >= 8) {
+        uint32_t lo, hi;
+        std::memcpy(&lo, p, 4);
+        std::memcpy(&hi, p + 4, 4);
+        lo ^= c;
+        c = tab[7][lo & 0xFF] ^ tab[6][(lo >> 8) & 0xFF] ^ tab[5][(lo >> 16) & 0xFF] ^ tab[4][lo >> 24] ^
+            tab[3][hi & 0xFF] ^ tab[2][(hi >> 8) & 0xFF] ^ tab[1][(hi >> 16) & 0xFF] ^ tab[0][hi >> 24];
+        p += 8;
+        n -= 8;
+    }
+    while (n--) c = (c >> 8) ^ tab[0][(c ^ *p++) & 0xFF];
+    return c ^ 0xFFFFFFFFu;
+}
+
 int gnn_device_count(int* count) {
     if (!count) {
         set_error("count is NULL");

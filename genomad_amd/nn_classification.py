@@ -252,7 +252,8 @@ def main(input_path, output_path, single_window, batch_size, restart, threads, v
 
     def stage(fasta, enc_dir, wid_path, npz_path, tsv_path, names_key, ids_key, what):
         windows = None
-        if skip and wid_path.exists() and len(list(enc_dir.glob("*.win.npy"))):      # :215-225
+        if skip and wid_path.exists() and (len(list(enc_dir.glob("*.win.npy")))
+                                           or len(list(enc_dir.glob("*.tfrec")))):   # :215-225
             console.log(f"{enc_dir.name} was found. Skipping {what} encoding.")
             z = np.load(wid_path)
             names, ids = z[names_key], z[ids_key]
@@ -272,7 +273,13 @@ def main(input_path, output_path, single_window, batch_size, restart, threads, v
         else:
             if windows is None:
                 files = sorted(enc_dir.glob("*.win.npy"))
-                windows = np.concatenate([np.load(f) for f in files]) if files else np.zeros((0, 6000), np.uint8)
+                if files:
+                    windows = np.concatenate([np.load(f) for f in files])
+                else:
+                    # a directory encoded by the reference itself (TFRecords of tokens, :43-52): rebuild
+                    # windows that tokenise to exactly those tokens
+                    from . import tfrecord
+                    windows = tfrecord.tokens_to_bases(tfrecord.read_dir(enc_dir))
             if not len(windows):                                                     # :297-299
                 console.error("No sequences were found. Please check your input FASTA.")
                 sys.exit(1)

@@ -164,6 +164,10 @@ int gnn_span_byte_count(gnn_ctx* ctx, const uint8_t* seq_dev, const int64_t* sta
 int gnn_classify_spans(gnn_ctx* ctx, const uint8_t* seq_dev, const int64_t* starts_host,
                        const int32_t* lens_host, int64_t n_spans, int precision, float* scores_host);
 
+/* CRC-32C (Castagnoli) of a host buffer: the checksum of the TFRecord framing that the reference's
+ * write_tfrecord produces (nn_classification.py:43-52); used by genomad_amd/tfrecord.py. Host only. */
+uint32_t gnn_crc32c(const void* data_host, size_t n_bytes);
+
 /* same forward as gnn_classify, also copying intermediates out (parity tests). */
 int gnn_debug_forward(gnn_ctx* ctx, const uint8_t* bases_host, int64_t n_windows, int precision,
                       float* scores_host, const gnn_taps* taps);

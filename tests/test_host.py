@@ -274,3 +274,69 @@ def test_keras_h5_weight_ingestion_roundtrip(synth_weights, tmp_path):
     h5.write_datasets(tmp_path / "bad.h5", bad)
     with pytest.raises(ValueError, match="conv"):
         h5.load_h5(tmp_path / "bad.h5")
+
+
+def test_tfrecord_wire_format(tmp_path):
+    """TFRecord framing + tf.train.Example encoding without TensorFlow."""
+    from genomad_amd import _lib, synthetic, tfrecord
+    lib = _lib.load()
+    assert lib.gnn_crc32c(b"123456789", 9) == 0xE3069283            # CRC-32C check value
+    assert lib.gnn_crc32c(b"", 0) == 0
+    # the serialisation of Example{features{feature{"sequence": int64_list[1,2,3]}}}
+    assert tfrecord.encode_example(np.array([1, 2, 3])) == \
+        b"\n\x15\n\x13\n\x08sequence\x12\x07\x1a\x05\n\x03\x01\x02\x03"
+    assert tfrecord.encode_example(np.array([0, 127, 128, 256])).endswith(b"\n\x06\x00\x7f\x80\x01\x80\x02")
+    bases = synthetic.synth_windows(0, 12)
+    toks = sequence_oracle.tokenize_closed_form(bases)
+    p = tmp_path / "12.tfrec"
+    tfrecord.write_file(p, toks)
+    raw = p.read_bytes()
+    n0 = int.from_bytes(raw[:8], "little")
+    assert len(tfrecord.encode_example(toks[0])) == n0 and len(raw) > 12 * (5997 + 16)
+    assert np.array_equal(tfrecord.read_file(p), toks)
+    corrupt = bytearray(raw)
+    corrupt[40] ^= 1
+    (tmp_path / "bad.tfrec").write_bytes(bytes(corrupt))
+    with pytest.raises(ValueError, match="corrupt"):
+        tfrecord.read_file(tmp_path / "bad.tfrec")
+    # file naming of generate_data: 10 000 per file, named by the running count
+    monkey = tfrecord.RECORDS_PER_FILE
+    tfrecord.RECORDS_PER_FILE = 5
+    try:
+        files = tfrecord.write_dir(tmp_path, toks)
+        assert [f.name for f in files] == ["5.tfrec", "10.tfrec", "12.tfrec"]
+        (tmp_path / "bad.tfrec").unlink()
+        assert np.array_equal(tfrecord.read_dir(tmp_path), toks)     # 5 + 5 + 2 records, numeric file order
+    finally:
+        tfrecord.RECORDS_PER_FILE = monkey
+    # tokens -> bases -> tokens is the identity (windows 5 and 9 contain N padding / an N run)
+    back = tfrecord.tokens_to_bases(toks)
+    assert back.shape == (12, 6000)
+    assert np.array_equal(sequence_oracle.tokenize_closed_form(back), toks)
+
+
+def test_resume_from_a_reference_encoded_directory(tmp_path):
+    """An `_encoded_sequences` directory as the reference leaves it (``*.tfrec`` + seq_window_id.npz,
+    no .win.npy) is picked up on resume: tokens are turned back into equivalent windows."""
+    from genomad_amd import tfrecord
+    rng = np.random.default_rng(2)
+    fa = tmp_path / "r.fna"
+    _write_fasta(fa, [("k1", "".join(rng.choice(list("ACGTN"), 9000, p=[.24, .24, .24, .24, .04]))), ("k2", "ACGT" * 700)])
+    out = tmp_path / "out"
+    nnc.main(fa, out, False, 128, False, 1, False, False, _backend=FakeBackend())
+    d = out / "r_nn_classification"
+    first = np.load(d / "r_nn_classification.npz")["predictions"]
+    enc = d / "r_encoded_sequences"
+    (win,) = list(enc.glob("*.win.npy"))
+    windows = np.load(win)
+    tfrecord.write_dir(enc, sequence_oracle.tokenize_closed_form(windows))     # what the reference would have written
+    win.unlink()
+    (d / "r_nn_classification.npz").unlink()
+
+    class Check(FakeBackend):
+        def score(self, w):
+            # equivalent windows: identical tokens
+            assert np.array_equal(sequence_oracle.tokenize_closed_form(w), sequence_oracle.tokenize_closed_form(windows))
+            return FakeBackend.score(self, windows)
+    nnc.main(fa, out, False, 128, False, 1, False, False, _backend=Check())
+    assert np.array_equal(np.load(d / "r_nn_classification.npz")["predictions"], first)
