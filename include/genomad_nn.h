@@ -164,6 +164,20 @@ int gnn_span_byte_count(gnn_ctx* ctx, const uint8_t* seq_dev, const int64_t* sta
 int gnn_classify_spans(gnn_ctx* ctx, const uint8_t* seq_dev, const int64_t* starts_host,
                        const int32_t* lens_host, int64_t n_spans, int precision, float* scores_host);
 
+/* ---- downstream score consumers as a device epilogue, float64 like the
+ * reference's numpy ------------------------------------------------------------------------------ */
+/* replaces branch_attention(w, b1, b2, temperature) (aggregated_classification.py:10-34): w[n] marker
+ * frequency, b1[n][3] marker scores, b2[n][3] nn scores -> out[n][3]. */
+int gnn_branch_attention(gnn_ctx* ctx, const double* w_host, const double* b1_host, const double* b2_host,
+                         int64_t n, double temperature, double* out_host);
+/* replaces the inference part of score_batch_correction (score_calibration.py:37-43): scores[n][3] and
+ * the (already smoothed, :18-21) composition[3] through the 6->20->20->3 tanh MLP whose weights are the
+ * arrays of genomad/data/score_calibration_weights.npz (kernel_1 (6,20), bias_1, kernel_2 (20,20), ...). */
+int gnn_score_calibration(gnn_ctx* ctx, const double* scores_host, const double* composition3,
+                          const double* kernel1, const double* bias1, const double* kernel2,
+                          const double* bias2, const double* kernel3, const double* bias3, int64_t n,
+                          double* out_host);
+
 /* CRC-32C (Castagnoli) of a host buffer: the checksum of the TFRecord framing that the reference's
  * write_tfrecord produces (nn_classification.py:43-52); used by genomad_amd/tfrecord.py. Host only. */
 uint32_t gnn_crc32c(const void* data_host, size_t n_bytes);

@@ -140,6 +140,29 @@ def main():
         ypA_rows=taps["ypA"][:, [0, 374, 748]], ypB_rows=taps["ypB"][:, [0, 374, 748]],
         bases_sha256=np.array(hashlib.sha256(bases.tobytes()).hexdigest()),
         weights_sha256=np.array(hashlib.sha256(b"".join(W[k].tobytes() for k in sorted(W))).hexdigest()))
+    # Downstream consumers: plain numpy in the reference, so the REFERENCE'S OWN
+    # functions run here and pin the device epilogue.
+    import importlib
+    agg = importlib.import_module("genomad.modules.aggregated_classification")
+    cal = importlib.import_module("genomad.modules.score_calibration")
+    wfile = os.path.join(reference_harness.REFERENCE_ROOT, "genomad", "data", "score_calibration_weights.npz")
+    n = 257
+    w = rng.random(n) * 0.6
+    w[:3] = [0.0, 1.0, 0.5]
+    b1 = rng.dirichlet([1, 1, 1], n)
+    b2 = rng.dirichlet([0.3, 0.3, 0.3], n)
+    fixture = {"w": w, "b1": b1, "b2": b2,
+               "branch_attention_t2": agg.branch_attention(w, b1, b2),
+               "branch_attention_t1": agg.branch_attention(w, b1, b2, temperature=1)}
+    comps = np.array([[0.7, 0.1, 0.2], [1 / 3, 1 / 3, 1 / 3], [0.98, 0.01, 0.01], [0.0, 0.0, 1.0]])
+    fixture["compositions"] = comps
+    for ci, comp in enumerate(comps):
+        for classifier in ("nn", "marker", "aggregated", "something_else"):
+            fixture[f"calibrated_{ci}_{classifier}"] = cal.score_batch_correction(b2, comp, classifier, wfile)
+    with np.load(wfile) as z:                      # the MLP weights are data the test needs on the GPU box
+        for k in z.files:
+            fixture[f"weights__{k}"] = z[k]
+    np.savez_compressed(os.path.join(GOLDEN, "consumers_golden.npz"), **fixture)
     print("golden fixtures written to", GOLDEN)
 
 

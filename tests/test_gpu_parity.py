@@ -304,3 +304,22 @@ def test_contig_front_end_equals_window_path(engine, synth_weights, golden_dir):
         assert np.abs(contig_scores - oracle).max() <= SCORE_TOL
     empty, ids = engine.classify_contigs(np.zeros(0, np.uint8), np.zeros(1, np.int64))
     assert empty.shape == (0, 3) and len(ids) == 0
+
+
+# ------------------------------------------------------------------ downstream consumers
+def test_downstream_consumers_match_the_reference_functions(engine, golden_dir, tmp_path):
+    """branch_attention / score_batch_correction on the device vs the outputs of the REFERENCE's own
+    numpy functions (tests/golden/consumers_golden.npz, generated by running them in place) — the one
+    floating-point part of the reference that can execute here, so this parity is pinned.  f64: 1e-12."""
+    from genomad_amd import consumers
+    g = np.load(os.path.join(golden_dir, "consumers_golden.npz"))
+    for t, key in ((2, "branch_attention_t2"), (1, "branch_attention_t1")):
+        got = consumers.branch_attention(engine, g["w"], g["b1"], g["b2"], temperature=t)
+        assert np.abs(got - g[key]).max() < 1e-12
+    wfile = tmp_path / "score_calibration_weights.npz"
+    np.savez(wfile, **{k[len("weights__"):]: g[k] for k in g.files if k.startswith("weights__")})
+    for ci, comp in enumerate(g["compositions"]):
+        for classifier in ("nn", "marker", "aggregated", "something_else"):
+            got = consumers.score_batch_correction(engine, g["b2"], comp, classifier, wfile)
+            assert np.abs(got - g[f"calibrated_{ci}_{classifier}"]).max() < 1e-12, (ci, classifier)
+    assert consumers.branch_attention(engine, np.zeros(0), np.zeros((0, 3)), np.zeros((0, 3))).shape == (0, 3)
