@@ -16,7 +16,7 @@ for prec in sys.argv[2:] or ['bf16x3','bf16']:
     eng.profile_enable(False)
 
 import ctypes as C
-names = ["tokens","conv1 gather","m-part A","wv+pool A","conv2 loop","conv2 epi","conv3 loop","conv3 epi+carry","m-part B","wv+pool B"]
+names = ["w_v+pool A","conv2 loop","wait B1","conv2 epi+B2","conv3 loop","wait B3","conv3 epi+B4","w_v+pool B+B0","helper m-partials","helper gather (late part)"]
 for prec in sys.argv[2:] or ['bf16x3']:
     if prec == 'f32': continue
     _lib.check(eng.lib.gnn_phase_cycles(eng.ctx, 1, None))
