@@ -50,10 +50,11 @@ __device__ __forceinline__ int base_code_f(uint32_t b) {
 // lane ends up with 4 consecutive channels of one position -> 8-byte LDS writes).  !SWAP: D = X W
 // (rows are positions; used by y@w_v so that the 8-row max-pool is 4 registers + one lane swap).
 //
-// Software pipeline (one wave per SIMD, so nothing else hides latency): weight fragments are
-// fetched from L2 two k-steps ahead, activation fragments from LDS one k-step ahead; the
-// sched_barriers keep hipcc from sinking the loads back down to their first use (it otherwise
-// emits load; s_waitcnt vmcnt(0); mfma — every L2 round trip exposed).
+// Software pipeline (one matrix wave per SIMD, so nothing else hides its latency): weight fragments
+// are fetched from L2 three k-steps ahead (ring of four), activation fragments from LDS one k-step
+// ahead (ring of two); sched_group_barriers interleave the loads 1:1 with the MFMAs and the
+// sched_barrier at the end of a k-step keeps hipcc from sinking loads back down to their first use
+// (left alone it emits load; s_waitcnt vmcnt(0); mfma — every L2 round trip exposed).
 template <int PASSES>
 struct WFrag {
     uint4 v[PASSES == 3 ? 2 : 1];
@@ -404,9 +405,9 @@ __global__ __launch_bounds__(512, 2) void fused_front_kernel(FusedArgs a) {
     }
     __syncthreads();
     if (helper) conv1_gather<0, FT / 8>(bufX, toks, a.conv1_k, a.conv1_b, 0, ht);
-#ifndef GNN_NO_SETPRIO
-    else __builtin_amdgcn_s_setprio(2);      // the matrix waves win issue arbitration on their SIMD
-#endif
+    // static priority for the matrix waves (measured neutral against no priority and against
+    // prioritising the helpers; kept so the matrix pipe never loses an issue slot to a helper)
+    else __builtin_amdgcn_s_setprio(2);
 
     unsigned long long cyc[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     unsigned long long tick_ = 0;
