@@ -89,19 +89,19 @@ __global__ __launch_bounds__(256) void tokenize_kernel(const uint8_t* __restrict
 }
 
 // Stand-alone encoder (HBM-write bound).  The output (n, 5997, 257) is one flat array; a block owns
-// RB = 64 consecutive one-hot rows, i.e. 64*257*sizeof(OutT) bytes = a whole number of 16-byte
-// chunks starting on a 16-byte boundary.  The block first puts its 65 tokens into LDS (one 64-bit
+// RB = 128 consecutive one-hot rows, i.e. 128*257*sizeof(OutT) bytes = a whole number of 16-byte
+// chunks starting on a 16-byte boundary.  The block first puts its 129 tokens into LDS (one 64-bit
 // division per token, not per chunk), then every thread produces 16-byte chunks with 32-bit index
 // math: a chunk is all zero except at most two elements (257 > 16: it touches at most two rows), so
 // it is built as four dwords with at most two OR-ed in, and written with one coalesced 16-byte store
 // (a wave writes 1 KiB contiguous).
-constexpr int RB = 64;
+constexpr int RB = 128;
 
 template <int ISZ>   // element size in bytes: 1 (u8), 2 (bf16), 4 (f32); `one` is the element's bit pattern
 __global__ __launch_bounds__(256) void onehot_kernel(const uint8_t* __restrict__ bases, int64_t n_rows,
                                                      uint4* __restrict__ out, uint32_t one) {
     constexpr int VEC = 16 / ISZ;                            // elements per 16-byte chunk
-    constexpr int CHUNKS = RB * GNN_DEPTH * ISZ / 16;        // chunks per full block (1028 / 2056 / 4112)
+    constexpr int CHUNKS = RB * GNN_DEPTH * ISZ / 16;        // chunks per full block (2056 / 4112 / 8224)
     __shared__ uint32_t tok[RB + 1];
     const int64_t row0 = (int64_t)blockIdx.x * RB;
     if (threadIdx.x <= RB) {
