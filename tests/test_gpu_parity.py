@@ -323,3 +323,22 @@ def test_downstream_consumers_match_the_reference_functions(engine, golden_dir, 
             got = consumers.score_batch_correction(engine, g["b2"], comp, classifier, wfile)
             assert np.abs(got - g[f"calibrated_{ci}_{classifier}"]).max() < 1e-12, (ci, classifier)
     assert consumers.branch_attention(engine, np.zeros(0), np.zeros((0, 3)), np.zeros((0, 3))).shape == (0, 3)
+
+
+def test_second_weight_set_and_engine(synth_weights):
+    """Nothing is specialised to the seed-42 weights: a second engine with other weights (other patch
+    positions -> other step buckets, larger conv gains) still matches the oracle; two engines coexist."""
+    from genomad_amd.engine import NNEngine
+    w2 = synthetic.synth_weights(seed=7)
+    w2["conv2_kernel"] = w2["conv2_kernel"] * 1.5          # different dynamic range
+    p = w2["iglooA_patches"].copy()
+    p[:300, :, 0] = np.sort(np.random.default_rng(1).integers(5880, 5997, (300, 4)), axis=1)   # crowd the last step
+    w2["iglooA_patches"] = p
+    bases = synthetic.synth_windows(40, 24)
+    want = igloo_oracle.classify_windows(bases, w2, np.float32)
+    with NNEngine(0, w2) as e2:
+        got = e2.classify(bases, "bf16x3")
+        exact = e2.classify(bases, "f32")
+    assert np.abs(exact - want).max() <= 2e-5
+    assert np.abs(got - want).max() <= SCORE_TOL
+    assert not np.array_equal(got, np.zeros_like(got))
