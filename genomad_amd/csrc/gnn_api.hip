@@ -175,18 +175,20 @@ int gnn_version(void) { return 100; }
 // TFRecord framing the reference writes its encoded windows with (nn_classification.py:43-52).
 // Host-only utility (slicing-by-8); no GPU involved.
 uint32_t gnn_crc32c(const void* data, size_t n) {
-    static uint32_t tab[8][256];
-    static bool init = false;
-    if (!init) {
-        for (uint32_t i = 0; i < 256; ++i) {
-            uint32_t c = i;
-            for (int k = 0; k < 8; ++k) c = (c >> 1) ^ (0x82F63B78u & (0u - (c & 1u)));
-            tab[0][i] = c;
+    struct Table {
+        uint32_t t[8][256];
+        Table() {
+            for (uint32_t i = 0; i < 256; ++i) {
+                uint32_t c = i;
+                for (int k = 0; k < 8; ++k) c = (c >> 1) ^ (0x82F63B78u & (0u - (c & 1u)));
+                t[0][i] = c;
+            }
+            for (uint32_t i = 0; i < 256; ++i)
+                for (int s = 1; s < 8; ++s) t[s][i] = (t[s - 1][i] >> 8) ^ t[0][t[s - 1][i] & 0xFF];
         }
-        for (uint32_t i = 0; i < 256; ++i)
-            for (int t = 1; t < 8; ++t) tab[t][i] = (tab[t - 1][i] >> 8) ^ tab[0][tab[t - 1][i] & 0xFF];
-        init = true;
-    }
+    };
+    static const Table table;            // thread-safe one-time initialisation (C++11 magic static)
+    const uint32_t(*tab)[256] = table.t;
     const unsigned char* p = static_cast<const unsigned char*>(data);
     uint32_t c = 0xFFFFFFFFu;
     while (n >= 8) {

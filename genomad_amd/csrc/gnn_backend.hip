@@ -269,9 +269,6 @@ extern "C" int gnn_segment_mean(gnn_ctx* ctx, const float* scores_host, const in
     GNN_HIP(hipSetDevice(ctx->device));
     float *ds = nullptr, *dout = nullptr;
     int64_t* di = nullptr;
-    GNN_HIP(hipMalloc((void**)&ds, std::max<size_t>(1, (size_t)n * GNN_CLASSES * sizeof(float))));
-    GNN_HIP(hipMalloc((void**)&di, std::max<size_t>(1, (size_t)n * sizeof(int64_t))));
-    GNN_HIP(hipMalloc((void**)&dout, (size_t)n_segments * GNN_CLASSES * sizeof(float)));
     int rc = GNN_OK;
     auto step = [&](hipError_t e, const char* what) {
         if (rc == GNN_OK && e != hipSuccess) {
@@ -279,7 +276,10 @@ extern "C" int gnn_segment_mean(gnn_ctx* ctx, const float* scores_host, const in
             rc = GNN_ERR_HIP;
         }
     };
-    if (n > 0) {
+    step(hipMalloc((void**)&ds, std::max<size_t>(1, (size_t)n * GNN_CLASSES * sizeof(float))), "hipMalloc scores");
+    step(hipMalloc((void**)&di, std::max<size_t>(1, (size_t)n * sizeof(int64_t))), "hipMalloc ids");
+    step(hipMalloc((void**)&dout, (size_t)n_segments * GNN_CLASSES * sizeof(float)), "hipMalloc out");
+    if (n > 0 && rc == GNN_OK) {
         step(hipMemcpyAsync(ds, scores_host, (size_t)n * GNN_CLASSES * sizeof(float), hipMemcpyHostToDevice, ctx->stream), "copy scores");
         step(hipMemcpyAsync(di, ids_host, (size_t)n * sizeof(int64_t), hipMemcpyHostToDevice, ctx->stream), "copy ids");
     }
