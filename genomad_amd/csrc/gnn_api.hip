@@ -686,15 +686,15 @@ static int drain_profile(gnn_ctx* ctx) {
 
 // Debug aid (not part of the hot path): run the fused kernel's instrumented build and return the
 // per-phase cycle sums of wave 0 of every workgroup.  on=1 allocates/zeroes, on=0 frees.
-int gnn_phase_cycles(gnn_ctx* ctx, int on, unsigned long long* out10) {
+int gnn_phase_cycles(gnn_ctx* ctx, int on, unsigned long long* out16) {
     int rc = check_ctx(ctx);
     if (rc) return rc;
     GNN_HIP(hipStreamSynchronize(ctx->stream));
-    if (out10 && ctx->phase_cycles)
-        GNN_HIP(hipMemcpy(out10, ctx->phase_cycles, 10 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    if (out16 && ctx->phase_cycles)
+        GNN_HIP(hipMemcpy(out16, ctx->phase_cycles, 16 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
     if (on) {
-        if (!ctx->phase_cycles) GNN_HIP(hipMalloc((void**)&ctx->phase_cycles, 10 * sizeof(unsigned long long)));
-        GNN_HIP(hipMemset(ctx->phase_cycles, 0, 10 * sizeof(unsigned long long)));
+        if (!ctx->phase_cycles) GNN_HIP(hipMalloc((void**)&ctx->phase_cycles, 16 * sizeof(unsigned long long)));
+        GNN_HIP(hipMemset(ctx->phase_cycles, 0, 16 * sizeof(unsigned long long)));
     } else if (ctx->phase_cycles) {
         (void)hipFree(ctx->phase_cycles);
         ctx->phase_cycles = nullptr;

@@ -114,8 +114,12 @@ template <bool SWAP, int PASSES>
 __device__ __forceinline__ void gemm_region(const WFrag<PASSES>& wcur, WFrag<PASSES>& wload, const XFrag<PASSES>& xcur,
                                             XFrag<PASSES>& xload, const unsigned char* __restrict__ xl,
                                             const uint4* __restrict__ wfrag, int ks_x, int ks_w, f32x16 (&acc)[4]) {
+#ifndef GNN_ABL_NOX
     load_x(xload, xl, ks_x);
+#endif
+#ifndef GNN_ABL_NOW
     load_w(wload, wfrag, ks_w);
+#endif
     mfma_block<SWAP, PASSES>(wcur, xcur, acc);
     if constexpr (PASSES == 3) {
 #pragma unroll

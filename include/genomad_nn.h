@@ -203,10 +203,9 @@ int gnn_profile_reset(gnn_ctx* ctx);
 int gnn_profile_get(gnn_ctx* ctx, int kernel_id, double* total_ms, int64_t* launches);
 
 /* debug aid: per-phase shader-cycle sums of the fused kernel (instrumented build).  on=1 starts
- * (zeroes the counters), on=0 stops; out10 (may be NULL) receives the 10 counters collected so far:
- * tokens, conv1 gather, m-partials A, w_v+pool A, conv2 loop, conv2 epilogue, conv3 loop,
- * conv3 epilogue, m-partials B, w_v+pool B. */
-int gnn_phase_cycles(gnn_ctx* ctx, int on, unsigned long long* out10);
+ * (zeroes the counters), on=0 stops; out16 (may be NULL) receives the 16 counters collected so far
+ * (their meaning depends on the kernel variant: see GNN_TICK in gnn_fused.hip / gnn_fused2.hip). */
+int gnn_phase_cycles(gnn_ctx* ctx, int on, unsigned long long* out16);
 
 /* measurement aid: sustained dense bf16 rate (TFLOP/s) of v_mfma_f32_32x32x16_bf16 with one wave per
  * SIMD and register operands, run for about ms_target milliseconds — the practical MFMA ceiling of

@@ -1,8 +1,9 @@
 """numpy restatement of the geNomad IGLOO classifier forward pass (fp32 or fp64).
 
-TEST INFRASTRUCTURE ONLY — see oracle/__init__.py.  PARITY UNPINNED against the
-reference's TensorFlow run (TF, Keras and the trained weights are unavailable);
-the restatement follows the reference's op order and Keras defaults:
+TEST INFRASTRUCTURE ONLY — see oracle/__init__.py.  TF, Keras and the trained weights are
+unavailable, so this is pinned against the reference's own model.py / igloo.py executed over numpy
+stand-ins of the TF/Keras primitives (oracle/keras_shim.py; agreement 3e-15 in fp64) rather than
+against a TensorFlow run.  The restatement follows the reference's op order and Keras defaults:
 
 * Conv1D(128, 6, padding="causal"): stride 1, left zero pad of 5, cross-correlation,
   kernel (k, in, out), bias added                       igloo.py:45-47, :66

@@ -8,9 +8,13 @@ TEST INFRASTRUCTURE ONLY — see oracle/__init__.py.
   outputs of the REFERENCE's own functions (genomad/sequence.py executed in place through
   oracle/reference_harness.py): tokenize_dna, seq_windows, read_fasta, Sequence.count /
   .seq_ascii, chained exactly as generate_data does (modules/nn_classification.py:54-82).
-* forward_golden.npz: fp64 oracle scores/intermediates for the first 16 synthetic windows with
-  the seed-42 synthetic weights.  This one is the oracle's own output (regression anchor, the
-  floating-point half of the reference cannot run here: "parity unpinned").
+* forward_golden.npz: for the first 16 synthetic windows with the seed-42 synthetic weights,
+  - ``scores_refgraph64`` / ``scores_refgraph32``: outputs of the REFERENCE'S OWN network code —
+    genomad/neural_network/model.py create_classifier() and igloo.py executed in place through
+    reference_harness.reference_classifier_scores(), TensorFlow/Keras primitives supplied by the
+    numpy stand-ins of oracle/keras_shim.py (TensorFlow itself is not installable here);
+  - ``scores`` and the intermediates: the fp64 oracle's own outputs (regression anchors for the
+    taps the reference graph does not expose).
 """
 import gzip
 import hashlib
@@ -132,8 +136,12 @@ def main():
     bases = synthetic.synth_windows(0, 16)
     tokens = sequence_oracle.tokenize_closed_form(bases)
     scores, taps = igloo_oracle.forward(tokens, W, dtype=np.float64, return_taps=True)
+    ref64 = reference_harness.reference_classifier_scores(tokens, W, np.float64)
+    ref32 = reference_harness.reference_classifier_scores(tokens, W, np.float32)
+    print("oracle fp64 vs reference graph fp64: max |d| = %.3e" % np.abs(scores - ref64).max())
     np.savez_compressed(
         os.path.join(GOLDEN, "forward_golden.npz"),
+        scores_refgraph64=ref64, scores_refgraph32=ref32,
         scores=scores, feat=taps["f"], logits=taps["logits"],
         mA=taps["mA"], mB=taps["mB"], alphaA=taps["alphaA"], alphaB=taps["alphaB"],
         x1_rows=taps["x1"][:, [0, 1, 5, 2999, 5996]], x3_rows=taps["x3"][:, [0, 1, 5, 2999, 5996]],

@@ -47,3 +47,24 @@ def load_reference_sequence():
 def load_reference_utils():
     load_reference_sequence()
     return importlib.import_module("genomad.utils")
+
+
+def load_reference_network():
+    """Return the reference's ``genomad.neural_network`` package (model.py + igloo.py, executed
+    from /root/reference) on top of the numpy stand-ins of ``oracle/keras_shim.py``."""
+    load_reference_sequence()          # registers the bare ``genomad`` namespace package
+    from oracle import keras_shim
+    keras_shim.install()
+    return importlib.import_module("genomad.neural_network")
+
+
+def reference_classifier_scores(tokens, weights, dtype=None):
+    """Scores of the reference's own ``create_classifier()`` graph (model.py:34-45) for (n,5997)
+    tokens, with its layers' weights taken from our flat schema.  dtype float32 (as the reference
+    runs) or float64."""
+    import numpy as np
+    from oracle import keras_shim
+    nn = load_reference_network()
+    keras_shim.new_session(keras_shim.schema_provider(weights), dtype or np.float32)
+    model = nn.create_classifier()
+    return model.predict(np.asarray(tokens, dtype=np.int64), verbose=0)

@@ -21,7 +21,7 @@ for prec in sys.argv[2:] or ['bf16x3']:
     if prec == 'f32': continue
     _lib.check(eng.lib.gnn_phase_cycles(eng.ctx, 1, None))
     eng.classify_dev(bases.ptr, n, scores.ptr, prec); eng.sync()
-    out = (C.c_uint64*10)()
+    out = (C.c_uint64*16)()
     _lib.check(eng.lib.gnn_phase_cycles(eng.ctx, 0, out))
     tot = sum(out)
     print(prec, "phase cycles per window-step (wave0):", {nm: round(v/n/47) for nm, v in zip(names, out)}, "total/step", round(tot/n/47))

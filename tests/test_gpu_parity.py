@@ -128,6 +128,9 @@ def test_f32_path_scores_vs_golden(engine, golden_dir):
     assert hashlib.sha256(bases.tobytes()).hexdigest() == str(g["bases_sha256"])
     scores = engine.classify(bases, "f32")
     assert np.abs(scores - g["scores"]).max() <= SCORE_TOL
+    # outputs of the reference's own network code (model.py / igloo.py run over numpy primitives)
+    assert np.abs(scores - g["scores_refgraph64"]).max() <= SCORE_TOL
+    assert np.abs(engine.classify(bases, "bf16x3") - g["scores_refgraph64"]).max() <= SCORE_TOL
     assert np.allclose(scores.sum(1), 1.0, atol=1e-5)
 
 
