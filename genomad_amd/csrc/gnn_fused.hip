@@ -114,6 +114,8 @@ template <bool SWAP, int PASSES>
 __device__ __forceinline__ void gemm_region(const WFrag<PASSES>& wcur, WFrag<PASSES>& wload, const XFrag<PASSES>& xcur,
                                             XFrag<PASSES>& xload, const unsigned char* __restrict__ xl,
                                             const uint4* __restrict__ wfrag, int ks_x, int ks_w, f32x16 (&acc)[4]) {
+    // GNN_ABL_NOX / GNN_ABL_NOW: measurement-only ablations (scripts/mkvariant.sh) that compile the
+    // operand loads out — wrong results, used to show the launch is power- rather than cycle-bound
 #ifndef GNN_ABL_NOX
     load_x(xload, xl, ks_x);
 #endif
