@@ -129,3 +129,27 @@ def synth_weights(seed: int = WEIGHT_SEED) -> dict:
     # the class scores spread over (0, 1) instead of saturating on one class
     w["out_dense_bias"] = np.array([-8.95, 6.15, -2.82], dtype=np.float32)
     return w
+
+
+def synth_metagenome_offsets(total_bp: int, seed: int = DATA_SEED, min_len: int = 1_000, max_len: int = 500_000):
+    """Contig layout of BASELINE config 5: contig lengths log-uniform in
+    [1 kbp, 500 kbp] (seeded), packed back to back until ``total_bp`` bytes are used; the last
+    contig is cut to fit (and dropped if that leaves it shorter than ``min_len``).  Returns the
+    (n_contigs+1,) int64 offsets.  The bytes themselves are the synthetic-window stream
+    (:func:`synth_windows` / ``gnn_synth_windows_dev``) read as one flat buffer."""
+    rng = np.random.default_rng(seed ^ 0x5EED)
+    est = max(16, int(total_bp / 60_000))
+    lens = []
+    used = 0
+    while used < total_bp:
+        batch = np.exp(rng.uniform(np.log(min_len), np.log(max_len), est)).astype(np.int64)
+        for L in batch:
+            L = int(min(L, total_bp - used))
+            if L < min_len:
+                used = total_bp
+                break
+            lens.append(L)
+            used += L
+            if used >= total_bp:
+                break
+    return np.concatenate([[0], np.cumsum(np.asarray(lens, dtype=np.int64))]).astype(np.int64)

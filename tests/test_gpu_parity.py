@@ -309,6 +309,63 @@ def test_contig_front_end_equals_window_path(engine, synth_weights, golden_dir):
     assert empty.shape == (0, 3) and len(ids) == 0
 
 
+def test_config5_metagenome_contigs_resident_in_hbm(engine):
+    """BASELINE config 5 at reduced size: a 48 Mbp synthetic metagenome (mixed 1-500 kbp contigs,
+    log-uniform) generated IN HBM, through the contig front end (spans -> N rule -> upper-case/pad ->
+    encode+IGLOO -> per-contig mean), against the same rules applied on the host + the window path;
+    plus the properties that hold at any size: contig sharding does not change a bit, rows sum to 1."""
+    from genomad_amd import sequence
+    nwin = 8000
+    offsets = synthetic.synth_metagenome_offsets(nwin * 6000, seed=99)
+    n_contigs = len(offsets) - 1
+    assert n_contigs > 300 and offsets[-1] == nwin * 6000
+    buf = engine.alloc(nwin * 6000)
+    try:
+        engine.synth_windows_dev(0, nwin, buf.ptr)
+        engine.sync()
+        got, ids = engine.classify_contigs_dev(buf.ptr, offsets, False, "bf16x3")
+        # host restatement of nn_classification.py:66-73 on the same bytes
+        seq = synthetic.synth_windows(0, nwin).reshape(-1)
+        starts, lens, cids, wn = sequence.candidate_spans(offsets)
+        keep = np.array([wn[i] == 0 or np.count_nonzero(seq[starts[i]:starts[i] + lens[i]] == ord("N")) <= 4000
+                         for i in range(len(starts))])
+        assert np.array_equal(ids, cids[keep])
+        wins = np.full((int(keep.sum()), 6000), ord("N"), np.uint8)
+        for r, i in enumerate(np.flatnonzero(keep)):
+            wins[r, :lens[i]] = seq[starts[i]:starts[i] + lens[i]]
+        want = engine.segment_mean(engine.classify(wins, "bf16x3"), cids[keep], n_contigs)
+        assert np.array_equal(got, want)
+        assert got.shape == (n_contigs, 3) and np.allclose(got.sum(1), 1.0, atol=1e-5)
+        # contigs shard embarrassingly: the two halves, classified separately, give the same bits
+        h = n_contigs // 2
+        a, _ = engine.classify_contigs_dev(buf.ptr, offsets[:h + 1], False, "bf16x3")
+        b, _ = engine.classify_contigs_dev(buf.ptr + int(offsets[h]), offsets[h:] - offsets[h], False, "bf16x3")
+        assert np.array_equal(np.concatenate([a, b]), got)
+        # host-side edits: lower-case bases are upper-cased on the device; a run of literal 'N' makes
+        # the skip rule fire (window_n > 0 and > 4000 'N'), a run of lower-case 'n' does not count
+        # (Sequence.count is case-sensitive on the raw string, sequence.py:38-39)
+        mod = seq.copy()
+        mod[::3] |= 0x20
+        order = np.argsort(-np.diff(offsets))
+        c0, c1 = int(order[0]), int(order[1])
+        assert offsets[c1 + 1] - offsets[c1] > 40000
+        mod[offsets[c0] + 6000:offsets[c0] + 6000 + 15000] = ord("N")
+        mod[offsets[c1] + 12000:offsets[c1] + 12000 + 15000] = ord("n")
+        got_mod, ids_mod = engine.classify_contigs(mod, offsets, False, "bf16x3")
+        keep2 = np.array([wn[i] == 0 or np.count_nonzero(mod[starts[i]:starts[i] + lens[i]] == ord("N")) <= 4000
+                          for i in range(len(starts))])
+        assert np.count_nonzero(~keep2 & (cids == c0)) == 2 and not np.any(~keep2 & (cids == c1))
+        assert np.array_equal(ids_mod, cids[keep2])
+        wins2 = np.full((int(keep2.sum()), 6000), ord("N"), np.uint8)
+        for r, i in enumerate(np.flatnonzero(keep2)):
+            w = mod[starts[i]:starts[i] + lens[i]]
+            wins2[r, :lens[i]] = np.where((w >= ord("a")) & (w <= ord("z")), w - 32, w)
+        want2 = engine.segment_mean(engine.classify(wins2, "bf16x3"), cids[keep2], n_contigs)
+        assert np.array_equal(got_mod, want2)
+    finally:
+        buf.free()
+
+
 # ------------------------------------------------------------------ downstream consumers (SURVEY §8f rank 3)
 def test_downstream_consumers_match_the_reference_functions(engine, golden_dir, tmp_path):
     """branch_attention / score_batch_correction on the device vs the outputs of the REFERENCE's own
