@@ -164,6 +164,25 @@ int gnn_span_byte_count(gnn_ctx* ctx, const uint8_t* seq_dev, const int64_t* sta
 int gnn_classify_spans(gnn_ctx* ctx, const uint8_t* seq_dev, const int64_t* starts_host,
                        const int32_t* lens_host, int64_t n_spans, int precision, float* scores_host);
 
+/* ---- host-side FASTA record packer (no GPU needed) ------------------------------------------------ */
+/* replaces the line loop of sequence.read_fasta(path, strip_n) (genomad/sequence.py:96-121) on an
+ * in-memory text buffer (already decompressed, newlines normalised to '\n').
+ * gnn_fasta_scan: number of header lines (= upper bound of the record count), total bytes of header
+ * text, and whether the buffer contains a '\r' (the caller then normalises newlines first, as the
+ * reference's text-mode read does).
+ * gnn_fasta_pack: sequence bytes of every surviving record back to back into seq_out (capacity n;
+ * MAY BE THE SAME BUFFER AS text: packing only moves bytes towards lower addresses), record i =
+ * seq_out[offsets[i] .. offsets[i+1]) (capacity+1 entries), and its header text (without the '>')
+ * = headers_out[header_offsets[i] .. header_offsets[i+1]) (headers_out: header_bytes from the scan).
+ * seq_out == NULL (with strip_n == 0) is the index mode: nothing is copied, offsets hold cumulative
+ * raw lengths — the headers of the non-empty records, which is what check_fasta needs
+ * (sequence.py:124-131).
+ * Rules: header = line starting with '>', text before the first header dropped, only '\n' removed,
+ * strip_n strips leading/trailing n/N, empty records dropped. */
+int gnn_fasta_scan(const uint8_t* text, int64_t n, int64_t* n_headers, int64_t* header_bytes, int* has_cr);
+int gnn_fasta_pack(const uint8_t* text, int64_t n, int strip_n, uint8_t* seq_out, int64_t* offsets,
+                   uint8_t* headers_out, int64_t* header_offsets, int64_t capacity, int64_t* n_records);
+
 /* ---- downstream score consumers as a device epilogue, float64 like the
  * reference's numpy ------------------------------------------------------------------------------ */
 /* replaces branch_attention(w, b1, b2, temperature) (aggregated_classification.py:10-34): w[n] marker

@@ -228,6 +228,54 @@ def test_packed_reader_and_candidate_spans_match_reference_rules(golden_dir, tmp
         assert list(ln) == [b - a for a, b in sequence.window_spans(L)]
 
 
+def test_native_fasta_packer_equals_the_python_rules_and_the_reference(tmp_path):
+    """gnn_fasta_scan / gnn_fasta_pack (host code in the library, in place) against the pure-Python
+    statement of the rules and, when the checkout is present, against the REFERENCE's own read_fasta
+    and check_fasta executed in place — on adversarial layouts and on random FASTA-like text."""
+    from oracle import reference_harness
+    ref_seq = reference_harness.load_reference_sequence() if reference_harness.available() else None
+    cases = [
+        b"", b"\n", b">", b">\n", b">a", b">a\n", b">a\nACGT", b">a\nACGT\n", b"ACGT\n>a\nAC\n\nGT\n",
+        b">a\n\n\n>b\nNNNN\n>c\nnNACGTNn\n>d\nN\nA\nN\n", b">a desc here\n AC GT \n>b\tq\nAC>GT\n>>c\n>\nAC\n",
+        b"\n>a\nACGT\n>a\nACGT\n", b">a\nNNNN\n>a\nNN\n", b">x\n" + b"N" * 5000 + b"\n" + b"ACGT" * 10 + b"\n" + b"n" * 70 + b"\n",
+        b">a\r\nAC\r\nGT\r\n>b\rACGT\r", b">only header no newline", b"no header at all\nACGT\n",
+        b">a\nACGT\n>b\n>c\n\n>d\nTTTT",
+    ]
+    rng = np.random.default_rng(11)
+    alphabet = np.frombuffer(b"ACGTNnacgt>>\n\n\n xyz", dtype=np.uint8)
+    for k in range(60):
+        body = alphabet[rng.integers(0, len(alphabet), int(rng.integers(1, 400)))].tobytes()
+        cases.append((b">r%d\n" % k if k % 3 else b"") + body)
+    for i, text in enumerate(cases):
+        p = tmp_path / f"case{i}.fna"
+        p.write_bytes(text)
+        def attempt(f, *a):
+            try:
+                return f(*a)
+            except IndexError:                       # header without an accession: header.split()[0] fails,
+                return "IndexError"                  # in the reference too (sequence.py:24-25)
+
+        for strip in (True, False):
+            want = attempt(sequence.read_fasta_packed_py, p, strip)
+            got = attempt(sequence.read_fasta_packed, p, strip)
+            if isinstance(want, str) or isinstance(got, str):
+                assert want == got, (i, text)
+                continue
+            (got_n, got_s, got_o), (want_n, want_s, want_o) = got, want
+            assert list(got_n) == list(want_n), (i, text)
+            assert bytes(got_s) == bytes(want_s) and list(got_o) == list(want_o), (i, text)
+            rec = list(sequence.read_fasta(p, strip_n=strip))
+            assert [len(s) for _, s in rec] == list(np.diff(got_o)), (i, text)
+            if ref_seq is not None:
+                ref = [(r.accession, r.seq) for r in ref_seq.read_fasta(p, strip_n=strip)]
+                assert [a for a, _ in ref] == list(got_n), (i, text)
+                assert "".join(s for _, s in ref).encode() == bytes(got_s), (i, text)
+        ok = attempt(sequence.check_fasta, p)
+        assert ok == attempt(sequence.check_fasta_py, p), (i, text)
+        if ref_seq is not None and not isinstance(ok, str):
+            assert ok == ref_seq.check_fasta(p), (i, text)
+
+
 def test_keras_h5_weight_ingestion_roundtrip(synth_weights, tmp_path):
     """a Keras-legacy-shaped HDF5 file (layer groups, ':0' suffixes, nested encoder
     model, an optimizer group that must be ignored) is read back into the repo schema by name + shape."""
