@@ -155,7 +155,7 @@ static int classify_chunks(gnn_ctx* ctx, const uint8_t* bases_dev, int64_t n, in
         }
         {
             ProfScope ps(ctx, GNN_K_BACKEND);
-            if ((rc = launch_backend(ctx, m, scores_dev + a * GNN_CLASSES))) return rc;
+            if ((rc = launch_backend(ctx, m, precision, scores_dev + a * GNN_CLASSES))) return rc;
         }
     }
     return GNN_OK;

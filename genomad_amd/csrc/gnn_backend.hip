@@ -32,62 +32,177 @@ __global__ __launch_bounds__(256) void m_kernel(const float* __restrict__ mp, co
     }
 }
 
-// logits[w][h][q] = sum_p m[w][h][p] * w_qk[h][p][q].  Block tile: 32 windows x 64 q, K chunk 32.
-// Each window's sum runs over p in ascending order independent of the batch it is in, so results
-// do not depend on how windows are sharded.
-constexpr int LW = 32, LQ = 64, LK = 32;
+// logits[w][h][q] = sum_p m[w][h][p] * w_qk[h][p][q].  Block tile: 64 windows x 128 q, K chunk 16;
+// thread tile 4 windows x 8 q (32 FMAs per 3 LDS reads).  Each (window, q) sum runs over p in
+// ascending order with one fmaf per term, independent of the batch the window is in, so results do
+// not depend on how windows are sharded or batched.
+constexpr int LW = 64, LQ = 128, LK = 16;
 
 __global__ __launch_bounds__(256) void logits_kernel(const float* __restrict__ m,
                                                      const float* __restrict__ w_qk0,
                                                      const float* __restrict__ w_qk1, int n,
                                                      float* __restrict__ logits) {
-    __shared__ float ms[LK][LW + 1];
-    __shared__ float qs[LK][LQ];
+    __shared__ __attribute__((aligned(16))) float ms[LK][LW + 4];
+    __shared__ __attribute__((aligned(16))) float qs[LK][LQ];
     const int h = blockIdx.z;
     const float* w_qk = h ? w_qk1 : w_qk0;
     const int w0 = blockIdx.y * LW;
     const int q0 = blockIdx.x * LQ;
-    const int tw = threadIdx.x >> 4;   // 16 groups x 2 windows
-    const int tq = threadIdx.x & 15;   // 16 groups x 4 q
-    float acc[2][4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+    const int tw = threadIdx.x >> 4;   // 16 groups x 4 windows
+    const int tq = threadIdx.x & 15;   // 16 groups x (4 + 4) q: columns tq*4.. and 64 + tq*4..
+    float acc[4][8];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int k = 0; k < 8; ++k) acc[i][k] = 0.f;
     for (int p0 = 0; p0 < NP; p0 += LK) {
-        // m tile: 32 p x 32 windows (thread -> one (window, p))
-        for (int i = threadIdx.x; i < LK * LW; i += 256) {
-            const int p = i % LK, w = i / LK;
-            float v = 0.f;
-            if (p0 + p < NP && w0 + w < n) v = m[((size_t)(w0 + w) * 2 + h) * NP + p0 + p];
-            ms[p][w] = v;
+        // m tile: 16 p x 64 windows; thread -> (window, 4 consecutive p) as one float4 (NP % 4 == 0)
+        {
+            const int w = threadIdx.x >> 2, pq = (threadIdx.x & 3) * 4;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (w0 + w < n && p0 + pq < NP)
+                v = *reinterpret_cast<const float4*>(m + ((size_t)(w0 + w) * 2 + h) * NP + p0 + pq);
+            ms[pq][w] = v.x;
+            ms[pq + 1][w] = v.y;
+            ms[pq + 2][w] = v.z;
+            ms[pq + 3][w] = v.w;
         }
         for (int i = threadIdx.x; i < LK * LQ; i += 256) {
             const int q = i % LQ, p = i / LQ;
             qs[p][q] = (p0 + p < NP && q0 + q < POOLED) ? w_qk[(size_t)(p0 + p) * POOLED + q0 + q] : 0.f;
         }
         __syncthreads();
-#pragma unroll 8
+#pragma unroll 4
         for (int p = 0; p < LK; ++p) {
-            const float a0 = ms[p][tw * 2], a1 = ms[p][tw * 2 + 1];
-            const float4 b = *reinterpret_cast<const float4*>(&qs[p][tq * 4]);
-            acc[0][0] = fmaf(a0, b.x, acc[0][0]);
-            acc[0][1] = fmaf(a0, b.y, acc[0][1]);
-            acc[0][2] = fmaf(a0, b.z, acc[0][2]);
-            acc[0][3] = fmaf(a0, b.w, acc[0][3]);
-            acc[1][0] = fmaf(a1, b.x, acc[1][0]);
-            acc[1][1] = fmaf(a1, b.y, acc[1][1]);
-            acc[1][2] = fmaf(a1, b.z, acc[1][2]);
-            acc[1][3] = fmaf(a1, b.w, acc[1][3]);
+            const float4 a = *reinterpret_cast<const float4*>(&ms[p][tw * 4]);
+            const float4 b0 = *reinterpret_cast<const float4*>(&qs[p][tq * 4]);
+            const float4 b1 = *reinterpret_cast<const float4*>(&qs[p][64 + tq * 4]);
+            const float av[4] = {a.x, a.y, a.z, a.w};
+            const float bv[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int k = 0; k < 8; ++k) acc[i][k] = fmaf(av[i], bv[k], acc[i][k]);
         }
         __syncthreads();
     }
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        const int w = w0 + tw * 2 + i;
+    for (int i = 0; i < 4; ++i) {
+        const int w = w0 + tw * 4 + i;
         if (w >= n) continue;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int q = q0 + tq * 4 + j;
-            if (q < POOLED) logits[((size_t)w * 2 + h) * POOLED + q] = acc[i][j];
+        for (int k = 0; k < 8; ++k) {
+            const int q = q0 + (k >> 2) * 64 + tq * 4 + (k & 3);
+            if (q < POOLED) logits[((size_t)w * 2 + h) * POOLED + q] = acc[i][k];
         }
     }
+}
+
+// The same GEMM on the matrix pipe for the bf16x3 / bf16 precisions (6.3 MFLOP per window: at f32
+// VALU rates it was a third of the back end's time).  A = m (windows x 2100, f32 in global, split to
+// bf16 hi/lo in registers), B = w_qk pre-split and packed in MFMA fragment order (zero padded to
+// 2112 x 768), D = A B accumulated in f32: rows = windows, so a window's logits never depend on which
+// other windows share its tile.  Wave tile 64 windows x 64 q (2 x 2 MFMA blocks), block = 4 waves =
+// 64 windows x 256 q; operands of k-step k+1 are fetched while the MFMAs of k-step k issue.
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+struct QkA {
+    float4 v[2][2];     // [m-block][half]: 8 consecutive patches of one window
+};
+struct QkB {
+    uint4 v[2][2];      // [n-block][plane hi, lo]
+};
+
+__device__ __forceinline__ void qk_load(QkA& a, QkB& b, const float* __restrict__ mrow0, const float* __restrict__ mrow1,
+                                        const uint4* __restrict__ bfrag, int ks, int lane) {
+    const int k = ks * 16 + (lane >> 5) * 8;
+    const float* rows[2] = {mrow0, mrow1};
+#pragma unroll
+    for (int mb = 0; mb < 2; ++mb) {
+        if (k + 8 <= NP) {
+            a.v[mb][0] = *reinterpret_cast<const float4*>(rows[mb] + k);
+            a.v[mb][1] = *reinterpret_cast<const float4*>(rows[mb] + k + 4);
+        } else {                                   // last k-step: patches >= 2100 do not exist
+            float t[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) t[e] = k + e < NP ? rows[mb][k + e] : 0.f;
+            a.v[mb][0] = make_float4(t[0], t[1], t[2], t[3]);
+            a.v[mb][1] = make_float4(t[4], t[5], t[6], t[7]);
+        }
+    }
+    const uint4* bp = bfrag + (size_t)ks * (QK_NBLK * 2 * 64);
+#pragma unroll
+    for (int nb = 0; nb < 2; ++nb) {
+        b.v[nb][0] = bp[nb * 2 * 64];
+        b.v[nb][1] = bp[nb * 2 * 64 + 64];
+    }
+}
+
+template <int PASSES>
+__device__ __forceinline__ void qk_mfma(const QkA& a, const QkB& b, f32x16 (&acc)[2][2]) {
+    typedef float f32x8 __attribute__((ext_vector_type(8)));
+#pragma unroll
+    for (int mb = 0; mb < 2; ++mb) {
+        const f32x8 x = {a.v[mb][0].x, a.v[mb][0].y, a.v[mb][0].z, a.v[mb][0].w,
+                         a.v[mb][1].x, a.v[mb][1].y, a.v[mb][1].z, a.v[mb][1].w};
+        const bf16x8 ah = __builtin_convertvector(x, bf16x8);
+        const bf16x8 al = __builtin_convertvector(x - __builtin_convertvector(ah, f32x8), bf16x8);
+#pragma unroll
+        for (int nb = 0; nb < 2; ++nb) {
+            const bf16x8 bh = __builtin_bit_cast(bf16x8, b.v[nb][0]);
+            if constexpr (PASSES == 3) {
+                const bf16x8 bl = __builtin_bit_cast(bf16x8, b.v[nb][1]);
+                acc[mb][nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc[mb][nb], 0, 0, 0);
+                acc[mb][nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc[mb][nb], 0, 0, 0);
+            }
+            acc[mb][nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc[mb][nb], 0, 0, 0);
+        }
+    }
+}
+
+template <int PASSES>
+__global__ __launch_bounds__(256) void logits_mfma_kernel(const float* __restrict__ m, const uint4* __restrict__ frag0,
+                                                          const uint4* __restrict__ frag1, int n,
+                                                          float* __restrict__ logits) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int h = blockIdx.z;
+    const int w0 = blockIdx.y * 64;
+    const int nb0 = blockIdx.x * 8 + wave * 2;                 // first of this wave's two n-blocks
+    const uint4* bfrag = (h ? frag1 : frag0) + (size_t)nb0 * 2 * 64 + lane;
+    // rows past the end are clamped (computed, never stored)
+    const float* mrow0 = m + ((size_t)min(w0 + (lane & 31), n - 1) * 2 + h) * NP;
+    const float* mrow1 = m + ((size_t)min(w0 + 32 + (lane & 31), n - 1) * 2 + h) * NP;
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    QkA a0, a1;
+    QkB b0, b1;
+    qk_load(a0, b0, mrow0, mrow1, bfrag, 0, lane);
+#pragma unroll 1
+    for (int ks = 0; ks < QK_KSTEPS; ks += 2) {                // QK_KSTEPS is even
+        qk_load(a1, b1, mrow0, mrow1, bfrag, ks + 1, lane);
+        qk_mfma<PASSES>(a0, b0, acc);
+        qk_load(a0, b0, mrow0, mrow1, bfrag, min(ks + 2, QK_KSTEPS - 1), lane);
+        qk_mfma<PASSES>(a1, b1, acc);
+    }
+    // C/D layout: column = lane&31 (q), row = (reg&3) + 8*(reg>>2) + 4*(lane>>5) (window)
+#pragma unroll
+    for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int w = w0 + mb * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+            if (w >= n) continue;
+#pragma unroll
+            for (int nb = 0; nb < 2; ++nb) {
+                const int q = (nb0 + nb) * 32 + (lane & 31);
+                if (q < POOLED) logits[((size_t)w * 2 + h) * POOLED + q] = acc[mb][nb][r];
+            }
+        }
 }
 
 // One block per (window, head): softmax over 749 logits, then feat = alpha @ yp.
@@ -133,14 +248,36 @@ __global__ __launch_bounds__(256) void attn_kernel(const float* __restrict__ log
         alpha_out[((size_t)wi * 2 + h) * POOLED + q] = v;
     }
     __syncthreads();
-    // 256 threads = 2 q-halves x 128 channels; rows of yp are 512 B, read coalesced
-    const int c = threadIdx.x & 127, half = threadIdx.x >> 7;
-    const float* y = yp + ((size_t)wi * 2 + h) * POOLED * C;
-    float acc = 0.f;
-    for (int q = half; q < POOLED; q += 2) acc = fmaf(a[q], y[(size_t)q * C + c], acc);
-    red[threadIdx.x] = acc;
+    // 256 threads = 8 q-groups x 32 channel quads: a row of yp (512 B) is one float4 per lane of a
+    // 32-lane group, four rows in flight per thread; partial sums are combined in a fixed order
+    const int cq = threadIdx.x & 31, g = threadIdx.x >> 5;
+    const float4* y = reinterpret_cast<const float4*>(yp + ((size_t)wi * 2 + h) * POOLED * C) + cq;
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    int q = g;
+    for (; q + 24 < POOLED; q += 32) {
+        const float4 v0 = y[(size_t)q * (C / 4)], v1 = y[(size_t)(q + 8) * (C / 4)], v2 = y[(size_t)(q + 16) * (C / 4)],
+                     v3 = y[(size_t)(q + 24) * (C / 4)];
+        const float a0 = a[q], a1 = a[q + 8], a2 = a[q + 16], a3 = a[q + 24];
+        acc.x = fmaf(a0, v0.x, acc.x); acc.y = fmaf(a0, v0.y, acc.y); acc.z = fmaf(a0, v0.z, acc.z); acc.w = fmaf(a0, v0.w, acc.w);
+        acc.x = fmaf(a1, v1.x, acc.x); acc.y = fmaf(a1, v1.y, acc.y); acc.z = fmaf(a1, v1.z, acc.z); acc.w = fmaf(a1, v1.w, acc.w);
+        acc.x = fmaf(a2, v2.x, acc.x); acc.y = fmaf(a2, v2.y, acc.y); acc.z = fmaf(a2, v2.z, acc.z); acc.w = fmaf(a2, v2.w, acc.w);
+        acc.x = fmaf(a3, v3.x, acc.x); acc.y = fmaf(a3, v3.y, acc.y); acc.z = fmaf(a3, v3.z, acc.z); acc.w = fmaf(a3, v3.w, acc.w);
+    }
+    for (; q < POOLED; q += 8) {
+        const float4 v = y[(size_t)q * (C / 4)];
+        const float aq = a[q];
+        acc.x = fmaf(aq, v.x, acc.x); acc.y = fmaf(aq, v.y, acc.y); acc.z = fmaf(aq, v.z, acc.z); acc.w = fmaf(aq, v.w, acc.w);
+    }
+    __shared__ float4 part[8][32];
+    part[g][cq] = acc;
     __syncthreads();
-    if (half == 0) feat[(size_t)wi * FEAT + h * C + c] = red[c] + red[128 + c];
+    if (threadIdx.x < 128) {
+        const int c = threadIdx.x;
+        float s = 0.f;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) s += reinterpret_cast<const float*>(&part[k][c >> 2])[c & 3];
+        feat[(size_t)wi * FEAT + h * C + c] = s;
+    }
 }
 
 // Dense stack for DW windows per block, 512 threads = one per hidden unit.
@@ -206,13 +343,22 @@ __global__ __launch_bounds__(512) void dense_kernel(const float* __restrict__ fe
     }
 }
 
-int launch_backend(gnn_ctx* ctx, int64_t n, float* scores_dev) {
+int launch_backend(gnn_ctx* ctx, int64_t n, int precision, float* scores_dev) {
     const DeviceWeights& d = ctx->w;
     Workspace& ws = ctx->ws;
     hipLaunchKernelGGL(m_kernel, dim3((unsigned)n, 2), dim3(256), 0, ctx->stream, ws.mp, d.w_bias[0], d.w_bias[1],
                        d.slot[0], d.slot[1], ws.m);
-    hipLaunchKernelGGL(logits_kernel, dim3((POOLED + LQ - 1) / LQ, (unsigned)((n + LW - 1) / LW), 2), dim3(256), 0,
-                       ctx->stream, ws.m, d.w_qk[0], d.w_qk[1], (int)n, ws.logits);
+    static_assert(QK_KSTEPS % 2 == 0 && QK_NBLK % 8 == 0, "logits_mfma_kernel tiling");
+    const dim3 qk_grid(QK_NBLK / 8, (unsigned)((n + 63) / 64), 2);
+    const uint4* qf0 = reinterpret_cast<const uint4*>(d.wqk_frag[0]);
+    const uint4* qf1 = reinterpret_cast<const uint4*>(d.wqk_frag[1]);
+    if (precision == GNN_PREC_BF16X3)
+        hipLaunchKernelGGL(logits_mfma_kernel<3>, qk_grid, dim3(256), 0, ctx->stream, ws.m, qf0, qf1, (int)n, ws.logits);
+    else if (precision == GNN_PREC_BF16)
+        hipLaunchKernelGGL(logits_mfma_kernel<1>, qk_grid, dim3(256), 0, ctx->stream, ws.m, qf0, qf1, (int)n, ws.logits);
+    else    // GNN_PREC_F32: exact f32 FMAs
+        hipLaunchKernelGGL(logits_kernel, dim3((POOLED + LQ - 1) / LQ, (unsigned)((n + LW - 1) / LW), 2), dim3(256), 0,
+                           ctx->stream, ws.m, d.w_qk[0], d.w_qk[1], (int)n, ws.logits);
     hipLaunchKernelGGL(attn_kernel, dim3((unsigned)n, 2), dim3(256), 0, ctx->stream, ws.logits, ws.yp, ws.alpha,
                        ws.feat);
     hipLaunchKernelGGL(dense_kernel, dim3((unsigned)((n + DW - 1) / DW)), dim3(512), 0, ctx->stream, ws.feat,

@@ -28,6 +28,10 @@ constexpr int FSTEPS = (T + FT - 1) / FT; // 47 steps per window
 // rows of a conv1 pair table: 1024 five-mers | 256 (N, 4-mer) | 256 (4-mer, N) | (N, N) | (absent,
 // absent) | 257 (absent, token) — see pair_row() in gnn_fused.hip
 constexpr int PAIR_ROWS = 1024 + 256 + 256 + 1 + 1 + 257;   // 1795
+// logits GEMM on the matrix pipe (gnn_backend.hip): K = 2100 patches padded to k-steps of 16,
+// N = 749 pooled positions padded to n-blocks of 32
+constexpr int QK_KSTEPS = (NP + 15) / 16;        // 132
+constexpr int QK_NBLK = (POOLED + 31) / 32;      // 24
 
 void set_error(const std::string& msg);
 
@@ -67,6 +71,7 @@ struct DeviceWeights {
     // fused path packs (gnn_fused.hip): MFMA fragment order, bf16 hi / lo planes
     uint16_t* conv_frag[2] = {nullptr, nullptr};  // conv2, conv3: [kstep 48][nblk 4][plane 2][lane 64][8]
     uint16_t* wv_frag[2] = {nullptr, nullptr};    // head A, B:   [kstep 8][nblk 4][plane 2][lane 64][8]
+    uint16_t* wqk_frag[2] = {nullptr, nullptr};   // head A, B:   [kstep 132][nblk 24][plane 2][lane 64][8], zero padded
 };
 
 struct Workspace {
@@ -118,7 +123,7 @@ int launch_materialize(gnn_ctx* ctx, const uint8_t* seq, const int64_t* starts, 
                        uint8_t* bases);
 int launch_front_f32(gnn_ctx* ctx, const uint8_t* bases, int64_t n);         // -> ws.mp, ws.yp (+ ws.x)
 int launch_front_fused(gnn_ctx* ctx, const uint8_t* bases, int64_t n, int precision);  // -> ws.mp, ws.yp
-int launch_backend(gnn_ctx* ctx, int64_t n, float* scores_dev);              // ws.mp, ws.yp -> scores
+int launch_backend(gnn_ctx* ctx, int64_t n, int precision, float* scores_dev);   // ws.mp, ws.yp -> scores
 
 // host-side packing for the fused path (gnn_fused.hip)
 int pack_fused_weights(gnn_ctx* ctx, const gnn_weights* w);

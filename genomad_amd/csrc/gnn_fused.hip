@@ -501,18 +501,22 @@ static inline float bf16_to_f32(uint16_t h) {
     return f;
 }
 
-// Wmat (K x 128, row major) -> [kstep K/16][nblk 4][plane hi,lo][lane 64][8] bf16 in the operand
-// layout of v_mfma_f32_32x32x16_bf16: lane l holds W[kstep*16 + (l>>5)*8 + e][nblk*32 + (l&31)].
-static std::vector<uint16_t> pack_frags(const float* wmat, int K) {
-    std::vector<uint16_t> out((size_t)(K / 16) * 4 * 2 * 64 * 8);
-    for (int ks = 0; ks < K / 16; ++ks)
-        for (int nb = 0; nb < 4; ++nb)
+// Wmat (K x N, row major) -> [kstep Kpad/16][nblk Npad/32][plane hi,lo][lane 64][8] bf16 in the operand
+// layout of v_mfma_f32_32x32x16_bf16: lane l holds W[kstep*16 + (l>>5)*8 + e][nblk*32 + (l&31)];
+// rows >= K and columns >= N are zero.
+static std::vector<uint16_t> pack_frags(const float* wmat, int K, int N) {
+    const int ksteps = (K + 15) / 16, nblks = (N + 31) / 32;
+    std::vector<uint16_t> out((size_t)ksteps * nblks * 2 * 64 * 8, 0);
+    for (int ks = 0; ks < ksteps; ++ks)
+        for (int nb = 0; nb < nblks; ++nb)
             for (int l = 0; l < 64; ++l)
                 for (int e = 0; e < 8; ++e) {
-                    const float v = wmat[(size_t)(ks * 16 + (l >> 5) * 8 + e) * C + nb * 32 + (l & 31)];
+                    const int k = ks * 16 + (l >> 5) * 8 + e, n = nb * 32 + (l & 31);
+                    if (k >= K || n >= N) continue;
+                    const float v = wmat[(size_t)k * N + n];
                     const uint16_t hi = bf16_rne(v);
                     const uint16_t lo = bf16_rne(v - bf16_to_f32(hi));
-                    const size_t base = ((size_t)(ks * 4 + nb) * 2) * 64 * 8;
+                    const size_t base = ((size_t)(ks * nblks + nb) * 2) * 64 * 8;
                     out[base + (size_t)l * 8 + e] = hi;
                     out[base + 64 * 8 + (size_t)l * 8 + e] = lo;
                 }
@@ -535,8 +539,9 @@ int pack_fused_weights(gnn_ctx* ctx, const gnn_weights* w) {
     const float* ck[2] = {w->conv2_kernel, w->conv3_kernel};
     const gnn_igloo_weights* ig[2] = {&w->igloo_a, &w->igloo_b};
     for (int i = 0; i < 2; ++i) {
-        if ((rc = upload_vec(ctx, pack_frags(ck[i], KS * C), &d.conv_frag[i]))) return rc;
-        if ((rc = upload_vec(ctx, pack_frags(ig[i]->w_v, C), &d.wv_frag[i]))) return rc;
+        if ((rc = upload_vec(ctx, pack_frags(ck[i], KS * C, C), &d.conv_frag[i]))) return rc;
+        if ((rc = upload_vec(ctx, pack_frags(ig[i]->w_v, C, C), &d.wv_frag[i]))) return rc;
+        if ((rc = upload_vec(ctx, pack_frags(ig[i]->w_qk, NP, POOLED), &d.wqk_frag[i]))) return rc;
     }
     return GNN_OK;
 }
