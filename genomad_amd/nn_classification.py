@@ -252,7 +252,10 @@ def main(input_path, output_path, single_window, batch_size, restart, threads, v
     """``_backend`` (tests only) replaces the GPU engine with an object offering score() and
     segment_mean(); the product path always builds a :class:`GpuBackend` and fails without a GPU."""
     input_path, output_path = Path(input_path), Path(output_path)
-    rank0 = int(os.environ.get("RANK", "0")) == 0
+    from . import sharding
+    # under torch.distributed.run: create the process group (nccl = RCCL) before the HIP library loads
+    rank, world = sharding.ensure_process_group() if _backend is None else (int(os.environ.get("RANK", "0")), 1)
+    rank0 = rank == 0
     if not output_path.is_dir():
         output_path.mkdir(exist_ok=True)
     prefix = sequence.prefix_of(input_path)
@@ -338,33 +341,48 @@ def main(input_path, output_path, single_window, batch_size, restart, threads, v
             write_tsv(tsv_path, names, predictions)                                  # :340-352 (always rewritten)
 
     def stage_device(fasta, enc_dir, wid_path, npz_path, tsv_path, names_key, ids_key, what):
-        """Single-process product path: the contig front end (NNEngine.classify_contigs) does
-        windowing, the N rule, tokenising, classification and the per-contig mean on the GPU, so
-        encoding and classification are one step; ``<prefix>_seq_window_id.npz`` is still written."""
+        """Product path: the contig front end (NNEngine.classify_contigs) does windowing, the N rule,
+        tokenising, classification and the per-contig mean on the GPU, so encoding and classification
+        are one step; ``<prefix>_seq_window_id.npz`` is still written.  With several ranks
+        (torch.distributed.run) the CONTIGS are sharded: every rank reads and packs only its own
+        record-aligned byte range of the file (or, for compressed inputs, its contig range of the
+        whole table), classifies it on its GPU, and rank 0 collects the per-contig scores with one
+        gather and writes the files — results are bit-identical for any number of ranks."""
         if skip and npz_path.exists():                                               # :284-292
             console.log(f"{npz_path.name} was found. Skipping {what} classification.")
             z = np.load(npz_path)
             names, predictions = z[names_key], z["predictions"]
         else:
-            names, seq, offsets = sequence.read_fasta_packed(fasta, strip_n=True)
+            if world > 1 and sequence.compression_of(fasta) == "uncompressed":
+                names, seq, offsets = sequence.read_fasta_packed(
+                    fasta, strip_n=True, byte_range=sequence.record_aligned_range(fasta, rank, world))
+            else:
+                names, seq, offsets = sequence.read_fasta_packed(fasta, strip_n=True)
+                if world > 1:
+                    a, b = sharding.contig_subset(offsets, rank, world)
+                    names, seq, offsets = names[a:b], seq[offsets[a]:offsets[b]], offsets[a:b + 1] - offsets[a]
             precision = os.environ.get("GENOMAD_AMD_PRECISION", "bf16x3")
             predictions, ids = _engine().classify_contigs(seq, offsets, single_window, precision)
-            if not len(ids):                                                         # :297-299
+            n_windows = len(ids)
+            if world > 1:
+                names, predictions, ids, n_windows = sharding.gather_contig_results(names, predictions, ids)
+            if not n_windows:                                                        # :297-299
                 console.error("No sequences were found. Please check your input FASTA.")
                 sys.exit(1)
-            if enc_dir.is_dir():
-                shutil.rmtree(enc_dir)
-            enc_dir.mkdir()
-            np.savez_compressed(wid_path, **{names_key: names, ids_key: ids})
-            console.log(f"{what.capitalize()}s classified ({len(ids)} windows).")
-            np.savez_compressed(npz_path, **{names_key: names, "predictions": predictions})
-        if cleanup and enc_dir.is_dir():
+            if rank0:
+                if enc_dir.is_dir():
+                    shutil.rmtree(enc_dir)
+                enc_dir.mkdir()
+                np.savez_compressed(wid_path, **{names_key: names, ids_key: ids})
+                console.log(f"{what.capitalize()}s classified ({len(ids)} windows).")
+                np.savez_compressed(npz_path, **{names_key: names, "predictions": predictions})
+        if cleanup and rank0 and enc_dir.is_dir():
             console.log(f"Deleting encoded {what} data.")
             shutil.rmtree(enc_dir)
-        write_tsv(tsv_path, names, predictions)
+        if rank0:
+            write_tsv(tsv_path, names, predictions)
 
-    device_front_end = (_backend is None and int(os.environ.get("WORLD_SIZE", "1")) == 1
-                        and os.environ.get("GENOMAD_AMD_FRONT_END", "device") == "device")
+    device_front_end = _backend is None and os.environ.get("GENOMAD_AMD_FRONT_END", "device") == "device"
     run = stage_device if device_front_end else stage
     try:
         run(input_path, outputs.encoded_sequences_dir, outputs.seq_window_id_output,

@@ -179,17 +179,53 @@ def read_fasta_packed_py(path, strip_n: bool = True):
     return np.array(names), seq, offsets
 
 
-def _read_text_array(path) -> np.ndarray:
-    """Writable uint8 array with the decompressed file contents (no newline normalisation)."""
+def record_aligned_range(path, rank: int, world: int) -> Tuple[int, int]:
+    """Half-open byte range of ``rank``'s share of an UNCOMPRESSED FASTA file, aligned to record
+    starts: both ends are moved forward to the next line that begins with '>' (a record belongs to
+    the rank whose nominal range contains its '>').  Ranges of consecutive ranks tile the file, so
+    every rank can read and pack only its own part (contigs shard embarrassingly).  Rank 0 starts
+    at 0: text before the first header is dropped by the packer anyway."""
+    if world < 1 or not (0 <= rank < world):
+        raise ValueError("bad shard arguments")
+    size = Path(path).stat().st_size
+
+    def align(a: int) -> int:
+        if a <= 0:
+            return 0
+        if a >= size:
+            return size
+        with open(path, "rb") as fin:
+            pos = a - 1                                   # "\n>" may straddle the nominal boundary
+            while pos < size:
+                fin.seek(pos)
+                block = fin.read(1 << 20)
+                if not block:
+                    break
+                k = block.find(b"\n>")
+                if k >= 0:
+                    return pos + k + 1
+                if len(block) < 2:                        # the last byte cannot start a "\n>" pair
+                    break
+                pos += len(block) - 1                     # keep one byte of overlap
+        return size
+
+    return align(size * rank // world), align(size * (rank + 1) // world)
+
+
+def _read_text_array(path, byte_range=None) -> np.ndarray:
+    """Writable uint8 array with the decompressed file contents (no newline normalisation);
+    ``byte_range`` (uncompressed files only) reads just [start, end)."""
     kind = compression_of(path)
     opener = {"gzip": gzip.open, "bzip2": bz2.open, "xz": lzma.open}.get(kind)
     if kind == "zstd" and sys.version_info >= (3, 14):
         from compression import zstd  # type: ignore
         opener = zstd.open
     if opener is None:
-        size = Path(path).stat().st_size
+        start, end = byte_range if byte_range is not None else (0, Path(path).stat().st_size)
+        size = max(end - start, 0)
         buf = bytearray(size)
         with open(path, "rb", buffering=0) as fin:
+            fin.seek(start)
             got, view = 0, memoryview(buf)
             while got < size:
                 k = fin.readinto(view[got:])
@@ -197,6 +233,8 @@ def _read_text_array(path) -> np.ndarray:
                     break
                 got += k
         return np.frombuffer(buf, dtype=np.uint8)[:got]
+    if byte_range is not None:
+        raise ValueError("byte ranges need an uncompressed file")
     with opener(path, "rb") as fin:
         return np.frombuffer(bytearray(fin.read()), dtype=np.uint8)
 
@@ -226,16 +264,17 @@ def _pack(text: np.ndarray, strip_n: bool, copy: bool = True):
     return names, (text[:offsets[-1]] if copy else None), offsets
 
 
-def read_fasta_packed(path, strip_n: bool = True):
+def read_fasta_packed(path, strip_n: bool = True, byte_range=None):
     """(names, seq, offsets): every record that ``read_fasta(path, strip_n)`` yields, packed into ONE
     uint8 buffer of raw (case-preserved) sequence bytes; contig i is seq[offsets[i]:offsets[i+1]].
 
     Same record rules as :func:`read_fasta` (header = a line starting with '>', only '\\n' is
     removed, leading/trailing n/N stripped, empty records dropped); the line work is done by the
     library's host-side packer (``gnn_fasta_pack``: memchr/memmove, IN PLACE in the buffer the file
-    was read into, several GB/s) so that real inputs keep up with the device.
+    was read into, several GB/s) so that real inputs keep up with the device.  ``byte_range`` (from
+    :func:`record_aligned_range`) restricts the read to one rank's share of an uncompressed file.
     """
-    names, seq, offsets = _pack(_read_text_array(path), strip_n)
+    names, seq, offsets = _pack(_read_text_array(path, byte_range), strip_n)
     return np.array(names), seq, offsets
 
 

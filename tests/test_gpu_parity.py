@@ -4,6 +4,7 @@ absolute (BASELINE.json north_star), intermediates within the tolerances stated 
 import hashlib
 import json
 import os
+import sys
 
 import numpy as np
 import pytest
@@ -364,6 +365,44 @@ def test_config5_metagenome_contigs_resident_in_hbm(engine):
         assert np.array_equal(got_mod, want2)
     finally:
         buf.free()
+
+
+def test_main_contig_sharded_two_ranks_equal_one_process(engine, synth_weights, tmp_path):
+    """main() under torch.distributed.run with two ranks (sharing this box's one GPU, so the gather
+    runs over gloo; on a node with several GPUs the same code takes nccl = RCCL): contigs are sharded
+    by record-aligned byte ranges, rank 0 gathers — NPZ / TSV / window ids equal a single process."""
+    import subprocess
+    from genomad_amd import nn_classification as nnc, weights as W
+    rng = np.random.default_rng(8)
+    fa = tmp_path / "sample.fna"
+    with open(fa, "wb") as f:
+        for i in range(23):
+            n = int(rng.integers(800, 40000))
+            body = rng.choice(np.frombuffer(b"ACGT", np.uint8), n).tobytes()
+            if i == 4:
+                body = body[:7000] + b"N" * 9000 + body[7000:]
+            f.write(b">c%d x\n" % i + b"\n".join(body[j:j + 70] for j in range(0, len(body), 70)) + b"\n")
+    wpath = tmp_path / "w.npz"
+    W.save_npz(wpath, synth_weights)
+    env = dict(os.environ, GENOMAD_AMD_WEIGHTS=str(wpath), GENOMAD_AMD_DEVICE="0", GENOMAD_AMD_DIST_BACKEND="gloo",
+               PYTHONPATH=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    code = ("import sys; from genomad_amd import nn_classification as n; "
+            "n.main(sys.argv[1], sys.argv[2], False, 128, True, 1, False, False)")
+    subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                    "--master-addr", "127.0.0.1", "--master-port", "29611", "--no-python",
+                    sys.executable, "-c", code, str(fa), str(tmp_path / "out2")],
+                   check=True, env=env, timeout=600)
+    env1 = {k: v for k, v in env.items() if k != "GENOMAD_AMD_DIST_BACKEND"}
+    subprocess.run([sys.executable, "-c", code, str(fa), str(tmp_path / "out1")], check=True, env=env1, timeout=600)
+    for name in ("sample_nn_classification.npz", "sample_encoded_sequences/sample_seq_window_id.npz"):
+        a = np.load(tmp_path / "out1" / "sample_nn_classification" / name)
+        b = np.load(tmp_path / "out2" / "sample_nn_classification" / name)
+        assert sorted(a.files) == sorted(b.files)
+        for k in a.files:
+            assert np.array_equal(a[k], b[k]), (name, k)
+    t1 = (tmp_path / "out1" / "sample_nn_classification" / "sample_nn_classification.tsv").read_text()
+    t2 = (tmp_path / "out2" / "sample_nn_classification" / "sample_nn_classification.tsv").read_text()
+    assert t1 == t2 and t1.count("\n") == 24
 
 
 # ------------------------------------------------------------------ downstream consumers (SURVEY §8f rank 3)

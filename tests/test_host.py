@@ -198,6 +198,98 @@ def test_gloo_world_size_2_gather_equals_single_process(n):
     assert np.array_equal(got, FakeBackend().score(windows))
 
 
+def _fake_contig_scores(seq, offsets):
+    """Stand-in for the GPU (tests only): per-contig base composition + candidate window ids."""
+    k = len(offsets) - 1
+    out = np.zeros((k, 3), np.float32)
+    for i in range(k):
+        c = seq[offsets[i]:offsets[i + 1]]
+        out[i] = [(c == b).mean() for b in (65, 67, 71)]
+    return out, sequence.candidate_spans(offsets)[2]
+
+
+def _write_sharding_fasta(path):
+    rng = np.random.default_rng(21)
+    with open(path, "wb") as f:
+        f.write(b"preamble that is not a record\n")
+        for i in range(37):
+            n = int(rng.integers(1, 30000))
+            body = rng.choice(np.frombuffer(b"ACGTN", np.uint8), n).tobytes()
+            if i % 7 == 3:
+                body = b"N" * n                                   # dropped after strip_n
+            f.write(b">ctg%d d=%d\n" % (i, n))
+            w = int(rng.integers(40, 90))
+            f.write(b"\n".join(body[j:j + w] for j in range(0, n, w)) + b"\n")
+            if i % 5 == 0:
+                f.write(b"\n")
+
+
+def test_record_aligned_byte_ranges_tile_the_file(tmp_path):
+    """Multi-rank front end: every rank packs only its record-aligned byte range; the concatenation
+    over ranks equals packing the whole file, for any number of ranks (also more ranks than records)."""
+    p = tmp_path / "meta.fna"
+    _write_sharding_fasta(p)
+    names, seq, offsets = sequence.read_fasta_packed(p)
+    size = p.stat().st_size
+    for world in (1, 2, 3, 5, 8, 64):
+        ranges = [sequence.record_aligned_range(p, r, world) for r in range(world)]
+        assert ranges[0][0] == 0 and ranges[-1][1] == size
+        assert all(ranges[r][1] == ranges[r + 1][0] for r in range(world - 1))
+        parts = [sequence.read_fasta_packed(p, True, rg) for rg in ranges]
+        assert [n for pt in parts for n in pt[0]] == list(names)
+        assert b"".join(bytes(pt[1]) for pt in parts) == bytes(seq)
+        assert np.array_equal(np.concatenate([np.diff(pt[2]) for pt in parts]), np.diff(offsets))
+        subs = [sharding.contig_subset(offsets, r, world) for r in range(world)]
+        assert subs[0][0] == 0 and subs[-1][1] == len(names)
+        assert all(subs[r][1] == subs[r + 1][0] for r in range(world - 1))
+    with pytest.raises(ValueError):
+        sequence.record_aligned_range(p, 2, 2)
+    with pytest.raises(ValueError):
+        sequence.read_fasta_packed(os.path.join(os.path.dirname(__file__), "golden", "fasta_fixture.fna.gz"), True, (0, 10))
+
+
+def _gloo_contig_worker(rank, world, port, path, q):
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank))
+    assert sharding.ensure_process_group() == (rank, world)       # gloo: no GPU here
+    names, seq, offsets = sequence.read_fasta_packed(path, True, sequence.record_aligned_range(path, rank, world))
+    scores, ids = _fake_contig_scores(seq, offsets)
+    out = sharding.gather_contig_results(names, scores, ids)
+    assert out[3] > 0
+    if rank == 0:
+        q.put(out)
+    else:
+        assert out[0] is None and out[1] is None and out[2] is None
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_gloo_contig_sharded_front_end_equals_single_process(tmp_path, world):
+    """N>1 path of main()'s device front end on CPU (gloo): ranks pack their own byte range, "classify"
+    their contigs, rank 0 gathers names / per-contig scores / window ids — equal to one process."""
+    mp = pytest.importorskip("torch.multiprocessing")
+    import socket
+    p = tmp_path / "meta.fna"
+    _write_sharding_fasta(p)
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_gloo_contig_worker, args=(r, world, port, str(p), q)) for r in range(world)]
+    for pr in procs:
+        pr.start()
+    names, preds, ids, total = q.get(timeout=180)
+    for pr in procs:
+        pr.join(timeout=180)
+        assert pr.exitcode == 0
+    n1, s1, o1 = sequence.read_fasta_packed(p)
+    want_scores, want_ids = _fake_contig_scores(s1, o1)
+    assert list(names) == list(n1) and np.array_equal(preds, want_scores)
+    assert np.array_equal(ids, want_ids) and total == len(want_ids)
+
+
 def test_packed_reader_and_candidate_spans_match_reference_rules(golden_dir, tmp_path):
     """read_fasta_packed + candidate_spans (the host half of the contig front end) reproduce what the
     reference's read_fasta / seq_windows yield (goldens generated from the reference itself)."""
