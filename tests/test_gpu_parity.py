@@ -243,6 +243,49 @@ def test_main_end_to_end_on_gpu(engine, synth_weights, tmp_path, monkeypatch):
     assert not (out / "mini_nn_classification" / "mini_encoded_sequences").exists()   # --cleanup
 
 
+def test_config1_kpneumoniae_shaped_genome_through_main(engine, synth_weights, tmp_path, monkeypatch):
+    """BASELINE config 1 (plumbing case): a genome shaped like GCF_009025895.1 — one ≈5.1 Mbp chromosome
+    and the seven plasmids of the documented lengths, ≈ 910 windows — through the drop-in main().  The
+    real assembly, TensorFlow and the trained weights are not available here, so the
+    content is seeded synthetic sequence; the seven plasmids (56 windows) are checked against the oracle
+    chain, the chromosome against the exact-f32 device path."""
+    from genomad_amd import nn_classification as nnc, sequence
+    from genomad_amd import weights as W
+    lengths = [5_100_000, 82_240, 61_331, 51_887, 50_635, 44_850, 28_729, 5_251]
+    rng = np.random.default_rng(1895)
+    fa = tmp_path / "GCF_009025895.1.fna"
+    with open(fa, "wb") as f:
+        for i, n in enumerate(lengths):
+            body = rng.choice(np.frombuffer(b"ACGT", np.uint8), n).tobytes()
+            f.write(b">NZ_CP0450%d.1 Klebsiella pneumoniae strain (synthetic stand-in)\n" % (15 + i))
+            f.write(b"\n".join(body[j:j + 80] for j in range(0, n, 80)) + b"\n")
+    wpath = tmp_path / "w.npz"
+    W.save_npz(wpath, synth_weights)
+    monkeypatch.setenv("GENOMAD_AMD_WEIGHTS", str(wpath))
+    monkeypatch.setattr(nnc, "_ENGINE", engine)
+    out = tmp_path / "out"
+    nnc.main(fa, out, False, 128, False, 1, False, False)
+    d = out / "GCF_009025895.1_nn_classification"
+    z = np.load(d / "GCF_009025895.1_nn_classification.npz")
+    wid = np.load(d / "GCF_009025895.1_encoded_sequences" / "GCF_009025895.1_seq_window_id.npz")
+    assert list(z["contig_names"]) == [f"NZ_CP0450{15 + i}.1" for i in range(8)]
+    assert len(wid["contig_ids"]) == sum(len(sequence.window_spans(n)) for n in lengths) == 906
+    pred = z["predictions"]
+    assert pred.shape == (8, 3) and np.allclose(pred.sum(1), 1.0, atol=1e-5)
+    names, seq, offsets = sequence.read_fasta_packed(fa)
+    exact, _ = engine.classify_contigs(seq, offsets, False, "f32")
+    assert np.abs(pred - exact).max() <= SCORE_TOL
+    plasmids = tmp_path / "plasmids.fna"
+    text = fa.read_bytes()
+    plasmids.write_bytes(text[text.index(b">NZ_CP045016.1"):])
+    _, ids, wins = sequence_oracle.encode_fasta(plasmids)
+    assert len(wins) == 56
+    want = sequence_oracle.segment_mean(igloo_oracle.classify_windows(wins, synth_weights, np.float32), ids)
+    assert np.abs(pred[1:] - want).max() <= SCORE_TOL
+    tsv = (d / "GCF_009025895.1_nn_classification.tsv").read_text().splitlines()
+    assert tsv[0] == "seq_name\tchromosome_score\tplasmid_score\tvirus_score" and len(tsv) == 9
+
+
 # ------------------------------------------------------------------ BASELINE.json sizes: properties
 def _classify_resident(engine, first, n, precision, shards=1):
     """Classify synthetic windows first..first+n generated on the device; optionally as `shards`
