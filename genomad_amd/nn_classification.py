@@ -270,11 +270,21 @@ def main(input_path, output_path, single_window, batch_size, restart, threads, v
                          outputs.provirus_nn_classification_npz_output]
     console.log(f"Executing geNomad nn-classification (genomad_amd, MI355X). Outputs in {outputs.nn_classification_dir}.")
     md5_async(input_path)            # starts hashing now; check_fasta and the stages overlap with it
+    device_front_end = _backend is None and os.environ.get("GENOMAD_AMD_FRONT_END", "device") == "device"
 
-    if not sequence.check_fasta(input_path):                                   # :164-170
-        console.error(f"{input_path} is either empty or contains multiple entries with the same identifier. "
-                      "Please check your input FASTA file and execute genomad nn-classification again.")
-        sys.exit(1)
+    def fail_on_bad_fasta(ok: bool):                                           # :164-170
+        if not ok:
+            console.error(f"{input_path} is either empty or contains multiple entries with the same identifier. "
+                          "Please check your input FASTA file and execute genomad nn-classification again.")
+            sys.exit(1)
+
+    # The device front end validates the FASTA on a helper thread while the GPU already classifies;
+    # nothing is written (no outputs, no execution info) before ``gate()`` has seen the verdict, so
+    # an invalid input leaves the same state behind as in the reference, which checks first.
+    check_pool = concurrent.futures.ThreadPoolExecutor(max_workers=1) if device_front_end else None
+    check_future = check_pool.submit(sequence.check_fasta, input_path) if check_pool else None
+    if check_future is None:
+        fail_on_bad_fasta(sequence.check_fasta(input_path))
 
     skip = False                                                               # :175-197
     if (outputs.nn_classification_execution_info.exists() and any(p.exists() for p in output_files) and not restart):
@@ -285,16 +295,27 @@ def main(input_path, output_path, single_window, batch_size, restart, threads, v
         else:
             console.log("The input file or the parameters changed since the last execution. "
                         "Previous outputs will be overwritten.")
-    info_writer = None
-    if rank0:
-        outputs.nn_classification_dir.mkdir(exist_ok=True)
-        # written as soon as the digest is ready, while the stages below already run (a non-daemon
-        # thread: it also completes if a stage ends the run with sys.exit)
-        info_writer = threading.Thread(
-            target=write_execution_info, name="genomad-amd-execution-info",
-            args=(MODULE_NAME, input_path, parameter_dict, outputs.nn_classification_execution_info,
-                  datetime.now(timezone.utc).astimezone().isoformat()))
-        info_writer.start()
+    state = {"info_writer": None, "gated": False}
+    start_time = datetime.now(timezone.utc).astimezone().isoformat()
+
+    def gate():
+        """First call: wait for the FASTA verdict, then start writing the execution info (as soon as
+        the digest is ready; a non-daemon thread, so it also completes if a stage ends the run with
+        sys.exit).  Every writer of an output file calls this first."""
+        if state["gated"]:
+            return
+        state["gated"] = True
+        if check_future is not None:
+            fail_on_bad_fasta(check_future.result())
+        if rank0:
+            outputs.nn_classification_dir.mkdir(exist_ok=True)
+            state["info_writer"] = threading.Thread(
+                target=write_execution_info, name="genomad-amd-execution-info",
+                args=(MODULE_NAME, input_path, parameter_dict, outputs.nn_classification_execution_info, start_time))
+            state["info_writer"].start()
+
+    if not device_front_end:
+        gate()
 
     def stage(fasta, enc_dir, wid_path, npz_path, tsv_path, names_key, ids_key, what):
         windows = None
@@ -349,23 +370,43 @@ def main(input_path, output_path, single_window, batch_size, restart, threads, v
         whole table), classifies it on its GPU, and rank 0 collects the per-contig scores with one
         gather and writes the files — results are bit-identical for any number of ranks."""
         if skip and npz_path.exists():                                               # :284-292
+            gate()
             console.log(f"{npz_path.name} was found. Skipping {what} classification.")
             z = np.load(npz_path)
             names, predictions = z[names_key], z["predictions"]
         else:
-            if world > 1 and sequence.compression_of(fasta) == "uncompressed":
-                names, seq, offsets = sequence.read_fasta_packed(
-                    fasta, strip_n=True, byte_range=sequence.record_aligned_range(fasta, rank, world))
+            precision = os.environ.get("GENOMAD_AMD_PRECISION", "bf16x3")
+            eng = _engine()
+            if sequence.compression_of(fasta) == "uncompressed":
+                # this rank's record-aligned share of the file, in pieces of about 128 MB: piece k+1
+                # is read and packed on a helper thread while the GPU classifies piece k
+                share = Path(fasta).stat().st_size // world
+                pieces = int(min(64, max(1, -(-share // (128 << 20)))))
+                read = lambda k: sequence.read_fasta_packed(  # noqa: E731
+                    fasta, True, sequence.record_aligned_range(fasta, rank, world, k, pieces))
+                parts, base = [], 0
+                with concurrent.futures.ThreadPoolExecutor(max_workers=1) as pool:
+                    nxt = pool.submit(read, 0)
+                    for k in range(pieces):
+                        nm, sq, off = nxt.result()
+                        if k + 1 < pieces:
+                            nxt = pool.submit(read, k + 1)
+                        pr, wid = eng.classify_contigs(sq, off, single_window, precision)
+                        parts.append((nm, pr, wid + base))
+                        base += len(nm)
+                names = np.concatenate([p[0] for p in parts])
+                predictions = np.concatenate([p[1] for p in parts])
+                ids = np.concatenate([p[2] for p in parts])
             else:
                 names, seq, offsets = sequence.read_fasta_packed(fasta, strip_n=True)
                 if world > 1:
                     a, b = sharding.contig_subset(offsets, rank, world)
                     names, seq, offsets = names[a:b], seq[offsets[a]:offsets[b]], offsets[a:b + 1] - offsets[a]
-            precision = os.environ.get("GENOMAD_AMD_PRECISION", "bf16x3")
-            predictions, ids = _engine().classify_contigs(seq, offsets, single_window, precision)
+                predictions, ids = eng.classify_contigs(seq, offsets, single_window, precision)
             n_windows = len(ids)
             if world > 1:
                 names, predictions, ids, n_windows = sharding.gather_contig_results(names, predictions, ids)
+            gate()
             if not n_windows:                                                        # :297-299
                 console.error("No sequences were found. Please check your input FASTA.")
                 sys.exit(1)
@@ -382,7 +423,6 @@ def main(input_path, output_path, single_window, batch_size, restart, threads, v
         if rank0:
             write_tsv(tsv_path, names, predictions)
 
-    device_front_end = _backend is None and os.environ.get("GENOMAD_AMD_FRONT_END", "device") == "device"
     run = stage_device if device_front_end else stage
     try:
         run(input_path, outputs.encoded_sequences_dir, outputs.seq_window_id_output,
@@ -393,8 +433,10 @@ def main(input_path, output_path, single_window, batch_size, restart, threads, v
                 outputs.provirus_window_id_output, outputs.provirus_nn_classification_npz_output,
                 outputs.provirus_nn_classification_output, "provirus_names", "provirus_ids", "provirus")
     finally:
-        if info_writer is not None:
-            info_writer.join()
+        if check_pool is not None:
+            check_pool.shutdown(wait=True)
+        if state["info_writer"] is not None:
+            state["info_writer"].join()
     console.log("geNomad nn-classification finished!")
 
 

@@ -179,15 +179,17 @@ def read_fasta_packed_py(path, strip_n: bool = True):
     return np.array(names), seq, offsets
 
 
-def record_aligned_range(path, rank: int, world: int) -> Tuple[int, int]:
+def record_aligned_range(path, rank: int, world: int, piece: int = 0, pieces: int = 1) -> Tuple[int, int]:
     """Half-open byte range of ``rank``'s share of an UNCOMPRESSED FASTA file, aligned to record
     starts: both ends are moved forward to the next line that begins with '>' (a record belongs to
     the rank whose nominal range contains its '>').  Ranges of consecutive ranks tile the file, so
     every rank can read and pack only its own part (contigs shard embarrassingly).  Rank 0 starts
-    at 0: text before the first header is dropped by the packer anyway."""
-    if world < 1 or not (0 <= rank < world):
+    at 0: text before the first header is dropped by the packer anyway.  ``piece``/``pieces`` cut a
+    rank's share further the same way (used to pack piece k+1 while the GPU classifies piece k)."""
+    if world < 1 or not (0 <= rank < world) or pieces < 1 or not (0 <= piece < pieces):
         raise ValueError("bad shard arguments")
     size = Path(path).stat().st_size
+    rank, world = rank * pieces + piece, world * pieces
 
     def align(a: int) -> int:
         if a <= 0:
@@ -275,7 +277,7 @@ def read_fasta_packed(path, strip_n: bool = True, byte_range=None):
     :func:`record_aligned_range`) restricts the read to one rank's share of an uncompressed file.
     """
     names, seq, offsets = _pack(_read_text_array(path, byte_range), strip_n)
-    return np.array(names), seq, offsets
+    return (np.array(names) if names else np.zeros(0, dtype="<U1")), seq, offsets
 
 
 def candidate_spans(offsets: np.ndarray, single_window: bool = False):

@@ -36,3 +36,30 @@ for run in range(2):
     z = np.load(out / "meta_nn_classification" / "meta_nn_classification.npz")
     print(f"  main() run {run}: {dt:.2f} s = {size / dt / 1e6:.0f} MB/s of FASTA, {len(z['contig_names'])} contigs scored"
           f" (first run includes library/engine start-up and weight upload)")
+
+# where the time goes inside main(): wrap the building blocks with timers and run once more
+import collections, functools
+from genomad_amd import engine as E
+acc = collections.OrderedDict()
+def timed(obj, name, label=None):
+    f = getattr(obj, name)
+    @functools.wraps(f)
+    def g(*a, **k):
+        t = time.time()
+        try:
+            return f(*a, **k)
+        finally:
+            acc[label or name] = acc.get(label or name, 0.0) + time.time() - t
+    setattr(obj, name, g)
+timed(sequence, "check_fasta"); timed(sequence, "read_fasta_packed"); timed(sequence, "candidate_spans")
+timed(E.DeviceBuffer, "upload", "upload packed contigs (H2D)")
+timed(E.NNEngine, "segment_mean")
+timed(nnc, "write_tsv"); timed(np, "savez_compressed")
+eng = nnc._engine()
+for name in ("gnn_span_byte_count", "gnn_classify_spans"):
+    timed(eng.lib, name)
+t = time.time()
+nnc.main(fa, tmp / "out_t", False, 128, True, 1, False, False)
+total = time.time() - t
+print(f"  breakdown of one main() call ({total:.2f} s):", {k: round(v, 3) for k, v in acc.items()},
+      "unaccounted", round(total - sum(v for k, v in acc.items() if k != 'candidate_spans'), 3))
