@@ -243,6 +243,38 @@ def test_main_end_to_end_on_gpu(engine, synth_weights, tmp_path, monkeypatch):
     assert not (out / "mini_nn_classification" / "mini_encoded_sequences").exists()   # --cleanup
 
 
+def test_main_device_path_invalid_fasta_leaves_nothing_behind(engine, synth_weights, tmp_path, monkeypatch):
+    """The device front end validates the FASTA concurrently with the classification; an input with a
+    duplicated identifier must still end like in the reference (error, exit 1) and must not leave an
+    NPZ / TSV / execution-info file behind (nn_classification.py:164-170 runs before anything else)."""
+    from genomad_amd import nn_classification as nnc
+    from genomad_amd import weights as W
+    rng = np.random.default_rng(3)
+    body = "".join(rng.choice(list("ACGT"), 7000))
+    fa = tmp_path / "dup.fna"
+    fa.write_text(f">a one\n{body}\n>b\n{body[:3000]}\n>a two\n{body[::-1]}\n")
+    wpath = tmp_path / "w.npz"
+    W.save_npz(wpath, synth_weights)
+    monkeypatch.setenv("GENOMAD_AMD_WEIGHTS", str(wpath))
+    monkeypatch.setattr(nnc, "_ENGINE", engine)
+    out = tmp_path / "out"
+    with pytest.raises(SystemExit) as exc:
+        nnc.main(fa, out, False, 128, False, 1, False, False)
+    assert exc.value.code == 1
+    d = out / "dup_nn_classification"
+    left = sorted(p.name for p in d.rglob("*")) if d.exists() else []
+    assert left == [], left
+    empty = tmp_path / "empty.fna"
+    empty.write_text("")
+    with pytest.raises(SystemExit):
+        nnc.main(empty, tmp_path / "out_e", False, 128, False, 1, False, False)
+    alln = tmp_path / "alln.fna"                       # valid FASTA, but no window survives strip_n
+    alln.write_text(">x\nNNNNNNNN\n")
+    with pytest.raises(SystemExit):
+        nnc.main(alln, tmp_path / "out_n", False, 128, False, 1, False, False)
+    assert not (tmp_path / "out_n" / "alln_nn_classification" / "alln_nn_classification.npz").exists()
+
+
 def test_config1_kpneumoniae_shaped_genome_through_main(engine, synth_weights, tmp_path, monkeypatch):
     """BASELINE config 1 (plumbing case): a genome shaped like GCF_009025895.1 — one ≈5.1 Mbp chromosome
     and the seven plasmids of the documented lengths, ≈ 910 windows — through the drop-in main().  The
