@@ -169,24 +169,48 @@ __device__ __forceinline__ void gemm_tile(const unsigned char* __restrict__ xbuf
     }
 }
 
-// conv epilogue: bias + LeakyReLU, split to bf16 hi/lo, write rows 5..132 of the output buffer.
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+
+// LeakyReLU + split of two values into packed bf16 hi / lo words.  Written on pairs so that hipcc
+// selects the packed forms (v_pk_mul_f32, v_cvt_pk_bf16_f32 on both halves, v_pk_add_f32): 8 VALU
+// ops per pair instead of 14 for the scalar form.  hi = bf16(x) (RNE), lo = bf16(x - hi).
+__device__ __forceinline__ void lrelu_split2(f32x2 v, uint32_t& hi, uint32_t& lo) {
+    const f32x2 s = v * LRELU;
+    v = f32x2{fmaxf(v[0], s[0]), fmaxf(v[1], s[1])};
+    hi = __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2));
+    const f32x2 back = {__uint_as_float(hi << 16), __uint_as_float(hi & 0xFFFF0000u)};
+    lo = __builtin_bit_cast(uint32_t, __builtin_convertvector(v - back, bf16x2));
+}
+
+// accumulators start at the bias (the bias add of the epilogue, for free): in the D = W^T X^T layout
+// register rg*4+e of a lane is output channel wave*32 + rg*8 + (lane>>5)*4 + e for every m-block
+__device__ __forceinline__ void acc_init_bias(f32x16 (&acc)[4], const float* __restrict__ bias, int wave, int lane) {
+#pragma unroll
+    for (int rg = 0; rg < 4; ++rg) {
+        const f32x4 b = *reinterpret_cast<const f32x4*>(bias + wave * 32 + rg * 8 + (lane >> 5) * 4);
+#pragma unroll
+        for (int mb = 0; mb < 4; ++mb)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc[mb][rg * 4 + e] = b[e];
+    }
+}
+
+// conv epilogue: LeakyReLU (the bias is already in the accumulators), split to bf16 hi/lo, write
+// rows 5..132 of the output buffer.
 // C/D layout of 32x32 MFMA: column = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5).
-__device__ __forceinline__ void conv_epilogue(unsigned char* __restrict__ obuf, const float* __restrict__ bias,
-                                              const f32x16 (&acc)[4], int wave, int lane) {
+__device__ __forceinline__ void conv_epilogue(unsigned char* __restrict__ obuf, const f32x16 (&acc)[4], int wave, int lane) {
 #pragma unroll
     for (int rg = 0; rg < 4; ++rg) {
         const int f0 = wave * 32 + rg * 8 + (lane >> 5) * 4;
-        const f32x4 b = *reinterpret_cast<const f32x4*>(bias + f0);
 #pragma unroll
         for (int mb = 0; mb < 4; ++mb) {
-            f32x4 v;
-#pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] = lrelu_f(acc[mb][rg * 4 + e] + b[e]);
-            const bf16x4 h = __builtin_convertvector(v, bf16x4);
-            const bf16x4 l = __builtin_convertvector(v - __builtin_convertvector(h, f32x4), bf16x4);
+            uint2 h, l;
+            lrelu_split2(f32x2{acc[mb][rg * 4], acc[mb][rg * 4 + 1]}, h.x, l.x);
+            lrelu_split2(f32x2{acc[mb][rg * 4 + 2], acc[mb][rg * 4 + 3]}, h.y, l.y);
             unsigned char* o = obuf + (CARRY + mb * 32 + (lane & 31)) * ROWB + f0 * 2;
-            *reinterpret_cast<uint2*>(o) = __builtin_bit_cast(uint2, h);
-            *reinterpret_cast<uint2*>(o + LO_OFF) = __builtin_bit_cast(uint2, l);
+            *reinterpret_cast<uint2*>(o) = h;
+            *reinterpret_cast<uint2*>(o + LO_OFF) = l;
         }
     }
 }
@@ -332,6 +356,9 @@ __device__ __forceinline__ uint32_t pair_row(int a, int b) {
 #ifndef GNN_GATHER_EARLY
 #define GNN_GATHER_EARLY 4      // positions (of 16 per thread) of the next step's gather done between B1 and B2
 #endif
+#ifndef GNN_GATHER_BATCH
+#define GNN_GATHER_BATCH 4      // positions whose 3 table loads each are in flight together
+#endif
 template <int P0, int P1>
 __device__ __forceinline__ void conv1_gather(unsigned char* __restrict__ xbuf, const uint16_t* __restrict__ prow,
                                              const float* __restrict__ pt, const float* __restrict__ b1,
@@ -343,11 +370,12 @@ __device__ __forceinline__ void conv1_gather(unsigned char* __restrict__ xbuf, c
     const uint2 r2 = *reinterpret_cast<const uint2*>(pr + 32);
     const uint32_t rw[10] = {r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, r1.z, r1.w, r2.x, r2.y};
     const float* ptc = pt + cq * 4;
+    constexpr int NB = (P1 - P0) % GNN_GATHER_BATCH == 0 ? GNN_GATHER_BATCH : 4;   // positions per load batch
 #pragma unroll
-    for (int i0 = P0; i0 < P1; i0 += 4) {
-        f32x4 v[4];
+    for (int i0 = P0; i0 < P1; i0 += NB) {
+        f32x4 v[NB];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
+        for (int i = 0; i < NB; ++i) {
             v[i] = b;
 #pragma unroll
             for (int j = 0; j < 3; ++j) {
@@ -357,14 +385,13 @@ __device__ __forceinline__ void conv1_gather(unsigned char* __restrict__ xbuf, c
             }
         }
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-#pragma unroll
-            for (int e = 0; e < 4; ++e) v[i][e] = fmaxf(v[i][e], v[i][e] * LRELU);   // LeakyReLU(0.1)
-            const bf16x4 h = __builtin_convertvector(v[i], bf16x4);
-            const bf16x4 l = __builtin_convertvector(v[i] - __builtin_convertvector(h, f32x4), bf16x4);
+        for (int i = 0; i < NB; ++i) {
+            uint2 h, l;
+            lrelu_split2(f32x2{v[i][0], v[i][1]}, h.x, l.x);                         // LeakyReLU(0.1) + hi/lo
+            lrelu_split2(f32x2{v[i][2], v[i][3]}, h.y, l.y);
             unsigned char* o = xbuf + (CARRY + ug * 16 + i0 + i) * ROWB + cq * 8;
-            *reinterpret_cast<uint2*>(o) = __builtin_bit_cast(uint2, h);
-            *reinterpret_cast<uint2*>(o + LO_OFF) = __builtin_bit_cast(uint2, l);
+            *reinterpret_cast<uint2*>(o) = h;
+            *reinterpret_cast<uint2*>(o + LO_OFF) = l;
         }
     }
 }
@@ -428,26 +455,20 @@ __global__ __launch_bounds__(512, 2) void fused_front_kernel(FusedArgs a) {
             wv_pool<PASSES>(bufX, vfrag[0], yp_w[0], t0, hw, lane);
             GNN_TICK(0)
             f32x16 acc[4];
-#pragma unroll
-            for (int mb = 0; mb < 4; ++mb)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) acc[mb][r] = 0.f;
+            acc_init_bias(acc, a.conv_b[0], hw, lane);
             gemm_tile<true, KS, PASSES>(bufX, cfrag[0], acc, lane);
             GNN_TICK(1)
             __syncthreads();                                                     // ---- B1
             GNN_TICK(2)
-            conv_epilogue(bufY, a.conv_b[0], acc, hw, lane);
+            conv_epilogue(bufY, acc, hw, lane);
             __syncthreads();                                                     // ---- B2
             GNN_TICK(3)
-#pragma unroll
-            for (int mb = 0; mb < 4; ++mb)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) acc[mb][r] = 0.f;
+            acc_init_bias(acc, a.conv_b[1], hw, lane);
             gemm_tile<true, KS, PASSES>(bufY, cfrag[1], acc, lane);
             GNN_TICK(4)
             __syncthreads();                                                     // ---- B3
             GNN_TICK(5)
-            conv_epilogue(bufY, a.conv_b[1], acc, hw, lane);
+            conv_epilogue(bufY, acc, hw, lane);
             __syncthreads();                                                     // ---- B4
             GNN_TICK(6)
             wv_pool<PASSES>(bufY, vfrag[1], yp_w[1], t0, hw, lane);
