@@ -135,7 +135,8 @@ static int classify_chunks(gnn_ctx* ctx, const uint8_t* bases_dev, int64_t n, in
         set_error("gnn_load_weights has not been called");
         return GNN_ERR_STATE;
     }
-    if (precision != GNN_PREC_F32 && precision != GNN_PREC_BF16X3 && precision != GNN_PREC_BF16) {
+    if (precision != GNN_PREC_F32 && precision != GNN_PREC_BF16X3 && precision != GNN_PREC_BF16 &&
+        precision != GNN_PREC_F16C8) {
         set_error("unknown precision " + std::to_string(precision));
         return GNN_ERR_ARG;
     }
@@ -151,7 +152,8 @@ static int classify_chunks(gnn_ctx* ctx, const uint8_t* bases_dev, int64_t n, in
             if ((rc = launch_front_f32(ctx, b, m))) return rc;
         } else {
             ProfScope ps(ctx, GNN_K_FUSED);
-            if ((rc = launch_front_fused(ctx, b, m, precision))) return rc;
+            if ((rc = precision == GNN_PREC_F16C8 ? launch_front_c8(ctx, b, m) : launch_front_fused(ctx, b, m, precision)))
+                return rc;
         }
         {
             ProfScope ps(ctx, GNN_K_BACKEND);
@@ -412,6 +414,7 @@ int gnn_load_weights(gnn_ctx* ctx, const gnn_weights* w) {
     if ((rc = upload(ctx, w->out_kernel, (size_t)HID * GNN_CLASSES, &d.d3_k))) return rc;
     if ((rc = upload(ctx, w->out_bias, (size_t)GNN_CLASSES, &d.d3_b))) return rc;
     if ((rc = pack_fused_weights(ctx, w))) return rc;
+    if ((rc = pack_fused_c8_weights(ctx, w))) return rc;
     ctx->has_weights = true;
     return GNN_OK;
 }

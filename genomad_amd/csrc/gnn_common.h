@@ -72,6 +72,12 @@ struct DeviceWeights {
     uint16_t* conv_frag[2] = {nullptr, nullptr};  // conv2, conv3: [kstep 48][nblk 4][plane 2][lane 64][8]
     uint16_t* wv_frag[2] = {nullptr, nullptr};    // head A, B:   [kstep 8][nblk 4][plane 2][lane 64][8]
     uint16_t* wqk_frag[2] = {nullptr, nullptr};   // head A, B:   [kstep 132][nblk 24][plane 2][lane 64][8], zero padded
+    // f16 + fp8-correction packs (gnn_fused_c8.hip): [k32 step][nblk 4][f16 even | f16 odd | fp8 lo | fp8 hi][lane 64] x 16 B
+    // and E8M0 block scales [tap][nblk 4][lane 64] u32
+    uint32_t* conv_c8[2] = {nullptr, nullptr};
+    uint32_t* conv_c8s[2] = {nullptr, nullptr};
+    uint32_t* wv_c8[2] = {nullptr, nullptr};
+    uint32_t* wv_c8s[2] = {nullptr, nullptr};
 };
 
 struct Workspace {
@@ -125,7 +131,10 @@ int launch_front_f32(gnn_ctx* ctx, const uint8_t* bases, int64_t n);         // 
 int launch_front_fused(gnn_ctx* ctx, const uint8_t* bases, int64_t n, int precision);  // -> ws.mp, ws.yp
 int launch_backend(gnn_ctx* ctx, int64_t n, int precision, float* scores_dev);   // ws.mp, ws.yp -> scores
 
-// host-side packing for the fused path (gnn_fused.hip)
+int launch_front_c8(gnn_ctx* ctx, const uint8_t* bases, int64_t n);             // GNN_PREC_F16C8 -> ws.mp, ws.yp
+
+// host-side packing for the fused paths (gnn_fused.hip, gnn_fused_c8.hip)
 int pack_fused_weights(gnn_ctx* ctx, const gnn_weights* w);
+int pack_fused_c8_weights(gnn_ctx* ctx, const gnn_weights* w);
 
 }  // namespace gnn

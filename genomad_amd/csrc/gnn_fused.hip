@@ -19,31 +19,9 @@
 // into VGPRs (L2 resident); wave w owns output channels 32w..32w+31 for all 128 rows.
 #include <cstring>
 
-#include "gnn_common.h"
+#include "gnn_fused_common.h"
 
 namespace gnn {
-
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
-typedef float f32x16 __attribute__((ext_vector_type(16)));
-typedef float f32x4 __attribute__((ext_vector_type(4)));
-
-constexpr int ROWB = 528;                    // LDS row stride in bytes
-constexpr int LO_OFF = 256;                  // lo plane offset inside a row
-constexpr int CARRY = KS - 1;                // 5 rows carried from the previous step
-constexpr int BUF_ROWS = CARRY + FT;         // 133
-constexpr int BUF_BYTES = BUF_ROWS * ROWB;   // 70224
-constexpr int TOK_OFF = 2 * BUF_BYTES;       // u16 tokens of the whole window, toks[j] = position j-5
-constexpr int TOK_COUNT = ((FSTEPS * FT + CARRY + KS) + 7) / 8 * 8;   // 6032
-constexpr int SMEM_BYTES = TOK_OFF + ((TOK_COUNT * 2 + 15) / 16) * 16;
-constexpr int FRAG_U4 = 64;                  // one fragment = 64 lanes x uint4
-
-// LeakyReLU(0.1) = max(v, 0.1 v) since the slope is < 1: two VALU ops instead of mul + compare + select
-__device__ __forceinline__ float lrelu_f(float v) { return fmaxf(v, v * LRELU); }
-
-__device__ __forceinline__ int base_code_f(uint32_t b) {
-    return b == 65 ? 0 : (b == 67 ? 1 : (b == 71 ? 2 : (b == 84 ? 3 : -1)));
-}
 
 // One GEMM tile of the wave: 4 m-blocks (128 rows of the LDS buffer) x 1 n-block (32 columns),
 // K = NTAPS * 128.  SWAP: D = W^T X^T (columns of D are positions; used by the convs so that a
@@ -169,7 +147,6 @@ __device__ __forceinline__ void gemm_tile(const unsigned char* __restrict__ xbuf
     }
 }
 
-typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 
 // LeakyReLU + split of two values into packed bf16 hi / lo words.  Written on pairs so that hipcc
@@ -182,6 +159,17 @@ __device__ __forceinline__ void lrelu_split2(f32x2 v, uint32_t& hi, uint32_t& lo
     const f32x2 back = {__uint_as_float(hi << 16), __uint_as_float(hi & 0xFFFF0000u)};
     lo = __builtin_bit_cast(uint32_t, __builtin_convertvector(v - back, bf16x2));
 }
+
+// conv1 gather epilogue of this kernel: 4 channels of one position -> bf16 hi / lo planes
+struct StoreBf16x2 {
+    static __device__ __forceinline__ void put(unsigned char* __restrict__ row, int cq, f32x4 v) {
+        uint2 h, l;
+        lrelu_split2(f32x2{v[0], v[1]}, h.x, l.x);
+        lrelu_split2(f32x2{v[2], v[3]}, h.y, l.y);
+        *reinterpret_cast<uint2*>(row + cq * 8) = h;
+        *reinterpret_cast<uint2*>(row + cq * 8 + LO_OFF) = l;
+    }
+};
 
 // accumulators start at the bias (the bias add of the epilogue, for free): in the D = W^T X^T layout
 // register rg*4+e of a lane is output channel wave*32 + rg*8 + (lane>>5)*4 + e for every m-block
@@ -298,104 +286,6 @@ __device__ __forceinline__ void m_partials(const unsigned char* __restrict__ xbu
     }
 }
 
-struct FusedArgs {
-    const uint8_t* bases;
-    const float* conv1_k;        // (3, PAIR_ROWS, 128) f32 conv1 pair tables
-    const float* conv1_b;
-    const uint4* conv_frag[2];
-    const float* conv_b[2];
-    const uint4* wv_frag[2];
-    const float* weff[2];
-    const int32_t* pos_sorted[2];
-    const int32_t* bucket_ptr[2];
-    float* mp;
-    float* yp;
-    unsigned long long* cycles;   // PROF builds: 10 phase counters, summed over workgroups
-};
-
-// PROF instrumentation: s_memtime deltas, MFMA wave 0 -> counters 0..7, helper wave 4 -> 8, 9:
-// 0 w_v+pool A, 1 conv2 loop, 2 wait B1, 3 conv2 epilogue+B2, 4 conv3 loop, 5 wait B3,
-// 6 conv3 epilogue+B4, 7 w_v+pool B + wait B0, 8 helper m-partials (B+A), 9 helper conv1 gather.
-#define GNN_TICK(i)                                                   \
-    if constexpr (PROF) {                                             \
-        const unsigned long long now_ = __builtin_readcyclecounter(); \
-        cyc[i] += now_ - tick_;                                       \
-        tick_ = now_;                                                 \
-    }
-
-// Token state of position t: -1 = before the window start (zero padding of the one-hot input),
-// 0 = the 4-mer touches a non-ACGT byte (or lies past the last token), 1..256 = 4-mer code + 1
-// (sequence.py:170-193, closed form).
-__device__ __forceinline__ int token_state(const uint8_t* __restrict__ bases, int t) {
-    if (t < 0) return -1;
-    if (t >= T) return 0;
-    const int c0 = base_code_f(bases[t]), c1 = base_code_f(bases[t + 1]), c2 = base_code_f(bases[t + 2]),
-              c3 = base_code_f(bases[t + 3]);
-    return (c0 | c1 | c2 | c3) < 0 ? 0 : 1 + c0 * 64 + c1 * 16 + c2 * 4 + c3;
-}
-
-// Row of the conv1 pair tables for the tokens (a, b) of two adjacent positions (layout built by
-// gnn_load_weights): adjacent 4-mers overlap in 3 bases, so a valid pair is a 5-mer.
-__device__ __forceinline__ uint32_t pair_row(int a, int b) {
-    if (a > 0 && b > 0) return (uint32_t)((a - 1) * 4 + ((b - 1) & 3));
-    if (a == 0 && b > 0) return 1024u + (uint32_t)(b - 1);
-    if (a > 0 && b == 0) return 1280u + (uint32_t)(a - 1);
-    if (a == 0) return 1536u;            // (N, N)
-    if (b < 0) return 1537u;             // both before the window start: zero row
-    return 1538u + (uint32_t)b;          // only the first one is before the window start
-}
-
-// conv1 + LeakyReLU for the 128 positions starting at t0, split to bf16 hi/lo, into rows 5..132 of
-// xbuf.  conv1 on a one-hot input is a 6-row gather-sum of its kernel (model.py:11 + igloo.py:45-48);
-// with the pair tables it is 3 rows: taps (0,1), (2,3), (4,5) of position t read the pairs starting
-// at t-5, t-3, t-1.  prow[j] is the pair row of positions (j-5, j-4).  256 helper threads:
-// thread = 4 channels x 16 CONSECUTIVE positions, so the 20 pair rows it needs are 40 contiguous
-// bytes of LDS, fetched with three wide reads up front: the LDS pipe is busy feeding the matrix
-// waves, and per-position index reads in the dependency chain of every load batch were what made
-// the gather 4x slower beside the MFMA loops than alone.  Positions P0..P1 (of 16) are produced.
-#ifndef GNN_GATHER_EARLY
-#define GNN_GATHER_EARLY 4      // positions (of 16 per thread) of the next step's gather done between B1 and B2
-#endif
-#ifndef GNN_GATHER_BATCH
-#define GNN_GATHER_BATCH 4      // positions whose 3 table loads each are in flight together
-#endif
-template <int P0, int P1>
-__device__ __forceinline__ void conv1_gather(unsigned char* __restrict__ xbuf, const uint16_t* __restrict__ prow,
-                                             const float* __restrict__ pt, const float* __restrict__ b1,
-                                             int t0, int ht) {
-    const int cq = ht & 31, ug = ht >> 5;
-    const f32x4 b = *reinterpret_cast<const f32x4*>(b1 + cq * 4);
-    const unsigned char* pr = reinterpret_cast<const unsigned char*>(prow + t0 + ug * 16);   // 32-B aligned
-    const uint4 r0 = *reinterpret_cast<const uint4*>(pr), r1 = *reinterpret_cast<const uint4*>(pr + 16);
-    const uint2 r2 = *reinterpret_cast<const uint2*>(pr + 32);
-    const uint32_t rw[10] = {r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, r1.z, r1.w, r2.x, r2.y};
-    const float* ptc = pt + cq * 4;
-    constexpr int NB = (P1 - P0) % GNN_GATHER_BATCH == 0 ? GNN_GATHER_BATCH : 4;   // positions per load batch
-#pragma unroll
-    for (int i0 = P0; i0 < P1; i0 += NB) {
-        f32x4 v[NB];
-#pragma unroll
-        for (int i = 0; i < NB; ++i) {
-            v[i] = b;
-#pragma unroll
-            for (int j = 0; j < 3; ++j) {
-                const int e = i0 + i + 2 * j;                           // static after unrolling
-                const uint32_t r = (rw[e >> 1] >> ((e & 1) * 16)) & 0xFFFFu;
-                v[i] += *reinterpret_cast<const f32x4*>(ptc + ((size_t)j * PAIR_ROWS + r) * C);
-            }
-        }
-#pragma unroll
-        for (int i = 0; i < NB; ++i) {
-            uint2 h, l;
-            lrelu_split2(f32x2{v[i][0], v[i][1]}, h.x, l.x);                         // LeakyReLU(0.1) + hi/lo
-            lrelu_split2(f32x2{v[i][2], v[i][3]}, h.y, l.y);
-            unsigned char* o = xbuf + (CARRY + ug * 16 + i0 + i) * ROWB + cq * 8;
-            *reinterpret_cast<uint2*>(o) = h;
-            *reinterpret_cast<uint2*>(o + LO_OFF) = l;
-        }
-    }
-}
-
 // Warp-specialised workgroup of 8 waves streaming one window through 47 steps of 128 positions:
 //   waves 0-3 ("MFMA waves", one per SIMD): y@w_v + pool of head A, conv2, conv3, y@w_v + pool of head B
 //   waves 4-7 ("helpers", the second wave of each SIMD): everything that is memory-latency bound —
@@ -437,7 +327,7 @@ __global__ __launch_bounds__(512, 2) void fused_front_kernel(FusedArgs a) {
         toks[j] = (uint16_t)pair_row(token_state(bases, t), token_state(bases, t + 1));
     }
     __syncthreads();
-    if (helper) conv1_gather<0, FT / 8>(bufX, toks, a.conv1_k, a.conv1_b, 0, ht);
+    if (helper) conv1_gather<0, FT / 8, StoreBf16x2>(bufX, toks, a.conv1_k, a.conv1_b, 0, ht);
     // static priority for the matrix waves (measured neutral against no priority and against
     // prioritising the helpers; kept so the matrix pipe never loses an issue slot to a helper)
     else __builtin_amdgcn_s_setprio(2);
@@ -485,10 +375,10 @@ __global__ __launch_bounds__(512, 2) void fused_front_kernel(FusedArgs a) {
             if (ht < CARRY * 32) *reinterpret_cast<uint4*>(bufX + cr * ROWB + cc * 16) = carry;
             // bufX is free from B1 on: the first part of the next step's gather runs while the matrix
             // waves are in their conv2 epilogue (no MFMA traffic to compete with), the rest beside conv3
-            if (step + 1 < FSTEPS) conv1_gather<0, GNN_GATHER_EARLY>(bufX, toks, a.conv1_k, a.conv1_b, t0 + FT, ht);
+            if (step + 1 < FSTEPS) conv1_gather<0, GNN_GATHER_EARLY, StoreBf16x2>(bufX, toks, a.conv1_k, a.conv1_b, t0 + FT, ht);
             __syncthreads();                                                     // ---- B2
             if constexpr (PROF) tick_ = __builtin_readcyclecounter();
-            if (step + 1 < FSTEPS) conv1_gather<GNN_GATHER_EARLY, FT / 8>(bufX, toks, a.conv1_k, a.conv1_b, t0 + FT, ht);
+            if (step + 1 < FSTEPS) conv1_gather<GNN_GATHER_EARLY, FT / 8, StoreBf16x2>(bufX, toks, a.conv1_k, a.conv1_b, t0 + FT, ht);
             if (ht < CARRY * 32) carry = *reinterpret_cast<const uint4*>(bufY + (FT + cr) * ROWB + cc * 16);
             GNN_TICK(9)
             __syncthreads();                                                     // ---- B3

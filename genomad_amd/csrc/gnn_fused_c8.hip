@@ -1,0 +1,568 @@
+// Fused front end, GNN_PREC_F16C8: same streaming structure as gnn_fused.hip (one workgroup = one
+// window, 47 steps of 128 positions, activations resident in LDS, 4 matrix waves + 4 helper waves),
+// different arithmetic on the matrix pipe: 2.0 instead of 3.0 bf16-pass equivalents per contraction.
+//
+//   x * w  ~=  f16(x) * f16(w)                      v_mfma_f32_32x32x16_f16, K = 16 per instruction
+//            + e4m3(x) * e4m3_mx(w - f16(w))        \  one v_mfma_scale_f32_32x32x64_f8f6f4 per 32 channels:
+//            + e4m3((x - f16(x)) * 2^11) * e4m3_mx(w) /  K block 0 = first product, K block 1 = second
+//
+// The f16 product carries 11 x 11 significant bits; what it misses is x*(w - f16 w) + (x - f16 x)*w, two
+// terms 2^-11 smaller that only need ~4 significant bits each, which is what fp8 e4m3 holds.  The MX
+// scales of the instruction (one E8M0 byte per lane and 32-element K block) put each term at its
+// place: activations use 2^0 (block 0) and 2^-11 (block 1, the residual is stored times 2^11),
+// weights use per-(32 k, column) block exponents chosen at packing time.  Measured in emulation
+// (oracle/precision_study.py, profiles/r02_precision_study.json): max |dscore| 4e-5 vs the fp64 oracle,
+// against 1.6e-5 for split-bf16 x 3 and a tolerance of 1e-4.  The fp8 MFMA runs at twice the f16 rate
+// (64 cycles for K = 64 against 32 cycles for K = 16), so a 32-channel slice of K costs 2 x 32 + 64 = 128
+// matrix-pipe cycles per 32x32 tile instead of 6 x 32 = 192.
+//
+// Operand layout facts established on the hardware by scripts/probe_mx.hip (profiles/r02_probe_mx.txt):
+//  * fp8 operands of 32x32x64: lane l = row (or column) l & 31; its bytes 0-15 are elements
+//    16*(l>>5) .. +15 of K block 0 and its bytes 16-31 the same elements of K block 1; the scale of
+//    block 0 comes from lanes 0-31, the scale of block 1 from lanes 32-63 (byte OPSEL of the scale VGPR).
+//  * v_cvt_pk_fp8_f32 rounds to nearest even, saturates only up to 464 and returns NaN above: inputs
+//    are clamped to +-448 first.  v_cvt_scalef32_pk_fp8_f32 converts x / scale.
+//
+// LDS row (528 B, same stride as the bf16 kernel): 128 ch f16 | 128 ch e4m3(x) | 128 ch e4m3((x - f16 x) 2^11) | pad
+#include <cmath>
+#include <cstring>
+
+#include "gnn_fused_common.h"
+
+namespace gnn {
+
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+typedef int i32x8 __attribute__((ext_vector_type(8)));
+typedef short i16x2 __attribute__((ext_vector_type(2)));
+
+constexpr int X8_OFF = 256;                  // e4m3(x) plane inside a row
+constexpr int XL8_OFF = 384;                 // e4m3((x - f16(x)) * 2^11) plane
+constexpr int XL_SHIFT = 11;                 // residual exponent shift (f16 has 11 significant bits)
+constexpr int C8_STEP_U4 = 4 * 4 * 64;       // uint4 per k32 step: 4 n-blocks x 4 fragments x 64 lanes
+constexpr int C8_NBLK_U4 = 4 * 64;           // uint4 per (k32 step, n-block)
+
+struct FusedArgsC8 {
+    const uint8_t* bases;
+    const float* conv1_k;        // (3, PAIR_ROWS, 128) f32 conv1 pair tables
+    const float* conv1_b;
+    const uint4* conv_w[2];      // [k32 step 24][nblk 4][f16 k16 even | f16 k16 odd | fp8 bytes 0-15 | fp8 bytes 16-31][lane 64] x 16 B
+    const uint32_t* conv_s[2];   // [tap 6][nblk 4][lane 64] u32: byte j = E8M0 scale of k32 step 4*tap + j
+    const float* conv_b[2];
+    const uint4* wv_w[2];        // same layouts, 4 k32 steps / 1 tap
+    const uint32_t* wv_s[2];
+    const float* weff[2];
+    const int32_t* pos_sorted[2];
+    const int32_t* bucket_ptr[2];
+    float* mp;
+    float* yp;
+    unsigned long long* cycles;
+};
+
+// Weights of one k32 step for this wave's n-block and activations of one k32 step for the 4 m-blocks.
+struct WStep {
+    uint4 h0, h1;      // f16 fragments of the two k16 halves
+    uint4 c0, c1;      // fp8 fragment: bytes 0-15 (K block 0: e4m3_mx(w - f16 w)), bytes 16-31 (K block 1: e4m3_mx(w))
+};
+struct XF16 {
+    uint4 v[2][4];     // [k16 half][m-block]
+};
+struct XC8 {
+    uint4 v[4][2];     // [m-block][K block]
+};
+
+// Weight fragments are addressed as (wave-uniform base pointer) + (32-bit per-lane byte offset) so that the
+// loads take the SGPR-base form and no 64-bit per-lane pointers have to live in VGPRs.
+__device__ __forceinline__ const uint4* wptr(const uint4* __restrict__ base, uint32_t lane_off, int frag) {
+    return reinterpret_cast<const uint4*>(reinterpret_cast<const unsigned char*>(base) + lane_off + frag * 1024);
+}
+__device__ __forceinline__ void load_w_h(WStep& w, const uint4* __restrict__ base, uint32_t lane_off) {
+    w.h0 = *wptr(base, lane_off, 0);
+    w.h1 = *wptr(base, lane_off, 1);
+}
+__device__ __forceinline__ void load_w_c(WStep& w, const uint4* __restrict__ base, uint32_t lane_off) {
+    w.c0 = *wptr(base, lane_off, 2);
+    w.c1 = *wptr(base, lane_off, 3);
+}
+// keeps memory operations inside their scheduling region: sched_barrier only binds the machine scheduler,
+// instruction selection is otherwise free to emit the (independent) loads of a basic block in any order
+#define GNN_REGION_END()                      \
+    __builtin_amdgcn_sched_barrier(0);        \
+    asm volatile("" ::: "memory")
+// xt = lane base of the tap row; J = k32 step inside the tap
+template <int J>
+__device__ __forceinline__ void load_xf(XF16& f, const unsigned char* __restrict__ xt) {
+#pragma unroll
+    for (int s = 0; s < 2; ++s)
+#pragma unroll
+        for (int mb = 0; mb < 4; ++mb)
+            f.v[s][mb] = *reinterpret_cast<const uint4*>(xt + mb * 32 * ROWB + (J * 2 + s) * 32);
+}
+template <int J>
+__device__ __forceinline__ void load_xc(XC8& f, const unsigned char* __restrict__ xt) {
+#pragma unroll
+    for (int mb = 0; mb < 4; ++mb) {
+        f.v[mb][0] = *reinterpret_cast<const uint4*>(xt + mb * 32 * ROWB + X8_OFF + J * 32);
+        f.v[mb][1] = *reinterpret_cast<const uint4*>(xt + mb * 32 * ROWB + XL8_OFF + J * 32);
+    }
+}
+
+template <bool SWAP>
+__device__ __forceinline__ void mfma_f16_phase(const WStep& w, const XF16& x, f32x16 (&acc)[4]) {
+    const f16x8 w0 = __builtin_bit_cast(f16x8, w.h0), w1 = __builtin_bit_cast(f16x8, w.h1);
+#pragma unroll
+    for (int mb = 0; mb < 4; ++mb) {
+        const f16x8 xv = __builtin_bit_cast(f16x8, x.v[0][mb]);
+        acc[mb] = SWAP ? __builtin_amdgcn_mfma_f32_32x32x16_f16(w0, xv, acc[mb], 0, 0, 0)
+                       : __builtin_amdgcn_mfma_f32_32x32x16_f16(xv, w0, acc[mb], 0, 0, 0);
+    }
+#pragma unroll
+    for (int mb = 0; mb < 4; ++mb) {
+        const f16x8 xv = __builtin_bit_cast(f16x8, x.v[1][mb]);
+        acc[mb] = SWAP ? __builtin_amdgcn_mfma_f32_32x32x16_f16(w1, xv, acc[mb], 0, 0, 0)
+                       : __builtin_amdgcn_mfma_f32_32x32x16_f16(xv, w1, acc[mb], 0, 0, 0);
+    }
+}
+
+// J selects the byte of the weight scale word (OPSEL); sx = activation scale word (byte 0)
+template <bool SWAP, int J>
+__device__ __forceinline__ void mfma_c8_phase(const WStep& w, const XC8& x, int ws, int sx, f32x16 (&acc)[4]) {
+    const i32x8 wv = {(int)w.c0.x, (int)w.c0.y, (int)w.c0.z, (int)w.c0.w, (int)w.c1.x, (int)w.c1.y, (int)w.c1.z, (int)w.c1.w};
+#pragma unroll
+    for (int mb = 0; mb < 4; ++mb) {
+        const uint4 a = x.v[mb][0], b = x.v[mb][1];
+        const i32x8 xv = {(int)a.x, (int)a.y, (int)a.z, (int)a.w, (int)b.x, (int)b.y, (int)b.z, (int)b.w};
+        acc[mb] = SWAP ? __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(wv, xv, acc[mb], 0, 0, J, ws, 0, sx)
+                       : __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(xv, wv, acc[mb], 0, 0, 0, sx, J, ws);
+    }
+}
+
+// One k32 step = two scheduling regions.  Region F: the 8 f16 MFMAs of step j, with the fp8 activation
+// fragments of the SAME step (8 LDS reads) and the f16 weight fragments of step j+3 (2 L2 loads) issued
+// between them.  Region C: the 4 fp8 MFMAs (64 cycles each), with the f16 activation fragments of step
+// j+1 and the fp8 weight fragment of step j+3.  Every operand is therefore requested at least 256
+// matrix-pipe cycles (LDS) or three k32 steps = 1536 cycles (L2) before the MFMA that reads it.
+template <bool SWAP, int J, int JN, bool LW, bool LX>
+__device__ __forceinline__ void k32_step(const WStep& wcur, WStep& wload, XF16& xf, XC8& xc,
+                                         const unsigned char* __restrict__ xt, const unsigned char* __restrict__ xt_next,
+                                         const uint4* __restrict__ wnext, uint32_t lane_off, int ws, int sx, f32x16 (&acc)[4]) {
+    load_xc<J>(xc, xt);
+    if constexpr (LW) load_w_h(wload, wnext, lane_off);
+    mfma_f16_phase<SWAP>(wcur, xf, acc);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);   // 1 MFMA
+        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);   // 1 DS read
+        if (LW && (i == 1 || i == 5)) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);   // 1 VMEM read
+    }
+    GNN_REGION_END();
+    if constexpr (LX) load_xf<JN>(xf, xt_next);
+    if constexpr (LW) load_w_c(wload, wnext, lane_off);
+    mfma_c8_phase<SWAP, J>(wcur, xc, ws, sx, acc);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        if (LX) __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+        if (LW && (i == 0 || i == 2)) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+    }
+    GNN_REGION_END();
+}
+
+// 128 rows x 32 columns, K = NTAPS * 128, as NTAPS * 4 k32 steps; weight ring of four k32 steps.
+// SWAP as in gnn_fused.hip: D = W^T X^T for the convs, D = X W for y @ w_v.  wbase / sbase are wave-uniform
+// (already offset to this wave's n-block), lane = lane id.
+template <bool SWAP, int NTAPS>
+__device__ __forceinline__ void gemm_tile_c8(const unsigned char* __restrict__ xbuf, const uint4* __restrict__ wbase,
+                                             const uint32_t* __restrict__ sbase, f32x16 (&acc)[4], int lane, int sx) {
+    constexpr int NK = NTAPS * 4;
+    constexpr bool MULTI = NTAPS > 1;        // single tap: no prefetch past the end (it would be a reload of step 0)
+    const unsigned char* xl = xbuf + (lane & 31) * ROWB + (lane >> 5) * 16;
+    const uint32_t lane_off = (uint32_t)lane * 16u, lane_s = (uint32_t)lane * 4u;
+    WStep w0, w1, w2, w3;
+    XF16 xf;
+    XC8 xc;
+    load_w_h(w0, wbase, lane_off);
+    load_w_c(w0, wbase, lane_off);
+    load_w_h(w1, wbase + C8_STEP_U4, lane_off);
+    load_w_c(w1, wbase + C8_STEP_U4, lane_off);
+    load_w_h(w2, wbase + 2 * C8_STEP_U4, lane_off);
+    load_w_c(w2, wbase + 2 * C8_STEP_U4, lane_off);
+    int ws = *reinterpret_cast<const int*>(reinterpret_cast<const unsigned char*>(sbase) + lane_s);
+    load_xf<0>(xf, xl);
+    GNN_REGION_END();
+#pragma unroll 1
+    for (int t = 0; t < NTAPS; ++t) {
+        const int k = t * 4;
+        const unsigned char* xt = xl + t * ROWB;
+        const unsigned char* xn = xl + min(t + 1, NTAPS - 1) * ROWB;
+        int ws_next = ws;
+        if constexpr (MULTI)
+            ws_next = *reinterpret_cast<const int*>(reinterpret_cast<const unsigned char*>(sbase + min(t + 1, NTAPS - 1) * 256) + lane_s);
+        // clamped prefetch indices past the end are harmless re-reads
+        k32_step<SWAP, 0, 1, true, true>(w0, w3, xf, xc, xt, xt, wbase + (size_t)min(k + 3, NK - 1) * C8_STEP_U4, lane_off, ws, sx, acc);
+        k32_step<SWAP, 1, 2, MULTI, true>(w1, w0, xf, xc, xt, xt, wbase + (size_t)min(k + 4, NK - 1) * C8_STEP_U4, lane_off, ws, sx, acc);
+        k32_step<SWAP, 2, 3, MULTI, true>(w2, w1, xf, xc, xt, xt, wbase + (size_t)min(k + 5, NK - 1) * C8_STEP_U4, lane_off, ws, sx, acc);
+        k32_step<SWAP, 3, 0, MULTI, MULTI>(w3, w2, xf, xc, xt, xn, wbase + (size_t)min(k + 6, NK - 1) * C8_STEP_U4, lane_off, ws, sx, acc);
+        ws = ws_next;
+    }
+}
+
+// LeakyReLU(0.1) on 4 consecutive channels of one position, then the three operand images:
+// h = f16(x) (RNE), x8 = e4m3(clamp(x, +-448)), xl8 = e4m3((x - h) * 2^11).
+__device__ __forceinline__ void lrelu_split4_c8(f32x4 v, uint2& h, uint32_t& x8, uint32_t& xl8) {
+    const f32x2 a = {v[0], v[1]}, b = {v[2], v[3]};
+    const f32x2 sa = a * LRELU, sb = b * LRELU;
+    const float x0 = fmaxf(a[0], sa[0]), x1 = fmaxf(a[1], sa[1]), x2 = fmaxf(b[0], sb[0]), x3 = fmaxf(b[1], sb[1]);
+    const f16x2 h01 = __builtin_convertvector(f32x2{x0, x1}, f16x2), h23 = __builtin_convertvector(f32x2{x2, x3}, f16x2);
+    h.x = __builtin_bit_cast(uint32_t, h01);
+    h.y = __builtin_bit_cast(uint32_t, h23);
+    const float r0 = x0 - (float)h01[0], r1 = x1 - (float)h01[1], r2 = x2 - (float)h23[0], r3 = x3 - (float)h23[1];
+    const float lim = 448.f;
+    int p = __builtin_amdgcn_cvt_pk_fp8_f32(__builtin_amdgcn_fmed3f(x0, -lim, lim), __builtin_amdgcn_fmed3f(x1, -lim, lim), 0, false);
+    p = __builtin_amdgcn_cvt_pk_fp8_f32(__builtin_amdgcn_fmed3f(x2, -lim, lim), __builtin_amdgcn_fmed3f(x3, -lim, lim), p, true);
+    x8 = (uint32_t)p;
+    // x / scale with scale = 2^-11: the residual times 2^11 (|.| <= |x| / 2, no overflow when x8 has none)
+    const float inv = 1.0f / (float)(1 << XL_SHIFT);
+    i16x2 q = {0, 0};
+    q = __builtin_amdgcn_cvt_scalef32_pk_fp8_f32(q, r0, r1, inv, false);
+    q = __builtin_amdgcn_cvt_scalef32_pk_fp8_f32(q, r2, r3, inv, true);
+    xl8 = __builtin_bit_cast(uint32_t, q);
+}
+
+struct StoreF16C8 {
+    static __device__ __forceinline__ void put(unsigned char* __restrict__ row, int cq, f32x4 v) {
+        uint2 h;
+        uint32_t x8, xl8;
+        lrelu_split4_c8(v, h, x8, xl8);
+        *reinterpret_cast<uint2*>(row + cq * 8) = h;
+        *reinterpret_cast<uint32_t*>(row + X8_OFF + cq * 4) = x8;
+        *reinterpret_cast<uint32_t*>(row + XL8_OFF + cq * 4) = xl8;
+    }
+};
+
+// bias pre-loaded into the accumulators, D = W^T X^T layout (see gnn_fused.hip)
+__device__ __forceinline__ void acc_init_bias_c8(f32x16 (&acc)[4], const float* __restrict__ bias, int wave, int lane) {
+#pragma unroll
+    for (int rg = 0; rg < 4; ++rg) {
+        const f32x4 b = *reinterpret_cast<const f32x4*>(bias + wave * 32 + rg * 8 + (lane >> 5) * 4);
+#pragma unroll
+        for (int mb = 0; mb < 4; ++mb)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc[mb][rg * 4 + e] = b[e];
+    }
+}
+
+__device__ __forceinline__ void conv_epilogue_c8(unsigned char* __restrict__ obuf, const f32x16 (&acc)[4], int wave, int lane) {
+#pragma unroll
+    for (int rg = 0; rg < 4; ++rg) {
+        const int cq = (wave * 32 + rg * 8 + (lane >> 5) * 4) >> 2;      // group of 4 channels
+#pragma unroll
+        for (int mb = 0; mb < 4; ++mb)
+            StoreF16C8::put(obuf + (CARRY + mb * 32 + (lane & 31)) * ROWB, cq,
+                            f32x4{acc[mb][rg * 4], acc[mb][rg * 4 + 1], acc[mb][rg * 4 + 2], acc[mb][rg * 4 + 3]});
+    }
+}
+
+// y @ w_v on the current 128 rows + MaxPool1D(8) -> yp rows (igloo.py:208-210)
+__device__ __forceinline__ void wv_pool_c8(const unsigned char* __restrict__ xbuf, const uint4* __restrict__ wfrag,
+                                           const uint32_t* __restrict__ wscale, float* __restrict__ yp_w, int t0, int wave,
+                                           int lane, int sx) {
+    f32x16 acc[4];
+#pragma unroll
+    for (int mb = 0; mb < 4; ++mb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[mb][r] = 0.f;
+    gemm_tile_c8<false, 1>(xbuf + CARRY * ROWB, wfrag, wscale, acc, lane, sx);
+    float m[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        const int mb = i >> 2, rg = i & 3;
+        const float v = fmaxf(fmaxf(acc[mb][rg * 4], acc[mb][rg * 4 + 1]), fmaxf(acc[mb][rg * 4 + 2], acc[mb][rg * 4 + 3]));
+        const unsigned bits = __float_as_uint(v);
+        const auto sw = __builtin_amdgcn_permlane32_swap(bits, bits, false, false);
+        m[i] = fmaxf(v, __uint_as_float(lane < 32 ? sw[1] : sw[0]));
+    }
+    const int q0 = t0 / GNN_POOL;
+    const int nq = min(16, POOLED - q0);
+    if (lane < 32) {
+        float* dst = yp_w + (size_t)q0 * C + wave * 32 + lane;
+#pragma unroll
+        for (int i = 0; i < 16; ++i)
+            if (i < nq) dst[(size_t)i * C] = m[i];
+    }
+}
+
+// IGLOO pair dot products of this step (igloo.py:192-204 with w_mult * w_summer folded), rows read back
+// from LDS as f16 + residual image: x = f16 + e4m3 * 2^-11.  Structure as m_partials in gnn_fused.hip.
+__device__ __forceinline__ void m_partials_c8(const unsigned char* __restrict__ xbuf, const float* __restrict__ weff,
+                                              const int32_t* __restrict__ pos, int t0, int e_begin, int e_end,
+                                              float* __restrict__ mp_w, int wave, int lane) {
+    constexpr int MB = 4;
+    const int sub = lane & 15;
+    for (int e = e_begin + wave * 4 + (lane >> 4); e < e_end; e += 16 * MB) {
+        int ei[MB], u[MB];
+        float4 w0[MB], w1[MB];
+        uint4 h[MB];
+        uint2 l[MB];
+#pragma unroll
+        for (int i = 0; i < MB; ++i) {
+            ei[i] = min(e + 16 * i, e_end - 1);
+            u[i] = pos[ei[i]] - t0;
+        }
+#pragma unroll
+        for (int i = 0; i < MB; ++i) {
+            w0[i] = *reinterpret_cast<const float4*>(weff + (size_t)ei[i] * C + sub * 8);
+            w1[i] = *reinterpret_cast<const float4*>(weff + (size_t)ei[i] * C + sub * 8 + 4);
+        }
+#pragma unroll
+        for (int i = 0; i < MB; ++i) {
+            const unsigned char* xr = xbuf + (CARRY + u[i]) * ROWB;
+            h[i] = *reinterpret_cast<const uint4*>(xr + sub * 16);
+            l[i] = *reinterpret_cast<const uint2*>(xr + XL8_OFF + sub * 8);
+        }
+#pragma unroll
+        for (int i = 0; i < MB; ++i) {
+            const uint32_t hv[4] = {h[i].x, h[i].y, h[i].z, h[i].w};
+            const float wv[8] = {w0[i].x, w0[i].y, w0[i].z, w0[i].w, w1[i].x, w1[i].y, w1[i].z, w1[i].w};
+            float s = 0.f, r = 0.f;
+            const f32x2 lo4[4] = {__builtin_amdgcn_cvt_pk_f32_fp8((int)l[i].x, false), __builtin_amdgcn_cvt_pk_f32_fp8((int)l[i].x, true),
+                                  __builtin_amdgcn_cvt_pk_f32_fp8((int)l[i].y, false), __builtin_amdgcn_cvt_pk_f32_fp8((int)l[i].y, true)};
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const f16x2 hh = __builtin_bit_cast(f16x2, hv[k]);
+                s = fmaf((float)hh[0], wv[2 * k], s);
+                s = fmaf((float)hh[1], wv[2 * k + 1], s);
+                r = fmaf(lo4[k][0], wv[2 * k], r);
+                r = fmaf(lo4[k][1], wv[2 * k + 1], r);
+            }
+            s = fmaf(r, 1.0f / (float)(1 << XL_SHIFT), s);
+#pragma unroll
+            for (int off = 8; off >= 1; off >>= 1) s += __shfl_xor(s, off, 16);
+            if (sub == 0 && e + 16 * i < e_end) mp_w[e + 16 * i] = s;
+        }
+    }
+}
+
+// Same step structure and barriers B0..B4 as fused_front_kernel (gnn_fused.hip).
+template <bool PROF>
+__global__ __launch_bounds__(512, 2) void fused_front_c8_kernel(FusedArgsC8 a) {
+    __shared__ __attribute__((aligned(16))) unsigned char smem[SMEM_BYTES];
+    unsigned char* bufX = smem;
+    unsigned char* bufY = smem + BUF_BYTES;
+    uint16_t* toks = reinterpret_cast<uint16_t*>(smem + TOK_OFF);
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const bool helper = wave >= 4;
+    const int hw = wave & 3;
+    const int ht = tid & 255;
+    const int64_t wi = blockIdx.x;
+    const uint8_t* bases = a.bases + wi * W;
+    float* mp_w[2] = {a.mp + (wi * 2 + 0) * NPAIR, a.mp + (wi * 2 + 1) * NPAIR};
+    float* yp_w[2] = {a.yp + (wi * 2 + 0) * (size_t)POOLED * C, a.yp + (wi * 2 + 1) * (size_t)POOLED * C};
+    // wave-uniform bases of this wave's n-block (the per-lane part is added as a 32-bit offset at the loads)
+    const uint4* cw[2] = {a.conv_w[0] + hw * C8_NBLK_U4, a.conv_w[1] + hw * C8_NBLK_U4};
+    const uint4* vw[2] = {a.wv_w[0] + hw * C8_NBLK_U4, a.wv_w[1] + hw * C8_NBLK_U4};
+    const uint32_t* cs[2] = {a.conv_s[0] + hw * 64, a.conv_s[1] + hw * 64};
+    const uint32_t* vs[2] = {a.wv_s[0] + hw * 64, a.wv_s[1] + hw * 64};
+    // activation scales: K block 0 (lanes 0-31) = e4m3(x) at 2^0, K block 1 (lanes 32-63) = residual image at 2^-11
+    const int sx = lane < 32 ? 127 : 127 - XL_SHIFT;
+
+    for (int i = tid; i < CARRY * ROWB / 16; i += 512) {
+        reinterpret_cast<uint4*>(bufX)[i] = make_uint4(0, 0, 0, 0);
+        reinterpret_cast<uint4*>(bufY)[i] = make_uint4(0, 0, 0, 0);
+    }
+    for (int j = tid; j < TOK_COUNT; j += 512) {
+        const int t = j - CARRY;
+        toks[j] = (uint16_t)pair_row(token_state(bases, t), token_state(bases, t + 1));
+    }
+    __syncthreads();
+    if (helper) conv1_gather<0, FT / 8, StoreF16C8>(bufX, toks, a.conv1_k, a.conv1_b, 0, ht);
+    else __builtin_amdgcn_s_setprio(2);
+
+    unsigned long long cyc[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long tick_ = 0;
+
+#pragma unroll 1
+    for (int step = 0; step < FSTEPS; ++step) {
+        const int t0 = step * FT;
+        __syncthreads();                                                         // ---- B0
+        if constexpr (PROF) tick_ = step == 0 ? __builtin_readcyclecounter() : tick_;
+        if (!helper) {
+            GNN_TICK(7)
+            wv_pool_c8(bufX, vw[0], vs[0], yp_w[0], t0, hw, lane, sx);
+            GNN_TICK(0)
+            f32x16 acc[4];
+            acc_init_bias_c8(acc, a.conv_b[0], hw, lane);
+            gemm_tile_c8<true, KS>(bufX, cw[0], cs[0], acc, lane, sx);
+            GNN_TICK(1)
+            __syncthreads();                                                     // ---- B1
+            GNN_TICK(2)
+            conv_epilogue_c8(bufY, acc, hw, lane);
+            __syncthreads();                                                     // ---- B2
+            GNN_TICK(3)
+            acc_init_bias_c8(acc, a.conv_b[1], hw, lane);
+            gemm_tile_c8<true, KS>(bufY, cw[1], cs[1], acc, lane, sx);
+            GNN_TICK(4)
+            __syncthreads();                                                     // ---- B3
+            GNN_TICK(5)
+            conv_epilogue_c8(bufY, acc, hw, lane);
+            __syncthreads();                                                     // ---- B4
+            GNN_TICK(6)
+            wv_pool_c8(bufY, vw[1], vs[1], yp_w[1], t0, hw, lane, sx);
+        } else {
+            if (step > 0)
+                m_partials_c8(bufY, a.weff[1], a.pos_sorted[1], t0 - FT, a.bucket_ptr[1][step - 1], a.bucket_ptr[1][step],
+                              mp_w[1], hw, lane);
+            m_partials_c8(bufX, a.weff[0], a.pos_sorted[0], t0, a.bucket_ptr[0][step], a.bucket_ptr[0][step + 1], mp_w[0], hw, lane);
+            uint4 carry = make_uint4(0, 0, 0, 0);
+            const int cr = ht >> 5, cc = ht & 31;        // 5 rows x 32 chunks of 16 B (the three planes = 512 B)
+            if (ht < CARRY * 32) carry = *reinterpret_cast<const uint4*>(bufX + (FT + cr) * ROWB + cc * 16);
+            GNN_TICK(8)
+            __syncthreads();                                                     // ---- B1
+            if (ht < CARRY * 32) *reinterpret_cast<uint4*>(bufX + cr * ROWB + cc * 16) = carry;
+            if (step + 1 < FSTEPS) conv1_gather<0, GNN_GATHER_EARLY, StoreF16C8>(bufX, toks, a.conv1_k, a.conv1_b, t0 + FT, ht);
+            __syncthreads();                                                     // ---- B2
+            if constexpr (PROF) tick_ = __builtin_readcyclecounter();
+            if (step + 1 < FSTEPS) conv1_gather<GNN_GATHER_EARLY, FT / 8, StoreF16C8>(bufX, toks, a.conv1_k, a.conv1_b, t0 + FT, ht);
+            if (ht < CARRY * 32) carry = *reinterpret_cast<const uint4*>(bufY + (FT + cr) * ROWB + cc * 16);
+            GNN_TICK(9)
+            __syncthreads();                                                     // ---- B3
+            if (ht < CARRY * 32) *reinterpret_cast<uint4*>(bufY + cr * ROWB + cc * 16) = carry;
+            __syncthreads();                                                     // ---- B4
+            if constexpr (PROF) tick_ = __builtin_readcyclecounter();
+        }
+    }
+    if (helper)
+        m_partials_c8(bufY, a.weff[1], a.pos_sorted[1], (FSTEPS - 1) * FT, a.bucket_ptr[1][FSTEPS - 1], a.bucket_ptr[1][FSTEPS],
+                      mp_w[1], hw, lane);
+    if constexpr (PROF) {
+        if (tid == 0)
+            for (int i = 0; i < 8; ++i) atomicAdd(a.cycles + i, cyc[i]);
+        if (tid == 256)
+            for (int i = 8; i < 10; ++i) atomicAdd(a.cycles + i, cyc[i]);
+    }
+}
+
+// ---------------------------------------------------------------------------------- host side
+// e4m3fn (OCP) encode, round to nearest even, saturating at 448 (matches v_cvt_pk_fp8_f32 below 464)
+static uint8_t e4m3_encode(double x) {
+    const uint8_t s = std::signbit(x) ? 0x80 : 0;
+    const double a = std::fabs(x);
+    if (!(a < 448.0)) return s | 0x7E;
+    if (a == 0) return s;
+    int e;
+    std::frexp(a, &e);
+    int E = std::max(e - 1, -6);
+    double r = std::nearbyint(a / std::ldexp(1.0, E - 3)) * std::ldexp(1.0, E - 3);
+    if (r >= 448.0) return s | 0x7E;
+    if (r == 0) return s;
+    std::frexp(r, &e);
+    E = e - 1;
+    if (E < -6) return s | (uint8_t)std::lround(r / std::ldexp(1.0, -9));
+    return s | (uint8_t)(((E + 7) << 3) | (int)std::lround((r / std::ldexp(1.0, E) - 1.0) * 8.0));
+}
+
+// power-of-two block scale: the smallest exponent e with amax / 2^e <= 448 (nothing saturates), biased E8M0
+static int mx_exponent(double amax) {
+    if (!(amax > 0)) return 0;
+    int e = (int)std::ceil(std::log2(amax / 448.0));
+    while (amax / std::ldexp(1.0, e) > 448.0) ++e;
+    while (e > -126 && amax / std::ldexp(1.0, e - 1) <= 448.0) --e;
+    return std::min(std::max(e, -126), 127);
+}
+
+// Wmat (K x N row major; K, N multiples of 32) -> the FusedArgsC8 weight stream and scale words.
+static void pack_c8(const float* wmat, int K, int N, std::vector<uint32_t>& frags, std::vector<uint32_t>& scales) {
+    const int nk32 = K / 32, nblks = N / 32, ntaps = (nk32 + 3) / 4;
+    frags.assign((size_t)nk32 * nblks * 4 * 64 * 4, 0);
+    scales.assign((size_t)ntaps * nblks * 64, 0x7F7F7F7Fu);
+    std::vector<uint16_t> h16((size_t)K * N);
+    std::vector<double> lo((size_t)K * N);
+    for (size_t i = 0; i < (size_t)K * N; ++i) {
+        const _Float16 h = (_Float16)wmat[i];          // RNE
+        std::memcpy(&h16[i], &h, 2);
+        lo[i] = (double)wmat[i] - (double)(float)h;
+    }
+    for (int ks = 0; ks < nk32; ++ks)
+        for (int nb = 0; nb < nblks; ++nb) {
+            uint32_t* base = &frags[((size_t)ks * nblks + nb) * 4 * 64 * 4];
+            uint8_t* bytes = reinterpret_cast<uint8_t*>(base);
+            for (int l = 0; l < 64; ++l) {
+                const int n = nb * 32 + (l & 31), half = l >> 5;
+                for (int s = 0; s < 2; ++s)             // f16 fragments: k = ks*32 + s*16 + half*8 + e
+                    for (int e = 0; e < 8; ++e) {
+                        const int k = ks * 32 + s * 16 + half * 8 + e;
+                        std::memcpy(bytes + (size_t)s * 1024 + l * 16 + e * 2, &h16[(size_t)k * N + n], 2);
+                    }
+                double amax_lo = 0, amax_w = 0;         // MX block = the 32 k of this step, column n
+                for (int k = ks * 32; k < ks * 32 + 32; ++k) {
+                    amax_lo = std::max(amax_lo, std::fabs(lo[(size_t)k * N + n]));
+                    amax_w = std::max(amax_w, std::fabs((double)wmat[(size_t)k * N + n]));
+                }
+                const int e_lo = mx_exponent(amax_lo), e_w = mx_exponent(amax_w);
+                for (int i = 0; i < 16; ++i) {          // bytes 0-15: K block 0, bytes 16-31: K block 1
+                    const int k = ks * 32 + half * 16 + i;
+                    bytes[2048 + l * 16 + i] = e4m3_encode(lo[(size_t)k * N + n] / std::ldexp(1.0, e_lo));
+                    bytes[3072 + l * 16 + i] = e4m3_encode((double)wmat[(size_t)k * N + n] / std::ldexp(1.0, e_w));
+                }
+                // lanes 0-31 carry the scale of K block 0, lanes 32-63 that of K block 1
+                uint8_t* sc = reinterpret_cast<uint8_t*>(&scales[((size_t)(ks >> 2) * nblks + nb) * 64 + l]);
+                sc[ks & 3] = (uint8_t)((half == 0 ? e_lo : e_w) + 127);
+            }
+        }
+}
+
+template <typename Tp>
+static int upload_vec_c8(gnn_ctx* ctx, const std::vector<Tp>& v, Tp** dev) {
+    void* p = nullptr;
+    GNN_HIP(hipMalloc(&p, v.size() * sizeof(Tp)));
+    ctx->owned.push_back(p);
+    GNN_HIP(hipMemcpy(p, v.data(), v.size() * sizeof(Tp), hipMemcpyHostToDevice));
+    *dev = static_cast<Tp*>(p);
+    return GNN_OK;
+}
+
+int pack_fused_c8_weights(gnn_ctx* ctx, const gnn_weights* w) {
+    DeviceWeights& d = ctx->w;
+    const float* ck[2] = {w->conv2_kernel, w->conv3_kernel};
+    const gnn_igloo_weights* ig[2] = {&w->igloo_a, &w->igloo_b};
+    std::vector<uint32_t> f, s;
+    int rc;
+    for (int i = 0; i < 2; ++i) {
+        pack_c8(ck[i], KS * C, C, f, s);
+        if ((rc = upload_vec_c8(ctx, f, &d.conv_c8[i]))) return rc;
+        if ((rc = upload_vec_c8(ctx, s, &d.conv_c8s[i]))) return rc;
+        pack_c8(ig[i]->w_v, C, C, f, s);
+        if ((rc = upload_vec_c8(ctx, f, &d.wv_c8[i]))) return rc;
+        if ((rc = upload_vec_c8(ctx, s, &d.wv_c8s[i]))) return rc;
+    }
+    return GNN_OK;
+}
+
+int launch_front_c8(gnn_ctx* ctx, const uint8_t* bases, int64_t n) {
+    const DeviceWeights& d = ctx->w;
+    FusedArgsC8 a;
+    a.bases = bases;
+    a.conv1_k = d.conv1_pairs;
+    a.conv1_b = d.conv1_b;
+    for (int i = 0; i < 2; ++i) {
+        a.conv_w[i] = reinterpret_cast<const uint4*>(d.conv_c8[i]);
+        a.conv_s[i] = d.conv_c8s[i];
+        a.conv_b[i] = d.conv_b[i];
+        a.wv_w[i] = reinterpret_cast<const uint4*>(d.wv_c8[i]);
+        a.wv_s[i] = d.wv_c8s[i];
+        a.weff[i] = d.weff_sorted[i];
+        a.pos_sorted[i] = d.pos_sorted[i];
+        a.bucket_ptr[i] = d.bucket_ptr[i];
+    }
+    a.mp = ctx->ws.mp;
+    a.yp = ctx->ws.yp;
+    a.cycles = ctx->phase_cycles;
+    if (ctx->phase_cycles) hipLaunchKernelGGL((fused_front_c8_kernel<true>), dim3((unsigned)n), dim3(512), 0, ctx->stream, a);
+    else hipLaunchKernelGGL((fused_front_c8_kernel<false>), dim3((unsigned)n), dim3(512), 0, ctx->stream, a);
+    GNN_HIP(hipGetLastError());
+    return GNN_OK;
+}
+
+}  // namespace gnn

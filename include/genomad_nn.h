@@ -51,8 +51,12 @@ typedef enum gnn_status {
 typedef enum gnn_precision {
     GNN_PREC_F32 = 0,        /* f32 reference path: unfused f32 kernels, activations in HBM   */
     GNN_PREC_BF16X3 = 1,     /* fused path: split-bf16 (hi+lo), 3 MFMA passes, f32 accumulate */
-    GNN_PREC_BF16 = 2        /* fused path: single bf16 MFMA pass (fails the 1e-4 tolerance;
+    GNN_PREC_BF16 = 2,       /* fused path: single bf16 MFMA pass (fails the 1e-4 tolerance;
                                 for roofline experiments only)                                */
+    GNN_PREC_F16C8 = 3       /* fused path: one f16 MFMA pass + MX-scaled fp8 (e4m3) MFMA corrections of
+                                both operands' f16 rounding residuals = 2.0 pass equivalents; inside the
+                                1e-4 tolerance (profiles/r02_precision_study.json); needs |activation| <
+                                65504 (f16 range)                                                 */
 } gnn_precision;
 
 typedef enum gnn_onehot_dtype { GNN_OH_U8 = 0, GNN_OH_BF16 = 1, GNN_OH_F32 = 2 } gnn_onehot_dtype;

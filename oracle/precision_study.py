@@ -1,0 +1,297 @@
+"""Precision study: which MFMA operand formats keep the class scores within 1e-4 of the reference.
+
+TEST INFRASTRUCTURE ONLY — see oracle/__init__.py.  numpy emulation (no GPU):
+
+    python -m oracle.precision_study [--windows 48] [--seeds 42 43] [--out profiles/r02_precision_study.json]
+
+The fused kernel (genomad_amd/csrc/gnn_fused.hip) evaluates four contractions per window on the matrix
+pipe — conv2, conv3 (igloo.py:66: K = 6·128, N = 128) and y @ w_v of both IGLOO heads (igloo.py:208:
+K = 128) — with f32 accumulation.  Each operand is an f32 value that has to be fed to the MFMA as one
+or more low-precision "limbs".  This script re-runs the oracle forward pass with those four
+contractions replaced by an emulation of a limb scheme (operands rounded exactly as the hardware
+formats round, products and sums in float64 so that only the operand formats are measured), and
+reports max |Δscore| against the fp64 oracle over the first ``--windows`` synthetic windows, for
+every weight seed given.  Everything else (conv1 gather, pair products, softmax, dense head) stays f64,
+except that the IGLOO pair products read the activations as the scheme stores them in LDS.
+
+Cost model ("passes"): one v_mfma_f32_32x32x16_{bf16,f16} pass over the K range = 1.0; i8 MFMA = 0.5;
+MX-scaled fp8 (v_mfma_scale_f32_32x32x64_f8f6f4, e4m3/e5m2) = 0.5; MX fp6/fp4 = 0.25
+(/opt/skills/guides/MI355X_MICROARCH.md "Matrix cores": 2382 / 4404 / 4686 / 8939 / 9099 TFLOP/s measured).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+from genomad_amd import synthetic  # noqa: E402
+from oracle import igloo_oracle as IO  # noqa: E402
+from oracle import sequence_oracle  # noqa: E402
+
+# ------------------------------------------------------------------ hardware number formats (RNE)
+FORMATS = {                      # explicit mantissa bits, min normal exponent, largest finite value
+    "bf16": (7, -126, 3.3895313892515355e38),
+    "fp16": (10, -14, 65504.0),
+    "e4m3": (3, -6, 448.0),      # OCP e4m3fn (gfx950: not MI300's fnuz)
+    "e5m2": (2, -14, 57344.0),
+    "e2m3": (3, 0, 7.5),         # MX fp6
+    "e3m2": (2, -2, 28.0),       # MX bf6
+    "e2m1": (1, 0, 6.0),         # MX fp4
+}
+EMAX = {"e4m3": 8, "e5m2": 15, "e2m3": 2, "e3m2": 4, "e2m1": 2}
+
+
+def rnd(x, fmt):
+    """Round to ``fmt``: round-to-nearest-even, gradual underflow, saturating."""
+    mant, emin, vmax = FORMATS[fmt]
+    x = np.asarray(x, dtype=np.float64)
+    ax = np.abs(x)
+    e = np.floor(np.log2(np.where(ax > 0, ax, 1.0)))
+    e = np.maximum(e, emin)
+    q = np.exp2(e - mant)
+    return np.clip(np.rint(x / q) * q, -vmax, vmax)
+
+
+def rnd_mx(x, fmt, axis, block=32):
+    """OCP MX block format: ``block`` consecutive elements along ``axis`` share a power-of-two scale
+    2^(floor(log2(max|x|)) - emax_elem); elements are rounded to ``fmt`` after scaling (saturating)."""
+    x = np.moveaxis(np.asarray(x, dtype=np.float64), axis, -1)
+    shp = x.shape
+    xb = x.reshape(shp[:-1] + (shp[-1] // block, block))
+    amax = np.abs(xb).max(axis=-1, keepdims=True)
+    se = np.floor(np.log2(np.where(amax > 0, amax, 1.0))) - EMAX[fmt]
+    se = np.clip(se, -127, 127)
+    s = np.exp2(se)
+    out = (rnd(xb / s, fmt) * s).reshape(shp)
+    return np.moveaxis(out, -1, axis)
+
+
+def limbs(x, fmts):
+    """x ≈ sum of limbs, limb i = round_{fmts[i]}(x - previous limbs)."""
+    out, r = [], np.asarray(x, dtype=np.float64)
+    for f in fmts:
+        l = rnd(r, f)
+        out.append(l)
+        r = r - l
+    return out
+
+
+def int_limbs(x, n, axis_scale):
+    """Fixed point on the i8 MFMA: x / s rounded to an integer of n balanced 7-bit digits (s chosen so
+    that max|x| over ``axis_scale`` maps to 127·2^(7(n-1)), i.e. the top digit fits int8).  Returns the
+    digits already multiplied by their weights, so that they sum to the rounded value."""
+    x = np.asarray(x, dtype=np.float64)
+    amax = np.abs(x).max(axis=axis_scale, keepdims=True)
+    s = np.where(amax > 0, amax, 1.0) / (127.0 * 2.0 ** (7 * (n - 1)))
+    q = np.rint(x / s)
+    out = []
+    for i in range(n):
+        w = 2.0 ** (7 * (n - 1 - i))
+        d = np.rint(q / w)
+        out.append(d * w * s)
+        q = q - d * w
+    return out
+
+
+# ------------------------------------------------------------------ limb schemes
+# A scheme turns (x rows, w matrix) into a list of (x_limb, w_limb) products to be summed, and says
+# how the activations are stored (what the pair-product path reads back).
+class Scheme:
+    def __init__(self, name, cost, xsplit, wsplit, terms, note=""):
+        self.name, self.cost, self.xsplit, self.wsplit, self.terms, self.note = name, cost, xsplit, wsplit, terms, note
+
+
+def _float_scheme(name, fmt, terms, cost, note=""):
+    return Scheme(name, cost, lambda x: limbs(x, [fmt, fmt]), lambda w: limbs(w, [fmt, fmt]), terms, note)
+
+
+def _corr_x(lo_fmt, mx):
+    """activations: [fp16 hi, fp8/fp6 image of x, fp8/fp6 image of the fp16 residual]"""
+    def f(x):
+        hi = rnd(x, "fp16")
+        if mx:      # block-scaled along channels (32 consecutive channels of one row = one MFMA K block)
+            return [hi, rnd_mx(x, lo_fmt, axis=-1), rnd_mx(x - hi, lo_fmt, axis=-1)]
+        # e4m3 with uniform hardware scales: x as is (range 2^-9 .. 448), residual scaled by 2^11
+        return [hi, rnd(x, lo_fmt), rnd((x - hi) * 2048.0, lo_fmt) / 2048.0]
+    return f
+
+
+def _corr_w(lo_fmt):
+    """weights (static): [fp16 hi, MX image of w, MX image of the fp16 residual], blocks along K"""
+    def f(w):
+        hi = rnd(w, "fp16")
+        return [hi, rnd_mx(w, lo_fmt, axis=0), rnd_mx(w - hi, lo_fmt, axis=0)]
+    return f
+
+
+HH, HL, LH, LL = (0, 0), (0, 1), (1, 0), (1, 1)
+SCHEMES = [
+    Scheme("f32 (exact operands)", 16.0, lambda x: [x], lambda w: [w], [HH]),
+    _float_scheme("bf16x1", "bf16", [HH], 1.0),
+    _float_scheme("bf16x2 (hh+lh: x 2 limbs, w 1)", "bf16", [HH, LH], 2.0),
+    _float_scheme("bf16x2 (hh+hl: x 1 limb, w 2)", "bf16", [HH, HL], 2.0),
+    _float_scheme("bf16x3 (round 1)", "bf16", [HH, HL, LH], 3.0),
+    _float_scheme("fp16x1", "fp16", [HH], 1.0),
+    _float_scheme("fp16x2 (hh+lh: x 2 limbs, w 1)", "fp16", [HH, LH], 2.0),
+    _float_scheme("fp16x2 (hh+hl: x 1 limb, w 2)", "fp16", [HH, HL], 2.0),
+    _float_scheme("fp16x3", "fp16", [HH, HL, LH], 3.0),
+    Scheme("fp16 + e4m3 corrections (x8*wl8 + xl8*w8)", 2.0, _corr_x("e4m3", False), _corr_w("e4m3"),
+           [(0, 0), (1, 2), (2, 1)], "MX fp8 MFMA, K-concatenated: one 32x32x64 per 32 channels"),
+    Scheme("fp16 + e5m2 corrections", 2.0, _corr_x("e5m2", False), _corr_w("e5m2"), [(0, 0), (1, 2), (2, 1)]),
+    Scheme("fp16 + e2m3 (fp6, MX both sides) corrections", 1.5, _corr_x("e2m3", True), _corr_w("e2m3"),
+           [(0, 0), (1, 2), (2, 1)]),
+    Scheme("fp16 + e3m2 (bf6, MX both sides) corrections", 1.5, _corr_x("e3m2", True), _corr_w("e3m2"),
+           [(0, 0), (1, 2), (2, 1)]),
+    Scheme("fp16 + e2m1 (fp4, MX both sides) corrections", 1.5, _corr_x("e2m1", True), _corr_w("e2m1"),
+           [(0, 0), (1, 2), (2, 1)]),
+    Scheme("fp16 + e4m3 correction of x only (xl8*w8)", 1.5, _corr_x("e4m3", False), _corr_w("e4m3"),
+           [(0, 0), (2, 1)], "w single fp16"),
+    Scheme("fp16 + e4m3 correction of w only (x8*wl8)", 1.5, _corr_x("e4m3", False), _corr_w("e4m3"),
+           [(0, 0), (1, 2)], "x single fp16"),
+    Scheme("bf16 + e4m3 corrections", 2.0,
+           lambda x: [rnd(x, "bf16"), rnd(x, "e4m3"), rnd((x - rnd(x, "bf16")) * 256.0, "e4m3") / 256.0],
+           lambda w: [rnd(w, "bf16"), rnd_mx(w, "e4m3", 0), rnd_mx(w - rnd(w, "bf16"), "e4m3", 0)],
+           [(0, 0), (1, 2), (2, 1)]),
+    # fixed point on the i8 MFMA: x scaled per window-step tile is not emulated here; per-row scale for x
+    # (optimistic: the accumulator cannot mix row scales across conv taps) and per-column scale for w
+    Scheme("int8 limbs x2/w2, 3 products (optimistic per-row x scale)", 1.5,
+           lambda x: int_limbs(x, 2, -1), lambda w: int_limbs(w, 2, 0), [HH, HL, LH]),
+    Scheme("int8 limbs x3/w2, 5 products (optimistic per-row x scale)", 2.5,
+           lambda x: int_limbs(x, 3, -1), lambda w: int_limbs(w, 2, 0), [(0, 0), (0, 1), (1, 0), (1, 1), (2, 0)]),
+    Scheme("int8 limbs x3/w3, 6 products (optimistic per-row x scale)", 3.0,
+           lambda x: int_limbs(x, 3, -1), lambda w: int_limbs(w, 3, 0),
+           [(0, 0), (0, 1), (1, 0), (1, 1), (2, 0), (0, 2)]),
+]
+BY_NAME = {s.name: s for s in SCHEMES}
+EXACT = SCHEMES[0]
+
+
+def contract(xl, wl, terms, taps):
+    """sum over limb products of the causal conv (taps=6) or the plain product (taps=1); xl: limbs of
+    x (B,T,C), wl: limbs of w (taps*C, N)."""
+    out = 0.0
+    B, T, C = xl[0].shape
+    for (i, j) in terms:
+        x, w = xl[i], wl[j]
+        if taps == 1:
+            out = out + x @ w
+        else:
+            xp = np.concatenate([np.zeros((B, taps - 1, C)), x], axis=1)
+            acc = 0.0
+            for k in range(taps):
+                acc = acc + xp[:, k:k + T] @ w[k * C:(k + 1) * C]
+            out = out + acc
+    return out
+
+
+def forward(tokens, W, layer_scheme):
+    """fp64 forward with the four matrix-pipe contractions emulated; ``layer_scheme`` maps
+    conv2 / conv3 / wvA / wvB to a Scheme."""
+    w = {k: (np.asarray(v, dtype=np.float64) if np.asarray(v).dtype.kind == "f" else np.asarray(v))
+         for k, v in W.items()}
+    f32 = lambda a: a.astype(np.float32).astype(np.float64)   # noqa: E731  activations are f32 before the split
+    x1 = f32(IO._lrelu(IO.conv1_gather(tokens, w["conv1_kernel"], w["conv1_bias"])))
+
+    def stored(x, sch):            # what the LDS holds = what the pair products read back
+        l = sch.xsplit(x)
+        if len(l) == 1:
+            return l[0]
+        if len(l) == 2:
+            return l[0] + l[1]
+        return l[0] + l[2]         # fp16 hi + low-precision residual image
+
+    def conv(x, name, sch):
+        xl, wl = sch.xsplit(x), sch.wsplit(w[f"{name}_kernel"].reshape(6 * 128, 128))
+        return f32(IO._lrelu(contract(xl, wl, sch.terms, 6) + w[f"{name}_bias"]))
+
+    def head(x, hname, sch_v, sch_store):
+        P = w[f"{hname}_patches"]
+        weff = w[f"{hname}_w_mult"][0] * w[f"{hname}_w_summer"][0, :, 0].reshape(4, 128)[None]
+        xs = stored(x, sch_store)
+        m = np.einsum("bpjc,pjc->bp", xs[:, P[:, :, 0], :], weff) + w[f"{hname}_w_bias"]
+        alpha = IO._softmax(m @ w[f"{hname}_w_qk"])
+        yp = contract(sch_v.xsplit(x), sch_v.wsplit(w[f"{hname}_w_v"][0]), sch_v.terms, 1)
+        Tp = x.shape[1] // 8
+        yp = f32(yp[:, :Tp * 8].reshape(x.shape[0], Tp, 8, 128).max(axis=2))
+        return np.einsum("bq,bqc->bc", alpha, yp)
+
+    x2 = conv(x1, "conv2", layer_scheme["conv2"])
+    x3 = conv(x2, "conv3", layer_scheme["conv3"])
+    # x1 is stored once: the scheme of its first consumer on the matrix pipe decides its LDS format
+    fA = head(x1, "iglooA", layer_scheme["wvA"], layer_scheme["conv2"])
+    fB = head(x3, "iglooB", layer_scheme["wvB"], layer_scheme["wvB"])
+    f = np.concatenate([fA, fB], axis=-1)
+    h1 = np.maximum(IO._bn(f @ w["enc_dense_kernel"] + w["enc_dense_bias"], w["enc_bn_gamma"], w["enc_bn_beta"],
+                           w["enc_bn_mean"], w["enc_bn_var"]), 0)
+    h2 = np.maximum(IO._bn(h1 @ w["head_dense_kernel"] + w["head_dense_bias"], w["head_bn_gamma"], w["head_bn_beta"],
+                           w["head_bn_mean"], w["head_bn_var"]), 0)
+    return IO._softmax(h2 @ w["out_dense_kernel"] + w["out_dense_bias"])
+
+
+def run(n_windows, seeds, names, per_layer, batch=8):
+    bases = synthetic.synth_windows(0, n_windows)
+    tokens = sequence_oracle.tokenize_closed_form(bases)
+    layers = ("conv2", "conv3", "wvA", "wvB")
+    rows = []
+    for seed in seeds:
+        W = synthetic.synth_weights(seed)
+        truth = np.concatenate([IO.forward(tokens[a:a + batch], W, dtype=np.float64, literal=False)
+                                for a in range(0, n_windows, batch)])
+        f32 = np.concatenate([IO.forward(tokens[a:a + batch], W, dtype=np.float32, literal=False)
+                              for a in range(0, n_windows, batch)])
+        print(f"seed {seed}: fp32 oracle vs fp64 oracle {np.abs(f32 - truth).max():.2e} "
+              f"(the f32-accumulation floor every scheme sits on)", flush=True)
+        rows.append({"seed": seed, "scheme": "fp32 oracle (f32 everywhere)", "cost": None,
+                     "max_abs_dscore": float(np.abs(f32 - truth).max())})
+
+        def measure(label, ls, cost):
+            t = time.time()
+            got = np.concatenate([forward(tokens[a:a + batch], W, ls) for a in range(0, n_windows, batch)])
+            err = float(np.abs(got - truth).max())
+            rows.append({"seed": seed, "scheme": label, "cost": cost, "max_abs_dscore": err})
+            print(f"seed {seed}: {label:75s} cost {cost:5.2f}  max|dscore| {err:.2e}  ({time.time() - t:.0f} s)", flush=True)
+
+        for name in names:
+            s = BY_NAME[name]
+            measure(s.name, {l: s for l in layers}, s.cost)
+        # per-layer mixes: `base` everywhere, one layer (or both w_v) replaced by `alt`
+        for base, alt in per_layer:
+            b, a = BY_NAME[base], BY_NAME[alt]
+            share = {"conv2": 0.427, "conv3": 0.427, "wvA": 0.071, "wvB": 0.071}
+            for group in (("conv2",), ("conv3",), ("wvA", "wvB"), ("conv2", "conv3")):
+                ls = {l: (a if l in group else b) for l in layers}
+                cost = sum(share[l] * ls[l].cost for l in layers) / sum(share.values())
+                measure(f"{b.name}, but {'+'.join(group)}: {a.name}", ls, cost)
+    return rows
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--windows", type=int, default=48)
+    ap.add_argument("--seeds", type=int, nargs="+", default=[42, 43])
+    ap.add_argument("--quick", action="store_true", help="only the headline schemes")
+    ap.add_argument("--out", default=os.path.join(ROOT, "profiles", "r02_precision_study.json"))
+    args = ap.parse_args()
+    names = [s.name for s in SCHEMES]
+    per_layer = [("fp16x3", "fp16x1"), ("fp16x3", "fp16x2 (hh+lh: x 2 limbs, w 1)"),
+                 ("fp16 + e4m3 corrections (x8*wl8 + xl8*w8)", "fp16x3"),
+                 ("fp16 + e2m3 (fp6, MX both sides) corrections", "fp16 + e4m3 corrections (x8*wl8 + xl8*w8)")]
+    if args.quick:
+        names = [n for n in names if n.startswith(("bf16x3", "fp16x3", "fp16 + e4m3 corrections", "fp16 + e2m3"))]
+        per_layer = []
+    rows = run(args.windows, args.seeds, names, per_layer)
+    with open(args.out, "w") as f:
+        json.dump({"windows": args.windows, "tolerance": 1e-4,
+                   "note": "max |dscore| vs the fp64 oracle; operands rounded like the hardware formats, products "
+                           "and accumulation in f64 (the f32-accumulation floor is the 'fp32 oracle' row)",
+                   "rows": rows}, f, indent=1)
+    print("wrote", args.out)
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,430 @@
+// Hardware probe for the gfx950 low-precision conversion and MX-scaled MFMA instructions the fused
+// kernel's "fp16 + fp8 corrections" scheme relies on (measurement aid, not on the hot path).
+//   hipcc --offload-arch=gfx950 -O2 scripts/probe_mx.hip -o build_variants/probe_mx && build_variants/probe_mx
+// Reports (stdout, one line per finding):
+//   * v_cvt_pk_fp8_f32: rounding, saturation / NaN above 448, subnormals
+//   * v_cvt_scalef32_pk_fp8_f32: direction of the scale (x / s or x * s)
+//   * v_cvt_scalef32_2xpk16_fp6_f32, v_cvt_scalef32_pk32_fp6_f16: element order and scale direction
+//   * v_mfma_scale_f32_32x32x64_f8f6f4 (fp8 and fp6 operands): operand layout hypothesis
+//     "lane l = row l&31, K block l>>5, 32 consecutive elements, one E8M0 scale per lane", OPSEL
+//   * sustained rates of the f16, MX-fp8, MX-fp6 MFMAs and of the 8 f16 + 4 fp8 mix of one k32 step
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <vector>
+
+typedef int v8i __attribute__((ext_vector_type(8)));
+typedef int v6i __attribute__((ext_vector_type(6)));
+typedef float v16f __attribute__((ext_vector_type(16)));
+typedef _Float16 v32h __attribute__((ext_vector_type(32)));
+typedef _Float16 v8h __attribute__((ext_vector_type(8)));
+typedef short v2s __attribute__((ext_vector_type(2)));
+
+#define CK(x)                                                                      \
+    do {                                                                           \
+        hipError_t e_ = (x);                                                       \
+        if (e_ != hipSuccess) {                                                    \
+            printf("HIP error %s at %s:%d\n", hipGetErrorString(e_), __FILE__, __LINE__); \
+            return 1;                                                              \
+        }                                                                          \
+    } while (0)
+
+// ---------------------------------------------------------------- host models of the formats
+static double e4m3_decode(uint8_t b) {
+    const int s = b >> 7, e = (b >> 3) & 15, m = b & 7;
+    if (e == 15 && m == 7) return NAN;
+    const double v = e == 0 ? m / 8.0 * std::ldexp(1.0, -6) : (1 + m / 8.0) * std::ldexp(1.0, e - 7);
+    return s ? -v : v;
+}
+static uint8_t e4m3_encode(double x) {   // RNE, saturating
+    const uint8_t s = std::signbit(x) ? 0x80 : 0;
+    double a = std::fabs(x);
+    if (a >= 448.0) return s | 0x7E;
+    int e;
+    std::frexp(a, &e);                    // a = f * 2^e, f in [0.5, 1)
+    int E = e - 1;
+    if (E < -6) E = -6;
+    const double q = std::ldexp(1.0, E - 3);
+    double r = std::nearbyint(a / q) * q;
+    if (r >= 448.0) return s | 0x7E;
+    if (r == 0) return s;
+    std::frexp(r, &e);
+    E = e - 1;
+    if (E < -6) return s | (uint8_t)std::lround(r / std::ldexp(1.0, -9));
+    const int m = (int)std::lround((r / std::ldexp(1.0, E) - 1.0) * 8.0);
+    return s | (uint8_t)(((E + 7) << 3) | m);
+}
+static double e2m3_decode(uint32_t c) {
+    const int s = (c >> 5) & 1, e = (c >> 3) & 3, m = c & 7;
+    const double v = e == 0 ? m / 8.0 : (1 + m / 8.0) * std::ldexp(1.0, e - 1);
+    return s ? -v : v;
+}
+static uint32_t e2m3_encode(double x) {
+    const uint32_t s = std::signbit(x) ? 32 : 0;
+    const double a = std::fabs(x);
+    uint32_t best = 0;
+    double bd = 1e30;
+    for (uint32_t c = 0; c < 32; ++c) {
+        const double d = std::fabs(e2m3_decode(c) - a);
+        if (d < bd || (d == bd && !(c & 1))) bd = d, best = c;
+    }
+    return s | best;
+}
+static uint32_t get6(const uint32_t* w, int i) {
+    const int bit = i * 6, k = bit >> 5, o = bit & 31;
+    uint64_t v = w[k];
+    if (k + 1 < 6) v |= (uint64_t)w[k + 1] << 32;
+    return (uint32_t)(v >> o) & 63;
+}
+static void put6(uint32_t* w, int i, uint32_t c) {
+    const int bit = i * 6, k = bit >> 5, o = bit & 31;
+    w[k] |= c << o;
+    if (o > 26 && k + 1 < 6) w[k + 1] |= c >> (32 - o);
+}
+
+// ---------------------------------------------------------------- conversion probes
+__global__ void cvt_kernel(const float* in, int n, float s0, uint32_t* out8, uint32_t* out8s, uint32_t* out6a,
+                           uint32_t* out6b, uint32_t* outh) {
+    const int i = threadIdx.x;
+    if (i < n / 2) {
+        out8[i] = (uint32_t)__builtin_amdgcn_cvt_pk_fp8_f32(in[2 * i], in[2 * i + 1], 0, false);
+        v2s o = {0, 0};
+        o = __builtin_amdgcn_cvt_scalef32_pk_fp8_f32(o, in[2 * i], in[2 * i + 1], s0, false);
+        out8s[i] = (uint32_t)__builtin_bit_cast(int, o);
+    }
+    if (i == 0) {
+        v16f x, y;
+        v32h h;
+        for (int k = 0; k < 16; ++k) x[k] = in[k], y[k] = in[16 + k];
+        for (int k = 0; k < 32; ++k) h[k] = (_Float16)in[k];
+        const v6i a = __builtin_amdgcn_cvt_scalef32_2xpk16_fp6_f32(x, y, s0);
+        const v6i b = __builtin_amdgcn_cvt_scalef32_pk32_fp6_f16(h, s0);
+        for (int k = 0; k < 6; ++k) out6a[k] = a[k], out6b[k] = b[k];
+    }
+    (void)outh;
+}
+
+// ---------------------------------------------------------------- MFMA layout probes
+template <int FMT, int OPA, int OPB>
+__global__ void mfma_kernel(const uint32_t* A, const uint32_t* B, const uint32_t* sa, const uint32_t* sb, float* D) {
+    const int l = threadIdx.x;
+    v8i a, b;
+    for (int i = 0; i < 8; ++i) a[i] = A[l * 8 + i], b[i] = B[l * 8 + i];
+    v16f c = {};
+    c = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a, b, c, FMT, FMT, OPA, (int)sa[l], OPB, (int)sb[l]);
+    for (int i = 0; i < 16; ++i) D[l * 16 + i] = c[i];
+}
+
+// ---------------------------------------------------------------- rate probes
+template <int MODE>   // 0: f16 32x32x16   1: MX fp8 32x32x64   2: MX fp6   3: 8 f16 + 4 fp8 (one k32 step of the kernel)
+__global__ __launch_bounds__(512) void rate_kernel(const uint32_t* ops, int iters, float* sink, unsigned long long* cyc) {
+    const int lane = threadIdx.x & 63;
+    v8i a[4], b[4];
+    for (int i = 0; i < 4; ++i)
+        for (int k = 0; k < 8; ++k) a[i][k] = ops[(i * 2) * 512 + lane * 8 + k], b[i][k] = ops[(i * 2 + 1) * 512 + lane * 8 + k];
+    const int sA = (int)ops[5000 + lane], sB = (int)ops[5100 + lane];
+    v16f acc[4];
+    for (int i = 0; i < 4; ++i)
+        for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+    const unsigned long long t0 = __builtin_readcyclecounter();
+#pragma unroll 1
+    for (int it = 0; it < iters; ++it) {
+        if constexpr (MODE == 0 || MODE == 3) {
+#pragma unroll
+            for (int rep = 0; rep < (MODE == 0 ? 3 : 2); ++rep)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const v8h ah = __builtin_bit_cast(v8h, __builtin_shufflevector(a[(i + rep) & 3], a[(i + rep) & 3], 0, 1, 2, 3));
+                    const v8h bh = __builtin_bit_cast(v8h, __builtin_shufflevector(b[i], b[i], 0, 1, 2, 3));
+                    acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, acc[i], 0, 0, 0);
+                }
+        }
+        if constexpr (MODE == 1 || MODE == 3) {
+#pragma unroll
+            for (int rep = 0; rep < (MODE == 1 ? 3 : 1); ++rep)
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+                    acc[i] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a[(i + rep) & 3], b[i], acc[i], 0, 0, 0, sA, 0, sB);
+        }
+        if constexpr (MODE == 2) {
+#pragma unroll
+            for (int rep = 0; rep < 3; ++rep)
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+                    acc[i] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a[(i + rep) & 3], b[i], acc[i], 2, 2, 0, sA, 0, sB);
+        }
+    }
+    const unsigned long long t1 = __builtin_readcyclecounter();
+    float s = 0.f;
+    for (int i = 0; i < 4; ++i)
+        for (int r = 0; r < 16; ++r) s += acc[i][r];
+    if (s == 12345.678f) sink[0] = s;
+    if (blockIdx.x == 0 && threadIdx.x == 0) cyc[0] = t1 - t0;
+}
+
+template <int MODE>
+static int run_rate(const char* name, const uint32_t* dops, int threads, double flop_per_iter_wave, int mfma_per_iter) {
+    float* sink;
+    unsigned long long* cyc;
+    CK(hipMalloc(&sink, 16));
+    CK(hipMalloc(&cyc, 8));
+    hipEvent_t e0, e1;
+    CK(hipEventCreate(&e0));
+    CK(hipEventCreate(&e1));
+    const int iters = 40000;
+    for (int rep = 0; rep < 2; ++rep) {
+        CK(hipEventRecord(e0));
+        hipLaunchKernelGGL(rate_kernel<MODE>, dim3(256), dim3(threads), 0, 0, dops, iters, sink, cyc);
+        CK(hipEventRecord(e1));
+        CK(hipEventSynchronize(e1));
+    }
+    float ms;
+    CK(hipEventElapsedTime(&ms, e0, e1));
+    unsigned long long c;
+    CK(hipMemcpy(&c, cyc, 8, hipMemcpyDeviceToHost));
+    const double waves = 256.0 * threads / 64;
+    printf("RATE %-28s waves/SIMD %d: %8.1f TFLOP/s  %6.2f ms  s_memtime ticks/MFMA(wave) %.2f  -> %.1f ns per MFMA per wave\n", name, threads / 256,
+           waves * iters * flop_per_iter_wave / (ms * 1e-3) / 1e12, ms, (double)c / iters / mfma_per_iter,
+           ms * 1e6 / iters / mfma_per_iter);
+    return 0;
+}
+
+int main() {
+    int dev = 0;
+    CK(hipSetDevice(dev));
+    hipDeviceProp_t prop;
+    CK(hipGetDeviceProperties(&prop, dev));
+    printf("device %s  CUs %d  clock %d kHz\n", prop.name, prop.multiProcessorCount, prop.clockRate);
+
+    // ---- conversions
+    std::vector<float> in = {0.f,     1.f,     1.0625f, 1.1875f, 1.3125f, 447.f,    448.f,   460.f,   464.f,   480.f,  1000.f,
+                             1e6f,    -1000.f, 0.015625f, 0.0078125f, 0.001953125f, 0.0009765625f, 0.00146484375f, 0.3f, 17.3f,
+                             -0.7f,   3.3f,    5.1f,    7.4f,    7.6f,    7.9f,     0.06f,   0.12f,   0.19f,   2.1f,   2.9f,  -6.5f};
+    const int n = (int)in.size();   // 32
+    float* din;
+    uint32_t *d8, *d8s, *d6a, *d6b, *dh;
+    CK(hipMalloc(&din, 256 * 4));
+    CK(hipMalloc(&d8, 256 * 4));
+    CK(hipMalloc(&d8s, 256 * 4));
+    CK(hipMalloc(&d6a, 64));
+    CK(hipMalloc(&d6b, 64));
+    CK(hipMalloc(&dh, 256 * 4));
+    CK(hipMemcpy(din, in.data(), n * 4, hipMemcpyHostToDevice));
+    for (float s0 : {1.0f, 4.0f, 0.25f}) {
+        hipLaunchKernelGGL(cvt_kernel, dim3(1), dim3(64), 0, 0, din, n, s0, d8, d8s, d6a, d6b, dh);
+        CK(hipDeviceSynchronize());
+        std::vector<uint32_t> o8(n / 2), o8s(n / 2), o6a(6), o6b(6);
+        CK(hipMemcpy(o8.data(), d8, n * 2, hipMemcpyDeviceToHost));
+        CK(hipMemcpy(o8s.data(), d8s, n * 2, hipMemcpyDeviceToHost));
+        CK(hipMemcpy(o6a.data(), d6a, 24, hipMemcpyDeviceToHost));
+        CK(hipMemcpy(o6b.data(), d6b, 24, hipMemcpyDeviceToHost));
+        if (s0 == 1.0f) {
+            int bad = 0;
+            for (int i = 0; i < n; ++i) {
+                const uint8_t got = (o8[i / 2] >> (8 * (i & 1))) & 0xFF, want = e4m3_encode(in[i]);
+                printf("CVT8 x=%-14g hw=0x%02x (%g)  model(RNE,sat)=0x%02x (%g)%s\n", in[i], got, e4m3_decode(got), want,
+                       e4m3_decode(want), got == want ? "" : "   <-- differs");
+                bad += got != want;
+            }
+            printf("CVT8 summary: %d of %d differ from the RNE saturating e4m3fn model\n", bad, n);
+        }
+        // scale direction of the scaled fp8 conversion
+        int div = 0, mul = 0;
+        for (int i = 0; i < n; ++i) {
+            if (std::fabs(in[i]) > 100 || in[i] == 0) continue;
+            const uint8_t got = (o8s[i / 2] >> (8 * (i & 1))) & 0xFF;
+            div += got == e4m3_encode(in[i] / s0);
+            mul += got == e4m3_encode(in[i] * s0);
+        }
+        printf("CVT8S scale %g: matches x/scale on %d, x*scale on %d values\n", s0, div, mul);
+        // fp6: find, for every output slot, which input it encodes (under x/scale and x*scale)
+        for (int which = 0; which < 2; ++which) {
+            const uint32_t* w = which ? o6b.data() : o6a.data();
+            printf("CVT6 %s scale %g: slot->input (d=x/s, m=x*s): ", which ? "pk32_fp6_f16" : "2xpk16_fp6_f32", s0);
+            for (int slot = 0; slot < 32; ++slot) {
+                const uint32_t c = get6(w, slot);
+                char tag = '?';
+                int src = -1;
+                for (int i = 0; i < n && src < 0; ++i) {
+                    if (c == e2m3_encode(std::fmin(std::fmax(in[i] / s0, -7.5), 7.5))) src = i, tag = 'd';
+                    else if (c == e2m3_encode(std::fmin(std::fmax(in[i] * s0, -7.5), 7.5))) src = i, tag = 'm';
+                }
+                (void)src;
+                printf("%d:%02x%c ", slot, c, tag);
+            }
+            printf("\n");
+            // direct check of the natural order hypothesis: slot i = input i
+            int okd = 0, okm = 0;
+            for (int i = 0; i < 32; ++i) {
+                okd += get6(w, i) == e2m3_encode(std::fmin(std::fmax(in[i] / s0, -7.5), 7.5));
+                okm += get6(w, i) == e2m3_encode(std::fmin(std::fmax(in[i] * s0, -7.5), 7.5));
+            }
+            printf("CVT6 %s scale %g: natural order slot i = input i matches %d/32 (x/s), %d/32 (x*s)\n",
+                   which ? "pk32_fp6_f16" : "2xpk16_fp6_f32", s0, okd, okm);
+        }
+    }
+
+    // ---- MFMA layout: D[i][j] = sum_k A[i][k] B[k][j] 2^(sa-127) 2^(sb-127)
+    std::vector<uint32_t> ops(8192, 0);
+    uint32_t rng = 12345u;
+    auto rnd = [&]() { rng = rng * 1664525u + 1013904223u; return rng >> 8; };
+    for (int fmt = 0; fmt < 2; ++fmt) {            // 0: fp8 e4m3, 1: fp6 e2m3
+        std::vector<double> Am(32 * 64), Bm(64 * 32);
+        std::vector<uint32_t> A(64 * 8, 0), B(64 * 8, 0), sa(64), sb(64);
+        for (int l = 0; l < 64; ++l) {
+            const uint32_t ea = 120 + rnd() % 12, eb = 121 + rnd() % 12;
+            // the scale byte in byte 0; bytes 1..3 hold decoys (+1, +2, +3) to detect OPSEL behaviour
+            sa[l] = ea | ((ea + 1) << 8) | ((ea + 2) << 16) | ((ea + 3) << 24);
+            sb[l] = eb | ((eb + 1) << 8) | ((eb + 2) << 16) | ((eb + 3) << 24);
+            for (int i = 0; i < 32; ++i) {
+                const int row = l & 31, k = (l >> 5) * 32 + i;
+                if (fmt == 0) {
+                    uint8_t ca = rnd() & 0xFF, cb = rnd() & 0xFF;
+                    if ((ca & 0x7F) == 0x7F) ca ^= 1;
+                    if ((cb & 0x7F) == 0x7F) cb ^= 1;
+                    ca = (ca & 0x87) | (((6 + rnd() % 4)) << 3);     // exponents 6..9: values ~0.5..7
+                    cb = (cb & 0x87) | (((6 + rnd() % 4)) << 3);
+                    A[l * 8 + i / 4] |= (uint32_t)ca << (8 * (i & 3));
+                    B[l * 8 + i / 4] |= (uint32_t)cb << (8 * (i & 3));
+                    Am[row * 64 + k] = e4m3_decode(ca);
+                    Bm[k * 32 + row] = e4m3_decode(cb);
+                } else {
+                    const uint32_t ca = rnd() & 63, cb = rnd() & 63;
+                    put6(&A[l * 8], i, ca);
+                    put6(&B[l * 8], i, cb);
+                    Am[row * 64 + k] = e2m3_decode(ca);
+                    Bm[k * 32 + row] = e2m3_decode(cb);
+                }
+            }
+        }
+        uint32_t *dA, *dB, *dsa, *dsb;
+        float* dD;
+        CK(hipMalloc(&dA, 2048));
+        CK(hipMalloc(&dB, 2048));
+        CK(hipMalloc(&dsa, 256));
+        CK(hipMalloc(&dsb, 256));
+        CK(hipMalloc(&dD, 4096));
+        CK(hipMemcpy(dA, A.data(), 2048, hipMemcpyHostToDevice));
+        CK(hipMemcpy(dB, B.data(), 2048, hipMemcpyHostToDevice));
+        CK(hipMemcpy(dsa, sa.data(), 256, hipMemcpyHostToDevice));
+        CK(hipMemcpy(dsb, sb.data(), 256, hipMemcpyHostToDevice));
+        for (int variant = 0; variant < 3; ++variant) {   // (opselA, opselB) = (0,0), (1,2), (3,3)
+            if (fmt == 0) {
+                if (variant == 0) hipLaunchKernelGGL((mfma_kernel<0, 0, 0>), dim3(1), dim3(64), 0, 0, dA, dB, dsa, dsb, dD);
+                if (variant == 1) hipLaunchKernelGGL((mfma_kernel<0, 1, 2>), dim3(1), dim3(64), 0, 0, dA, dB, dsa, dsb, dD);
+                if (variant == 2) hipLaunchKernelGGL((mfma_kernel<0, 3, 3>), dim3(1), dim3(64), 0, 0, dA, dB, dsa, dsb, dD);
+            } else {
+                if (variant == 0) hipLaunchKernelGGL((mfma_kernel<2, 0, 0>), dim3(1), dim3(64), 0, 0, dA, dB, dsa, dsb, dD);
+                if (variant == 1) hipLaunchKernelGGL((mfma_kernel<2, 1, 2>), dim3(1), dim3(64), 0, 0, dA, dB, dsa, dsb, dD);
+                if (variant == 2) hipLaunchKernelGGL((mfma_kernel<2, 3, 3>), dim3(1), dim3(64), 0, 0, dA, dB, dsa, dsb, dD);
+            }
+            CK(hipDeviceSynchronize());
+            std::vector<float> D(1024);
+            CK(hipMemcpy(D.data(), dD, 4096, hipMemcpyDeviceToHost));
+            const int opa = variant == 0 ? 0 : (variant == 1 ? 1 : 3), opb = variant == 0 ? 0 : (variant == 1 ? 2 : 3);
+            // hypotheses: the scale byte used is byte `opsel` (honoured) or byte 0 (ignored)
+            for (int hyp = 0; hyp < 2; ++hyp) {
+                double maxerr = 0, maxref = 0;
+                for (int l = 0; l < 64; ++l)
+                    for (int r = 0; r < 16; ++r) {
+                        const int j = l & 31, i = (r & 3) + 8 * (r >> 2) + 4 * (l >> 5);   // C/D layout of 32x32
+                        double ref = 0;
+                        for (int kb = 0; kb < 2; ++kb) {
+                            const int ba = hyp == 0 ? opa : 0, bb = hyp == 0 ? opb : 0;
+                            const double fa = std::ldexp(1.0, (int)((sa[kb * 32 + i] >> (8 * ba)) & 0xFF) - 127);
+                            const double fb = std::ldexp(1.0, (int)((sb[kb * 32 + j] >> (8 * bb)) & 0xFF) - 127);
+                            double s = 0;
+                            for (int k = 0; k < 32; ++k) s += Am[i * 64 + kb * 32 + k] * Bm[(kb * 32 + k) * 32 + j];
+                            ref += s * fa * fb;
+                        }
+                        maxerr = std::fmax(maxerr, std::fabs(ref - D[l * 16 + r]));
+                        maxref = std::fmax(maxref, std::fabs(ref));
+                    }
+                printf("MFMA %s opsel(%d,%d) hypothesis '%s': max|err| %.3e (max|ref| %.3e) %s\n", fmt ? "fp6" : "fp8", opa, opb,
+                       hyp == 0 ? "scale byte = opsel" : "scale byte = 0", maxerr, maxref, maxerr <= 1e-5 * maxref ? "MATCH" : "no");
+            }
+        }
+        if (fmt == 0) {
+            for (int i = 0; i < 8; ++i) {
+                memcpy(&ops[i * 512], (i & 1) ? B.data() : A.data(), 2048);
+            }
+            for (int l = 0; l < 64; ++l) ops[5000 + l] = 127, ops[5100 + l] = 127;
+        }
+    }
+
+    // ---- which operand bytes does a lane's scale govern (fp8)?  A and B use the same lane/byte -> K map, so
+    // the map itself cancels out of the dot product; only the scale blocks are observable.  Give the two
+    // lane halves different scales on one side and solve for the coefficient of every (lane half, byte
+    // octet) group of products.
+    {
+        std::vector<uint32_t> A(64 * 8, 0), B(64 * 8, 0), sa(64), sb(64);
+        std::vector<double> Af(64 * 32), Bf(64 * 32);
+        for (int l = 0; l < 64; ++l)
+            for (int i = 0; i < 32; ++i) {
+                uint8_t ca = (rnd() & 0x87) | ((6 + rnd() % 3) << 3), cb = (rnd() & 0x87) | ((6 + rnd() % 3) << 3);
+                A[l * 8 + i / 4] |= (uint32_t)ca << (8 * (i & 3));
+                B[l * 8 + i / 4] |= (uint32_t)cb << (8 * (i & 3));
+                Af[l * 32 + i] = e4m3_decode(ca);
+                Bf[l * 32 + i] = e4m3_decode(cb);
+            }
+        uint32_t *dA, *dB, *dsa, *dsb;
+        float* dD;
+        CK(hipMalloc(&dA, 2048));
+        CK(hipMalloc(&dB, 2048));
+        CK(hipMalloc(&dsa, 256));
+        CK(hipMalloc(&dsb, 256));
+        CK(hipMalloc(&dD, 4096));
+        CK(hipMemcpy(dA, A.data(), 2048, hipMemcpyHostToDevice));
+        CK(hipMemcpy(dB, B.data(), 2048, hipMemcpyHostToDevice));
+        for (int side = 0; side < 2; ++side) {
+            for (int l = 0; l < 64; ++l) {
+                sa[l] = 127 + (side == 0 && l >= 32 ? 3 : 0);
+                sb[l] = 127 + (side == 1 && l >= 32 ? 3 : 0);
+            }
+            CK(hipMemcpy(dsa, sa.data(), 256, hipMemcpyHostToDevice));
+            CK(hipMemcpy(dsb, sb.data(), 256, hipMemcpyHostToDevice));
+            hipLaunchKernelGGL((mfma_kernel<0, 0, 0>), dim3(1), dim3(64), 0, 0, dA, dB, dsa, dsb, dD);
+            CK(hipDeviceSynchronize());
+            std::vector<float> D(1024);
+            CK(hipMemcpy(D.data(), dD, 4096, hipMemcpyDeviceToHost));
+            int found = 0;
+            for (int mask = 0; mask < 256; ++mask) {      // bit (h*4+g): group (lane half h, byte octet g) scaled by 8
+                double maxerr = 0, maxref = 0;
+                for (int l = 0; l < 64 && maxerr <= 1e-4 * (maxref + 1); ++l)
+                    for (int r = 0; r < 16; ++r) {
+                        const int j = l & 31, i = (r & 3) + 8 * (r >> 2) + 4 * (l >> 5);
+                        double ref = 0;
+                        for (int h = 0; h < 2; ++h)
+                            for (int g = 0; g < 4; ++g) {
+                                double q = 0;
+                                for (int b = 0; b < 8; ++b) q += Af[(h * 32 + i) * 32 + g * 8 + b] * Bf[(h * 32 + j) * 32 + g * 8 + b];
+                                ref += q * (((mask >> (h * 4 + g)) & 1) ? 8.0 : 1.0);
+                            }
+                        maxerr = std::fmax(maxerr, std::fabs(ref - D[l * 16 + r]));
+                        maxref = std::fmax(maxref, std::fabs(ref));
+                    }
+                if (maxerr <= 1e-5 * maxref) {
+                    printf("FP8 SCALE BLOCKS (%s scales differ per lane half): the scale of lanes 32-63 governs groups mask 0x%02x "
+                           "[bit h*4+g: lane half h, byte octet g]\n", side ? "B" : "A", mask);
+                    ++found;
+                }
+            }
+            if (!found) printf("FP8 SCALE BLOCKS (%s): no (lane half, byte octet) assignment matches\n", side ? "B" : "A");
+        }
+    }
+
+    // ---- rates
+    uint32_t* dops;
+    CK(hipMalloc(&dops, ops.size() * 4));
+    CK(hipMemcpy(dops, ops.data(), ops.size() * 4, hipMemcpyHostToDevice));
+    for (int threads : {256, 512}) {
+        if (run_rate<0>("f16 32x32x16", dops, threads, 12 * 32768.0, 12)) return 1;
+        if (run_rate<1>("MX fp8 32x32x64", dops, threads, 12 * 131072.0, 12)) return 1;
+        if (run_rate<2>("MX fp6 32x32x64", dops, threads, 12 * 131072.0, 12)) return 1;
+        if (run_rate<3>("k32 step: 8 f16 + 4 fp8", dops, threads, 8 * 32768.0 + 4 * 131072.0, 12)) return 1;
+    }
+    return 0;
+}
