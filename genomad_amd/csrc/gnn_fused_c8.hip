@@ -168,42 +168,59 @@ __device__ __forceinline__ void k32_step(const WStep& wcur, WStep& wload, XF16& 
     GNN_REGION_END();
 }
 
-// 128 rows x 32 columns, K = NTAPS * 128, as NTAPS * 4 k32 steps; weight ring of four k32 steps.
-// SWAP as in gnn_fused.hip: D = W^T X^T for the convs, D = X W for y @ w_v.  wbase / sbase are wave-uniform
-// (already offset to this wave's n-block), lane = lane id.
+// First three k32 steps of a tile's weights + its first scale word.  Loaded by prefetch_w() BEFORE the
+// epilogue and barrier that precede the tile, so the L2 round trip is hidden behind them instead of
+// being exposed at the head of every tile (four tiles per step).
+struct WRing {
+    WStep w0, w1, w2;
+    int ws;
+};
+__device__ __forceinline__ void prefetch_w(WRing& r, const uint4* __restrict__ wbase, const uint32_t* __restrict__ sbase, int lane) {
+    const uint32_t lane_off = (uint32_t)lane * 16u;
+    load_w_h(r.w0, wbase, lane_off);
+    load_w_c(r.w0, wbase, lane_off);
+    load_w_h(r.w1, wbase + C8_STEP_U4, lane_off);
+    load_w_c(r.w1, wbase + C8_STEP_U4, lane_off);
+    load_w_h(r.w2, wbase + 2 * C8_STEP_U4, lane_off);
+    load_w_c(r.w2, wbase + 2 * C8_STEP_U4, lane_off);
+    r.ws = *reinterpret_cast<const int*>(reinterpret_cast<const unsigned char*>(sbase) + (uint32_t)lane * 4u);
+    asm volatile("" ::: "memory");
+}
+
+// 128 rows x 32 columns, K = NTAPS * 128, as NTAPS * 4 k32 steps; weight ring of four k32 steps, the first
+// three already in flight (prefetch_w).  SWAP as in gnn_fused.hip: D = W^T X^T for the convs, D = X W for
+// y @ w_v.  wbase / sbase are wave-uniform (already offset to this wave's n-block).
 template <bool SWAP, int NTAPS>
 __device__ __forceinline__ void gemm_tile_c8(const unsigned char* __restrict__ xbuf, const uint4* __restrict__ wbase,
-                                             const uint32_t* __restrict__ sbase, f32x16 (&acc)[4], int lane, int sx) {
+                                             const uint32_t* __restrict__ sbase, WRing& ring, f32x16 (&acc)[4], int lane, int sx) {
     constexpr int NK = NTAPS * 4;
-    constexpr bool MULTI = NTAPS > 1;        // single tap: no prefetch past the end (it would be a reload of step 0)
     const unsigned char* xl = xbuf + (lane & 31) * ROWB + (lane >> 5) * 16;
     const uint32_t lane_off = (uint32_t)lane * 16u, lane_s = (uint32_t)lane * 4u;
-    WStep w0, w1, w2, w3;
+    WStep w3;
     XF16 xf;
     XC8 xc;
-    load_w_h(w0, wbase, lane_off);
-    load_w_c(w0, wbase, lane_off);
-    load_w_h(w1, wbase + C8_STEP_U4, lane_off);
-    load_w_c(w1, wbase + C8_STEP_U4, lane_off);
-    load_w_h(w2, wbase + 2 * C8_STEP_U4, lane_off);
-    load_w_c(w2, wbase + 2 * C8_STEP_U4, lane_off);
-    int ws = *reinterpret_cast<const int*>(reinterpret_cast<const unsigned char*>(sbase) + lane_s);
+    int ws = ring.ws;
     load_xf<0>(xf, xl);
     GNN_REGION_END();
+    // all taps but the last: every k32 step prefetches the weights three steps and the activations one step ahead
 #pragma unroll 1
-    for (int t = 0; t < NTAPS; ++t) {
+    for (int t = 0; t < NTAPS - 1; ++t) {
         const int k = t * 4;
         const unsigned char* xt = xl + t * ROWB;
-        const unsigned char* xn = xl + min(t + 1, NTAPS - 1) * ROWB;
-        int ws_next = ws;
-        if constexpr (MULTI)
-            ws_next = *reinterpret_cast<const int*>(reinterpret_cast<const unsigned char*>(sbase + min(t + 1, NTAPS - 1) * 256) + lane_s);
-        // clamped prefetch indices past the end are harmless re-reads
-        k32_step<SWAP, 0, 1, true, true>(w0, w3, xf, xc, xt, xt, wbase + (size_t)min(k + 3, NK - 1) * C8_STEP_U4, lane_off, ws, sx, acc);
-        k32_step<SWAP, 1, 2, MULTI, true>(w1, w0, xf, xc, xt, xt, wbase + (size_t)min(k + 4, NK - 1) * C8_STEP_U4, lane_off, ws, sx, acc);
-        k32_step<SWAP, 2, 3, MULTI, true>(w2, w1, xf, xc, xt, xt, wbase + (size_t)min(k + 5, NK - 1) * C8_STEP_U4, lane_off, ws, sx, acc);
-        k32_step<SWAP, 3, 0, MULTI, MULTI>(w3, w2, xf, xc, xt, xn, wbase + (size_t)min(k + 6, NK - 1) * C8_STEP_U4, lane_off, ws, sx, acc);
+        const int ws_next = *reinterpret_cast<const int*>(reinterpret_cast<const unsigned char*>(sbase + (t + 1) * 256) + lane_s);
+        k32_step<SWAP, 0, 1, true, true>(ring.w0, w3, xf, xc, xt, xt, wbase + (size_t)(k + 3) * C8_STEP_U4, lane_off, ws, sx, acc);
+        k32_step<SWAP, 1, 2, true, true>(ring.w1, ring.w0, xf, xc, xt, xt, wbase + (size_t)(k + 4) * C8_STEP_U4, lane_off, ws, sx, acc);
+        k32_step<SWAP, 2, 3, true, true>(ring.w2, ring.w1, xf, xc, xt, xt, wbase + (size_t)(k + 5) * C8_STEP_U4, lane_off, ws, sx, acc);
+        k32_step<SWAP, 3, 0, true, true>(w3, ring.w2, xf, xc, xt, xt + ROWB, wbase + (size_t)(k + 6) * C8_STEP_U4, lane_off, ws, sx, acc);
         ws = ws_next;
+    }
+    // last tap: only its first step still has weights to fetch (step NK-1); nothing is loaded past the end
+    {
+        const unsigned char* xt = xl + (NTAPS - 1) * ROWB;
+        k32_step<SWAP, 0, 1, true, true>(ring.w0, w3, xf, xc, xt, xt, wbase + (size_t)(NK - 1) * C8_STEP_U4, lane_off, ws, sx, acc);
+        k32_step<SWAP, 1, 2, false, true>(ring.w1, ring.w0, xf, xc, xt, xt, wbase, lane_off, ws, sx, acc);
+        k32_step<SWAP, 2, 3, false, true>(ring.w2, ring.w1, xf, xc, xt, xt, wbase, lane_off, ws, sx, acc);
+        k32_step<SWAP, 3, 0, false, false>(w3, ring.w2, xf, xc, xt, xt, wbase, lane_off, ws, sx, acc);
     }
 }
 
@@ -263,16 +280,18 @@ __device__ __forceinline__ void conv_epilogue_c8(unsigned char* __restrict__ obu
     }
 }
 
-// y @ w_v on the current 128 rows + MaxPool1D(8) -> yp rows (igloo.py:208-210)
-__device__ __forceinline__ void wv_pool_c8(const unsigned char* __restrict__ xbuf, const uint4* __restrict__ wfrag,
-                                           const uint32_t* __restrict__ wscale, float* __restrict__ yp_w, int t0, int wave,
-                                           int lane, int sx) {
-    f32x16 acc[4];
+// y @ w_v on the current 128 rows (igloo.py:208) ...
+__device__ __forceinline__ void wv_mfma_c8(const unsigned char* __restrict__ xbuf, const uint4* __restrict__ wbase,
+                                           const uint32_t* __restrict__ sbase, WRing& ring, f32x16 (&acc)[4], int lane, int sx) {
 #pragma unroll
     for (int mb = 0; mb < 4; ++mb)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[mb][r] = 0.f;
-    gemm_tile_c8<false, 1>(xbuf + CARRY * ROWB, wfrag, wscale, acc, lane, sx);
+    gemm_tile_c8<false, 1>(xbuf + CARRY * ROWB, wbase, sbase, ring, acc, lane, sx);
+}
+// ... and MaxPool1D(8) -> yp rows (igloo.py:209-210): rows 8rg..8rg+3 of a 32-row block sit in lanes 0-31, rows
+// 8rg+4..8rg+7 in lanes 32-63, so the 8-row max is 4 registers + one exchange with lane^32.
+__device__ __forceinline__ void wv_pool_store_c8(const f32x16 (&acc)[4], float* __restrict__ yp_w, int t0, int wave, int lane) {
     float m[16];
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
@@ -292,54 +311,85 @@ __device__ __forceinline__ void wv_pool_c8(const unsigned char* __restrict__ xbu
     }
 }
 
-// IGLOO pair dot products of this step (igloo.py:192-204 with w_mult * w_summer folded), rows read back
-// from LDS as f16 + residual image: x = f16 + e4m3 * 2^-11.  Structure as m_partials in gnn_fused.hip.
-__device__ __forceinline__ void m_partials_c8(const unsigned char* __restrict__ xbuf, const float* __restrict__ weff,
-                                              const int32_t* __restrict__ pos, int t0, int e_begin, int e_end,
-                                              float* __restrict__ mp_w, int wave, int lane) {
+// IGLOO pair dot products (igloo.py:192-204 with w_mult * w_summer folded) of head B for the previous step's
+// x3 rows (bufY) and of head A for this step's x1 rows (bufX), in ONE loop: 16 lanes per entry, 8 channels
+// per lane, 4 entries of each head in flight per lane group.  Rows are read back from LDS as f16 + residual
+// image (x = f16 + e4m3 * 2^-11).  The only dependent chain is position -> LDS row; the positions of the
+// next iteration are fetched while this one computes, so an iteration exposes one L2 round trip (the
+// streamed weights) instead of two.  Results are written in entry order (the back end un-permutes).
+struct PairJob {
+    const unsigned char* xbuf;
+    const float* weff;
+    const int32_t* pos;
+    float* mp;
+    int t0, e, e_end;
+};
+__device__ __forceinline__ void m_partials2_c8(PairJob jb, PairJob ja, int wave, int lane) {
     constexpr int MB = 4;
     const int sub = lane & 15;
-    for (int e = e_begin + wave * 4 + (lane >> 4); e < e_end; e += 16 * MB) {
-        int ei[MB], u[MB];
-        float4 w0[MB], w1[MB];
-        uint4 h[MB];
-        uint2 l[MB];
+    PairJob job[2] = {jb, ja};
+    int u[2][MB];
 #pragma unroll
-        for (int i = 0; i < MB; ++i) {
-            ei[i] = min(e + 16 * i, e_end - 1);
-            u[i] = pos[ei[i]] - t0;
-        }
+    for (int h = 0; h < 2; ++h) {
+        job[h].e += wave * 4 + (lane >> 4);
 #pragma unroll
-        for (int i = 0; i < MB; ++i) {
-            w0[i] = *reinterpret_cast<const float4*>(weff + (size_t)ei[i] * C + sub * 8);
-            w1[i] = *reinterpret_cast<const float4*>(weff + (size_t)ei[i] * C + sub * 8 + 4);
-        }
+        for (int i = 0; i < MB; ++i) u[h][i] = job[h].e_end > job[h].e ? job[h].pos[min(job[h].e + 16 * i, job[h].e_end - 1)] : job[h].t0;
+    }
+    // the 16 lanes of an entry share e, so a lane group enters/leaves together and the width-16 shuffles below
+    // only ever read active lanes
+    while (job[0].e < job[0].e_end || job[1].e < job[1].e_end) {
+        float4 w0[2][MB], w1[2][MB];
+        uint4 hx[2][MB];
+        uint2 lx[2][MB];
+        int un[2][MB];
 #pragma unroll
-        for (int i = 0; i < MB; ++i) {
-            const unsigned char* xr = xbuf + (CARRY + u[i]) * ROWB;
-            h[i] = *reinterpret_cast<const uint4*>(xr + sub * 16);
-            l[i] = *reinterpret_cast<const uint2*>(xr + XL8_OFF + sub * 8);
-        }
+        for (int h = 0; h < 2; ++h)
 #pragma unroll
-        for (int i = 0; i < MB; ++i) {
-            const uint32_t hv[4] = {h[i].x, h[i].y, h[i].z, h[i].w};
-            const float wv[8] = {w0[i].x, w0[i].y, w0[i].z, w0[i].w, w1[i].x, w1[i].y, w1[i].z, w1[i].w};
-            float s = 0.f, r = 0.f;
-            const f32x2 lo4[4] = {__builtin_amdgcn_cvt_pk_f32_fp8((int)l[i].x, false), __builtin_amdgcn_cvt_pk_f32_fp8((int)l[i].x, true),
-                                  __builtin_amdgcn_cvt_pk_f32_fp8((int)l[i].y, false), __builtin_amdgcn_cvt_pk_f32_fp8((int)l[i].y, true)};
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                const f16x2 hh = __builtin_bit_cast(f16x2, hv[k]);
-                s = fmaf((float)hh[0], wv[2 * k], s);
-                s = fmaf((float)hh[1], wv[2 * k + 1], s);
-                r = fmaf(lo4[k][0], wv[2 * k], r);
-                r = fmaf(lo4[k][1], wv[2 * k + 1], r);
+            for (int i = 0; i < MB; ++i) {
+                const int ei = max(min(job[h].e + 16 * i, job[h].e_end - 1), 0);   // clamped duplicates are computed, not stored
+                w0[h][i] = *reinterpret_cast<const float4*>(job[h].weff + (size_t)ei * C + sub * 8);
+                w1[h][i] = *reinterpret_cast<const float4*>(job[h].weff + (size_t)ei * C + sub * 8 + 4);
             }
-            s = fmaf(r, 1.0f / (float)(1 << XL_SHIFT), s);
 #pragma unroll
-            for (int off = 8; off >= 1; off >>= 1) s += __shfl_xor(s, off, 16);
-            if (sub == 0 && e + 16 * i < e_end) mp_w[e + 16 * i] = s;
-        }
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+            for (int i = 0; i < MB; ++i) {
+                const unsigned char* xr = job[h].xbuf + (CARRY + u[h][i] - job[h].t0) * ROWB;
+                hx[h][i] = *reinterpret_cast<const uint4*>(xr + sub * 16);
+                lx[h][i] = *reinterpret_cast<const uint2*>(xr + XL8_OFF + sub * 8);
+            }
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+            for (int i = 0; i < MB; ++i) {
+                const int en = job[h].e + 16 * MB + 16 * i;
+                un[h][i] = en < job[h].e_end ? job[h].pos[en] : job[h].t0;
+            }
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+            for (int i = 0; i < MB; ++i) {
+                const uint32_t hv[4] = {hx[h][i].x, hx[h][i].y, hx[h][i].z, hx[h][i].w};
+                const float wv[8] = {w0[h][i].x, w0[h][i].y, w0[h][i].z, w0[h][i].w, w1[h][i].x, w1[h][i].y, w1[h][i].z, w1[h][i].w};
+                const f32x2 lo4[4] = {__builtin_amdgcn_cvt_pk_f32_fp8((int)lx[h][i].x, false), __builtin_amdgcn_cvt_pk_f32_fp8((int)lx[h][i].x, true),
+                                      __builtin_amdgcn_cvt_pk_f32_fp8((int)lx[h][i].y, false), __builtin_amdgcn_cvt_pk_f32_fp8((int)lx[h][i].y, true)};
+                float s = 0.f, r = 0.f;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const f16x2 hh = __builtin_bit_cast(f16x2, hv[k]);
+                    s = fmaf((float)hh[0], wv[2 * k], s);
+                    s = fmaf((float)hh[1], wv[2 * k + 1], s);
+                    r = fmaf(lo4[k][0], wv[2 * k], r);
+                    r = fmaf(lo4[k][1], wv[2 * k + 1], r);
+                }
+                s = fmaf(r, 1.0f / (float)(1 << XL_SHIFT), s);
+#pragma unroll
+                for (int off = 8; off >= 1; off >>= 1) s += __shfl_xor(s, off, 16);
+                if (sub == 0 && job[h].e + 16 * i < job[h].e_end) job[h].mp[job[h].e + 16 * i] = s;
+                u[h][i] = un[h][i];
+            }
+        job[0].e += 16 * MB;
+        job[1].e += 16 * MB;
     }
 }
 
@@ -377,24 +427,38 @@ __global__ __launch_bounds__(512, 2) void fused_front_c8_kernel(FusedArgsC8 a) {
         toks[j] = (uint16_t)pair_row(token_state(bases, t), token_state(bases, t + 1));
     }
     __syncthreads();
-    if (helper) conv1_gather<0, FT / 8, StoreF16C8>(bufX, toks, a.conv1_k, a.conv1_b, 0, ht);
-    else __builtin_amdgcn_s_setprio(2);
-
     unsigned long long cyc[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     unsigned long long tick_ = 0;
 
+    // Two role-specific step loops with the same barrier sequence B1..B4 per step (keeping them apart keeps
+    // the matrix waves' weight ring out of the helpers' live ranges and vice versa).  Per step s:
+    //   matrix : w_v A(s), conv2 loop [bufX] | B1 | epilogue -> bufY (x2) | B2 | conv3 loop [bufY] | B3 |
+    //            epilogue -> bufY (x3) | B4 | w_v B(s) [bufY]   -> straight into step s+1
+    //   helpers: pair products B(s-1) [bufY] and A(s) [bufX] | B1 | x1 carry rows, gather(s+1) part 1 -> bufX |
+    //            B2 | gather part 2, read x2 carry | B3 | x2 carry rows -> bufY, gather part 3 | B4
+    // No barrier is needed between w_v B(s) and w_v A(s+1): bufX (x1 of s+1) is complete at B4(s), and the
+    // next writer of bufY is the conv2 epilogue behind B1(s+1).  The helpers thus start the pair products of
+    // the next step while the matrix waves still run w_v B, and their gather may use the whole B1..B4 span:
+    // the vector-memory pipe (the busiest unit: all weight fragments, table rows and folded IGLOO weights
+    // of a step, 1.3 MB, go through it) never idles behind a barrier.
+    if (!helper) {
+        __builtin_amdgcn_s_setprio(2);
+        WRing ring;
+        prefetch_w(ring, vw[0], vs[0], lane);
+        __syncthreads();                                                         // x1 of step 0 is in bufX
+        if constexpr (PROF) tick_ = __builtin_readcyclecounter();
 #pragma unroll 1
-    for (int step = 0; step < FSTEPS; ++step) {
-        const int t0 = step * FT;
-        __syncthreads();                                                         // ---- B0
-        if constexpr (PROF) tick_ = step == 0 ? __builtin_readcyclecounter() : tick_;
-        if (!helper) {
+        for (int step = 0; step < FSTEPS; ++step) {
+            const int t0 = step * FT;
             GNN_TICK(7)
-            wv_pool_c8(bufX, vw[0], vs[0], yp_w[0], t0, hw, lane, sx);
-            GNN_TICK(0)
             f32x16 acc[4];
+            wv_mfma_c8(bufX, vw[0], vs[0], ring, acc, lane, sx);
+            prefetch_w(ring, cw[0], cs[0], lane);                                // conv2 weights, hidden by the pooling
+            wv_pool_store_c8(acc, yp_w[0], t0, hw, lane);
+            GNN_TICK(0)
             acc_init_bias_c8(acc, a.conv_b[0], hw, lane);
-            gemm_tile_c8<true, KS>(bufX, cw[0], cs[0], acc, lane, sx);
+            gemm_tile_c8<true, KS>(bufX, cw[0], cs[0], ring, acc, lane, sx);
+            prefetch_w(ring, cw[1], cs[1], lane);                                // conv3 weights, hidden by epilogue + barriers
             GNN_TICK(1)
             __syncthreads();                                                     // ---- B1
             GNN_TICK(2)
@@ -402,40 +466,55 @@ __global__ __launch_bounds__(512, 2) void fused_front_c8_kernel(FusedArgsC8 a) {
             __syncthreads();                                                     // ---- B2
             GNN_TICK(3)
             acc_init_bias_c8(acc, a.conv_b[1], hw, lane);
-            gemm_tile_c8<true, KS>(bufY, cw[1], cs[1], acc, lane, sx);
+            gemm_tile_c8<true, KS>(bufY, cw[1], cs[1], ring, acc, lane, sx);
+            prefetch_w(ring, vw[1], vs[1], lane);                                // w_v of head B
             GNN_TICK(4)
             __syncthreads();                                                     // ---- B3
             GNN_TICK(5)
             conv_epilogue_c8(bufY, acc, hw, lane);
             __syncthreads();                                                     // ---- B4
             GNN_TICK(6)
-            wv_pool_c8(bufY, vw[1], vs[1], yp_w[1], t0, hw, lane, sx);
-        } else {
-            if (step > 0)
-                m_partials_c8(bufY, a.weff[1], a.pos_sorted[1], t0 - FT, a.bucket_ptr[1][step - 1], a.bucket_ptr[1][step],
-                              mp_w[1], hw, lane);
-            m_partials_c8(bufX, a.weff[0], a.pos_sorted[0], t0, a.bucket_ptr[0][step], a.bucket_ptr[0][step + 1], mp_w[0], hw, lane);
+            wv_mfma_c8(bufY, vw[1], vs[1], ring, acc, lane, sx);
+            prefetch_w(ring, vw[0], vs[0], lane);                                // w_v of head A for the next step
+            wv_pool_store_c8(acc, yp_w[1], t0, hw, lane);
+        }
+    } else {
+        conv1_gather<0, FT / 8, StoreF16C8>(bufX, toks, a.conv1_k, a.conv1_b, 0, ht);
+        __syncthreads();
+        if constexpr (PROF) tick_ = __builtin_readcyclecounter();
+#pragma unroll 1
+        for (int step = 0; step < FSTEPS; ++step) {
+            const int t0 = step * FT;
+            {
+                const int sb = max(step - 1, 0);                                 // step 0: empty head-B range
+                const PairJob jb = {bufY, a.weff[1], a.pos_sorted[1], mp_w[1], t0 - FT,
+                                    step > 0 ? a.bucket_ptr[1][sb] : 0, step > 0 ? a.bucket_ptr[1][sb + 1] : 0};
+                const PairJob ja = {bufX, a.weff[0], a.pos_sorted[0], mp_w[0], t0, a.bucket_ptr[0][step], a.bucket_ptr[0][step + 1]};
+                m_partials2_c8(jb, ja, hw, lane);
+            }
             uint4 carry = make_uint4(0, 0, 0, 0);
             const int cr = ht >> 5, cc = ht & 31;        // 5 rows x 32 chunks of 16 B (the three planes = 512 B)
             if (ht < CARRY * 32) carry = *reinterpret_cast<const uint4*>(bufX + (FT + cr) * ROWB + cc * 16);
             GNN_TICK(8)
             __syncthreads();                                                     // ---- B1
             if (ht < CARRY * 32) *reinterpret_cast<uint4*>(bufX + cr * ROWB + cc * 16) = carry;
-            if (step + 1 < FSTEPS) conv1_gather<0, GNN_GATHER_EARLY, StoreF16C8>(bufX, toks, a.conv1_k, a.conv1_b, t0 + FT, ht);
+            const bool more = step + 1 < FSTEPS;
+            if (more) conv1_gather<0, 4, StoreF16C8, 4>(bufX, toks, a.conv1_k, a.conv1_b, t0 + FT, ht);
             __syncthreads();                                                     // ---- B2
-            if constexpr (PROF) tick_ = __builtin_readcyclecounter();
-            if (step + 1 < FSTEPS) conv1_gather<GNN_GATHER_EARLY, FT / 8, StoreF16C8>(bufX, toks, a.conv1_k, a.conv1_b, t0 + FT, ht);
+            if (more) conv1_gather<4, 12, StoreF16C8, 8>(bufX, toks, a.conv1_k, a.conv1_b, t0 + FT, ht);
             if (ht < CARRY * 32) carry = *reinterpret_cast<const uint4*>(bufY + (FT + cr) * ROWB + cc * 16);
-            GNN_TICK(9)
             __syncthreads();                                                     // ---- B3
             if (ht < CARRY * 32) *reinterpret_cast<uint4*>(bufY + cr * ROWB + cc * 16) = carry;
+            if (more) conv1_gather<12, 16, StoreF16C8, 4>(bufX, toks, a.conv1_k, a.conv1_b, t0 + FT, ht);
+            GNN_TICK(9)
             __syncthreads();                                                     // ---- B4
             if constexpr (PROF) tick_ = __builtin_readcyclecounter();
         }
+        const PairJob jb = {bufY, a.weff[1], a.pos_sorted[1], mp_w[1], (FSTEPS - 1) * FT, a.bucket_ptr[1][FSTEPS - 1],
+                            a.bucket_ptr[1][FSTEPS]};
+        const PairJob none = {bufX, a.weff[0], a.pos_sorted[0], mp_w[0], 0, 0, 0};
+        m_partials2_c8(jb, none, hw, lane);
     }
-    if (helper)
-        m_partials_c8(bufY, a.weff[1], a.pos_sorted[1], (FSTEPS - 1) * FT, a.bucket_ptr[1][FSTEPS - 1], a.bucket_ptr[1][FSTEPS],
-                      mp_w[1], hw, lane);
     if constexpr (PROF) {
         if (tid == 0)
             for (int i = 0; i < 8; ++i) atomicAdd(a.cycles + i, cyc[i]);

@@ -91,7 +91,7 @@ __device__ __forceinline__ uint32_t pair_row(int a, int b) {
 #ifndef GNN_GATHER_BATCH
 #define GNN_GATHER_BATCH 4      // positions whose 3 table loads each are in flight together
 #endif
-template <int P0, int P1, typename Store>
+template <int P0, int P1, typename Store, int NBATCH = 0>
 __device__ __forceinline__ void conv1_gather(unsigned char* __restrict__ xbuf, const uint16_t* __restrict__ prow,
                                              const float* __restrict__ pt, const float* __restrict__ b1,
                                              int t0, int ht) {
@@ -102,7 +102,9 @@ __device__ __forceinline__ void conv1_gather(unsigned char* __restrict__ xbuf, c
     const uint2 r2 = *reinterpret_cast<const uint2*>(pr + 32);
     const uint32_t rw[10] = {r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, r1.z, r1.w, r2.x, r2.y};
     const float* ptc = pt + cq * 4;
-    constexpr int NB = (P1 - P0) % GNN_GATHER_BATCH == 0 ? GNN_GATHER_BATCH : 4;   // positions per load batch
+    // positions per load batch (NBATCH must divide P1 - P0 when given)
+    constexpr int NB = NBATCH > 0 ? NBATCH : ((P1 - P0) % GNN_GATHER_BATCH == 0 ? GNN_GATHER_BATCH : 4);
+    static_assert((P1 - P0) % NB == 0, "gather batch must divide the position range");
 #pragma unroll
     for (int i0 = P0; i0 < P1; i0 += NB) {
         f32x4 v[NB];
