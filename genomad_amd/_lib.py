@@ -79,6 +79,15 @@ SIGNATURES = {
     "gnn_crc32c": (C.c_uint32, [_vp, _sz]),
     "gnn_fasta_scan": (_int, [_vp, _i64, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_int)]),
     "gnn_fasta_pack": (_int, [_vp, _i64, _int, _vp, _vp, _vp, _vp, _i64, C.POINTER(C.c_int64)]),
+    "gnn_comm_unique_id": (_int, [_vp]),
+    "gnn_comm_init": (_int, [_vp, _int, _int, _vp]),
+    "gnn_comm_destroy": (_int, [_vp]),
+    "gnn_comm_info": (_int, [_vp, C.POINTER(_int), C.POINTER(_int)]),
+    "gnn_comm_gather_dev": (_int, [_vp, _vp, _vp, _sz, _int]),
+    "gnn_comm_gather": (_int, [_vp, _vp, _vp, _sz, _int]),
+    "gnn_comm_allgather": (_int, [_vp, _vp, _vp, _sz]),
+    "gnn_comm_allreduce_max": (_int, [_vp, C.POINTER(C.c_double), _int]),
+    "gnn_comm_barrier": (_int, [_vp]),
     "gnn_branch_attention": (_int, [_vp, _vp, _vp, _vp, _i64, C.c_double, _vp]),
     "gnn_score_calibration": (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp]),
 }

@@ -252,6 +252,7 @@ int gnn_destroy(gnn_ctx* ctx) {
     if (!ctx) return GNN_OK;
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
+    if (ctx->comm || ctx->comm_scratch) (void)gnn_comm_destroy(ctx);
     free_ws(ctx->ws);
     for (void* p : ctx->owned) (void)hipFree(p);
     for (auto& s : ctx->prof)

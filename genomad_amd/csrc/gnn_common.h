@@ -115,6 +115,11 @@ struct gnn_ctx {
     std::vector<void*> owned;   // device allocations to free at destroy
     int cu_count = 0;
     unsigned long long* phase_cycles = nullptr;   // non-null: fused kernel runs its instrumented build
+    // RCCL communicator of this ctx (gnn_comm.hip); ncclComm_t kept opaque here
+    void* comm = nullptr;
+    int comm_ranks = 1, comm_rank = 0;
+    void* comm_scratch = nullptr;
+    size_t comm_scratch_bytes = 0;
 };
 
 namespace gnn {

@@ -15,8 +15,10 @@ no TFRecord round trip).  ``<prefix>_encoded_sequences/`` holds ``<prefix>_seq_w
 bounds the windows per GPU launch (results do not depend on it).
 
 Weights: ``$GENOMAD_AMD_WEIGHTS`` or ``<genomad data dir>/nn_classifier.npz`` in the schema of
-genomad_amd/weights.py.  With WORLD_SIZE > 1 (torch.distributed.run, one process per GPU) the
-windows are sharded across ranks and rank 0 writes the files.
+genomad_amd/weights.py.  With WORLD_SIZE > 1 (one process per GPU, e.g. started by
+``python -m torch.distributed.run`` — used only as a process launcher) the contigs are sharded across
+ranks, the per-contig scores are collected with one RCCL gather (genomad_amd/rccl.py, no torch) and rank 0
+writes the files.
 """
 import concurrent.futures
 import hashlib
@@ -33,6 +35,9 @@ import numpy as np
 
 from . import sequence
 
+# arithmetic of the fused front end: "f16c8" = f16 MFMA + MX-fp8 corrections (fastest inside the 1e-4 tolerance),
+# "bf16x3" = split-bf16 three passes, "f32" = exact f32 reference kernels
+DEFAULT_PRECISION = "f16c8"
 MODULE_NAME = "nn_classification"   # utils.write_execution_info("nn_classification", ...) :207-212
 TSV_HEADER = "seq_name\tchromosome_score\tplasmid_score\tvirus_score\n"   # :345
 
@@ -133,8 +138,10 @@ def write_execution_info(module_name, input_file: Path, parameters: dict, output
                        "input_md5": get_md5(input_file),
                        "start_time": start_time,
                        "parameters": parameters}, indent=4)
-    with open(output_file, "w") as fout:
+    tmp = Path(f"{output_file}.tmp{os.getpid()}")      # never leave a half-written JSON for a concurrent reader
+    with open(tmp, "w") as fout:
         fout.write(f"{dump}\n")
+    os.replace(tmp, output_file)
 
 
 def compare_executions(input_file, parameters, execution_info_file) -> bool:   # utils.py:266-277
@@ -203,11 +210,11 @@ def _engine():
     weights are uploaded once and reused for the provirus pass)."""
     global _ENGINE
     if _ENGINE is None:
+        from . import rccl
         from .engine import NNEngine
         # the reference module sets CUDA_VISIBLE_DEVICES=-1 at import (nn_classification.py:8), which
-        # HIP honours; undo it before the HIP runtime is initialised
-        if os.environ.get("CUDA_VISIBLE_DEVICES") == "-1":
-            del os.environ["CUDA_VISIBLE_DEVICES"]
+        # HIP honours; undo it before the HIP runtime is initialised (main() and install() do so as well)
+        rccl.prepare_env()
         device = int(os.environ.get("GENOMAD_AMD_DEVICE", os.environ.get("LOCAL_RANK", "0")))
         _ENGINE = NNEngine(device, load_weights_file(find_weights()))
     return _ENGINE
@@ -219,7 +226,7 @@ class GpuBackend:
     def __init__(self, batch_size: int):
         self.eng = _engine()
         self.chunk = max(int(batch_size), 4096)
-        self.precision = os.environ.get("GENOMAD_AMD_PRECISION", "bf16x3")
+        self.precision = os.environ.get("GENOMAD_AMD_PRECISION", DEFAULT_PRECISION)
 
     def score(self, windows: np.ndarray) -> np.ndarray:
         out = [self.eng.classify(windows[a:a + self.chunk], self.precision)
@@ -230,11 +237,11 @@ class GpuBackend:
         return self.eng.segment_mean(scores, ids, n_segments)
 
 
-def classify_windows(windows: np.ndarray, contig_ids: np.ndarray, n_contigs: int, backend):
-    """Window scores -> per-contig mean (nn_classification.py:316-320), sharded over ranks when
-    torch.distributed is initialised (rank 0 gets the result, other ranks None)."""
+def classify_windows(windows: np.ndarray, contig_ids: np.ndarray, n_contigs: int, backend, comm=None):
+    """Window scores -> per-contig mean (nn_classification.py:316-320), sharded over the ranks of ``comm``
+    (rank 0 gets the result, other ranks None)."""
     from . import sharding
-    scores = sharding.classify_sharded(windows, backend.score)
+    scores = sharding.classify_sharded(windows, backend.score, comm)
     if scores is None:
         return None
     return backend.segment_mean(scores, contig_ids, n_contigs)
@@ -248,13 +255,21 @@ def _encode(fasta_path, enc_dir: Path, window_id_path: Path, single_window: bool
 
 
 def main(input_path, output_path, single_window, batch_size, restart, threads, verbose, cleanup,
-         _backend=None):
+         _backend=None, _comm=None):
     """``_backend`` (tests only) replaces the GPU engine with an object offering score() and
-    segment_mean(); the product path always builds a :class:`GpuBackend` and fails without a GPU."""
+    segment_mean(); ``_comm`` (tests only) replaces the RCCL transport with another implementation of the
+    sharding.py transport interface.  The product path always builds a :class:`GpuBackend` and an
+    :class:`genomad_amd.rccl.RcclComm`, and fails without a GPU."""
+    from . import rccl, sharding
+    rccl.prepare_env()        # before ANY HIP call: drops the reference's CUDA_VISIBLE_DEVICES=-1 (:8)
     input_path, output_path = Path(input_path), Path(output_path)
-    from . import sharding
-    # under torch.distributed.run: create the process group (nccl = RCCL) before the HIP library loads
-    rank, world = sharding.ensure_process_group() if _backend is None else (int(os.environ.get("RANK", "0")), 1)
+    if _comm is not None:
+        comm = _comm
+    elif _backend is None and rccl.world_from_env()[1] > 1:
+        comm = rccl.comm_for(_engine())      # one process per GPU: RCCL communicator of this rank's engine
+    else:
+        comm = None
+    rank, world = (comm.rank, comm.world) if comm is not None else (0, 1)
     rank0 = rank == 0
     if not output_path.is_dir():
         output_path.mkdir(exist_ok=True)
@@ -262,15 +277,21 @@ def main(input_path, output_path, single_window, batch_size, restart, threads, v
     outputs = Outputs(prefix, output_path)
     console = Console(output_file=outputs.nn_classification_log if rank0 else None, verbose=verbose and rank0)
     parameter_dict = {"single_window": single_window}
-    classify_proviruses = check_provirus_execution(outputs, input_path)
+    md5_async(input_path)            # starts hashing now; check_fasta and the stages overlap with it
+    device_front_end = _backend is None and os.environ.get("GENOMAD_AMD_FRONT_END", "device") == "device"
+
+    def everywhere(*flags):
+        """Decisions read from files that rank 0 is about to rewrite are taken on rank 0 and made known to
+        the other ranks, so that all of them walk through the same gathers."""
+        return [bool(f) for f in sharding.broadcast_flags(comm, flags)] if comm is not None else [bool(f) for f in flags]
+
+    (classify_proviruses,) = everywhere(check_provirus_execution(outputs, input_path) if rank0 else False)
     output_files = [outputs.nn_classification_execution_info, outputs.encoded_sequences_dir,
                     outputs.nn_classification_output, outputs.nn_classification_npz_output]
     if classify_proviruses:
         output_files += [outputs.encoded_proviruses_dir, outputs.provirus_nn_classification_output,
                          outputs.provirus_nn_classification_npz_output]
     console.log(f"Executing geNomad nn-classification (genomad_amd, MI355X). Outputs in {outputs.nn_classification_dir}.")
-    md5_async(input_path)            # starts hashing now; check_fasta and the stages overlap with it
-    device_front_end = _backend is None and os.environ.get("GENOMAD_AMD_FRONT_END", "device") == "device"
 
     def fail_on_bad_fasta(ok: bool):                                           # :164-170
         if not ok:
@@ -278,35 +299,39 @@ def main(input_path, output_path, single_window, batch_size, restart, threads, v
                           "Please check your input FASTA file and execute genomad nn-classification again.")
             sys.exit(1)
 
-    # The device front end validates the FASTA on a helper thread while the GPU already classifies;
-    # nothing is written (no outputs, no execution info) before ``gate()`` has seen the verdict, so
-    # an invalid input leaves the same state behind as in the reference, which checks first.
-    check_pool = concurrent.futures.ThreadPoolExecutor(max_workers=1) if device_front_end else None
+    # The FASTA is validated once, on rank 0 (in bounded memory: sequence.check_fasta), and the verdict is
+    # shared.  The device front end runs it on a helper thread while the GPU already classifies; nothing is
+    # written (no outputs, no execution info) before ``gate()`` has seen the verdict, so an invalid input
+    # leaves the same state behind as in the reference, which checks first.
+    check_pool = concurrent.futures.ThreadPoolExecutor(max_workers=1) if (device_front_end and rank0) else None
     check_future = check_pool.submit(sequence.check_fasta, input_path) if check_pool else None
-    if check_future is None:
-        fail_on_bad_fasta(sequence.check_fasta(input_path))
+    if not device_front_end:
+        fail_on_bad_fasta(everywhere(sequence.check_fasta(input_path) if rank0 else True)[0])
 
-    skip = False                                                               # :175-197
-    if (outputs.nn_classification_execution_info.exists() and any(p.exists() for p in output_files) and not restart):
-        if compare_executions(input_path, parameter_dict, outputs.nn_classification_execution_info):
-            skip = True
-            console.log("Previous execution detected. Steps will be skipped unless their outputs are not found. "
-                        "Use the --restart option to force the execution of all the steps again.")
-        else:
-            console.log("The input file or the parameters changed since the last execution. "
-                        "Previous outputs will be overwritten.")
+    skip, changed = False, False                                               # :175-197
+    if rank0 and (outputs.nn_classification_execution_info.exists() and any(p.exists() for p in output_files)
+                  and not restart):
+        skip = compare_executions(input_path, parameter_dict, outputs.nn_classification_execution_info)
+        changed = not skip
+    skip, changed = everywhere(skip, changed)
+    if skip:
+        console.log("Previous execution detected. Steps will be skipped unless their outputs are not found. "
+                    "Use the --restart option to force the execution of all the steps again.")
+    elif changed:
+        console.log("The input file or the parameters changed since the last execution. "
+                    "Previous outputs will be overwritten.")
     state = {"info_writer": None, "gated": False}
     start_time = datetime.now(timezone.utc).astimezone().isoformat()
 
     def gate():
-        """First call: wait for the FASTA verdict, then start writing the execution info (as soon as
-        the digest is ready; a non-daemon thread, so it also completes if a stage ends the run with
-        sys.exit).  Every writer of an output file calls this first."""
+        """First call (every rank, at the same point of the program): wait for the FASTA verdict, then start
+        writing the execution info (as soon as the digest is ready; a non-daemon thread, so it also
+        completes if a stage ends the run with sys.exit).  Every writer of an output file calls this first."""
         if state["gated"]:
             return
         state["gated"] = True
-        if check_future is not None:
-            fail_on_bad_fasta(check_future.result())
+        if device_front_end:
+            fail_on_bad_fasta(everywhere(check_future.result() if rank0 else True)[0])
         if rank0:
             outputs.nn_classification_dir.mkdir(exist_ok=True)
             state["info_writer"] = threading.Thread(
@@ -319,8 +344,9 @@ def main(input_path, output_path, single_window, batch_size, restart, threads, v
 
     def stage(fasta, enc_dir, wid_path, npz_path, tsv_path, names_key, ids_key, what):
         windows = None
-        if skip and wid_path.exists() and (len(list(enc_dir.glob("*.win.npy")))
-                                           or len(list(enc_dir.glob("*.tfrec")))):   # :215-225
+        (have_enc,) = everywhere(rank0 and skip and wid_path.exists() and bool(
+            len(list(enc_dir.glob("*.win.npy"))) or len(list(enc_dir.glob("*.tfrec")))))       # :215-225
+        if have_enc:
             console.log(f"{enc_dir.name} was found. Skipping {what} encoding.")
             z = np.load(wid_path)
             names, ids = z[names_key], z[ids_key]
@@ -333,10 +359,13 @@ def main(input_path, output_path, single_window, batch_size, restart, threads, v
             else:
                 names, ids, windows = sequence.encode_fasta(fasta, single_window)
             console.log(f"Encoded {what} data written to {enc_dir.name}.")
-        if skip and npz_path.exists():                                               # :284-292
+        (have_npz,) = everywhere(rank0 and skip and npz_path.exists())                   # :284-292
+        predictions = None
+        if have_npz:
             console.log(f"{npz_path.name} was found. Skipping {what} classification.")
-            z = np.load(npz_path)
-            names, predictions = z[names_key], z["predictions"]
+            if rank0:
+                z = np.load(npz_path)
+                names, predictions = z[names_key], z["predictions"]
         else:
             if windows is None:
                 files = sorted(enc_dir.glob("*.win.npy"))
@@ -351,7 +380,7 @@ def main(input_path, output_path, single_window, batch_size, restart, threads, v
                 console.error("No sequences were found. Please check your input FASTA.")
                 sys.exit(1)
             backend = _backend if _backend is not None else GpuBackend(batch_size)
-            predictions = classify_windows(windows, ids, len(names), backend)
+            predictions = classify_windows(windows, ids, len(names), backend, comm)
             console.log(f"{what.capitalize()}s classified.")
             if rank0:
                 np.savez_compressed(npz_path, **{names_key: names, "predictions": predictions})   # :326-330
@@ -364,19 +393,23 @@ def main(input_path, output_path, single_window, batch_size, restart, threads, v
     def stage_device(fasta, enc_dir, wid_path, npz_path, tsv_path, names_key, ids_key, what):
         """Product path: the contig front end (NNEngine.classify_contigs) does windowing, the N rule,
         tokenising, classification and the per-contig mean on the GPU, so encoding and classification
-        are one step; ``<prefix>_seq_window_id.npz`` is still written.  With several ranks
-        (torch.distributed.run) the CONTIGS are sharded: every rank reads and packs only its own
-        record-aligned byte range of the file (or, for compressed inputs, its contig range of the
-        whole table), classifies it on its GPU, and rank 0 collects the per-contig scores with one
-        gather and writes the files — results are bit-identical for any number of ranks."""
-        if skip and npz_path.exists():                                               # :284-292
+        are one step; ``<prefix>_seq_window_id.npz`` is still written.  With several ranks the CONTIGS are
+        sharded: every rank reads and packs only its own record-aligned byte range of the file (for
+        compressed inputs: every world-th record-aligned chunk of the decompressed stream), classifies it
+        on its GPU, and rank 0 collects the per-contig scores with one gather and writes the files —
+        results are bit-identical for any number of ranks."""
+        (have_npz,) = everywhere(rank0 and skip and npz_path.exists())                   # :284-292
+        names = predictions = None
+        if have_npz:
             gate()
             console.log(f"{npz_path.name} was found. Skipping {what} classification.")
-            z = np.load(npz_path)
-            names, predictions = z[names_key], z["predictions"]
+            if rank0:
+                z = np.load(npz_path)
+                names, predictions = z[names_key], z["predictions"]
         else:
-            precision = os.environ.get("GENOMAD_AMD_PRECISION", "bf16x3")
+            precision = os.environ.get("GENOMAD_AMD_PRECISION", DEFAULT_PRECISION)
             eng = _engine()
+            parts = []
             if sequence.compression_of(fasta) == "uncompressed":
                 # this rank's record-aligned share of the file, in pieces of about 128 MB: piece k+1
                 # is read and packed on a helper thread while the GPU classifies piece k
@@ -384,7 +417,6 @@ def main(input_path, output_path, single_window, batch_size, restart, threads, v
                 pieces = int(min(64, max(1, -(-share // (128 << 20)))))
                 read = lambda k: sequence.read_fasta_packed(  # noqa: E731
                     fasta, True, sequence.record_aligned_range(fasta, rank, world, k, pieces))
-                parts, base = [], 0
                 with concurrent.futures.ThreadPoolExecutor(max_workers=1) as pool:
                     nxt = pool.submit(read, 0)
                     for k in range(pieces):
@@ -392,20 +424,17 @@ def main(input_path, output_path, single_window, batch_size, restart, threads, v
                         if k + 1 < pieces:
                             nxt = pool.submit(read, k + 1)
                         pr, wid = eng.classify_contigs(sq, off, single_window, precision)
-                        parts.append((nm, pr, wid + base))
-                        base += len(nm)
-                names = np.concatenate([p[0] for p in parts])
-                predictions = np.concatenate([p[1] for p in parts])
-                ids = np.concatenate([p[2] for p in parts])
+                        parts.append((rank * 64 + k, nm, pr, wid))
             else:
-                names, seq, offsets = sequence.read_fasta_packed(fasta, strip_n=True)
-                if world > 1:
-                    a, b = sharding.contig_subset(offsets, rank, world)
-                    names, seq, offsets = names[a:b], seq[offsets[a]:offsets[b]], offsets[a:b + 1] - offsets[a]
-                predictions, ids = eng.classify_contigs(seq, offsets, single_window, precision)
-            n_windows = len(ids)
-            if world > 1:
-                names, predictions, ids, n_windows = sharding.gather_contig_results(names, predictions, ids)
+                # compressed streams cannot be read by byte range: every rank decompresses the stream
+                # chunk by chunk (bounded memory) and packs + classifies every world-th chunk
+                for i, chunk in enumerate(sequence.iter_text_chunks(fasta)):
+                    if i % world != rank:
+                        continue
+                    nm, sq, off = sequence.pack_text(chunk, strip_n=True)
+                    pr, wid = eng.classify_contigs(sq, off, single_window, precision)
+                    parts.append((i, nm, pr, wid))
+            names, predictions, ids, n_windows = sharding.gather_contig_parts(comm, parts)
             gate()
             if not n_windows:                                                        # :297-299
                 console.error("No sequences were found. Please check your input FASTA.")
@@ -437,14 +466,18 @@ def main(input_path, output_path, single_window, batch_size, restart, threads, v
             check_pool.shutdown(wait=True)
         if state["info_writer"] is not None:
             state["info_writer"].join()
+    if comm is not None:
+        comm.barrier()               # rank 0 has written everything before any rank returns
     console.log("geNomad nn-classification finished!")
 
 
 def install():
     """Make the reference CLI use this module: ``genomad.nn_classification`` is looked up at call
     time (cli.py:772, :1367), so rebinding the attribute is enough."""
+    from . import rccl
     import genomad
-    import genomad.modules
+    import genomad.modules          # importing the reference module exports CUDA_VISIBLE_DEVICES=-1 (:8) ...
+    rccl.prepare_env()              # ... which HIP would honour: undo it before any HIP call
     this = sys.modules[__name__]
     genomad.nn_classification = this
     genomad.modules.nn_classification = this

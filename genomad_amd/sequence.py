@@ -90,10 +90,25 @@ def check_fasta_py(path) -> bool:
     return bool(acc) and len(acc) == len(set(acc))
 
 
-def check_fasta(path) -> bool:
-    """:func:`check_fasta_py` with the line loop done by the library's packer in index mode."""
-    acc, _, _ = _pack(_read_text_array(path), strip_n=False, copy=False)
-    return bool(acc) and len(acc) == len(set(acc))
+def check_fasta(path, chunk_bytes: int = 256 << 20) -> bool:
+    """:func:`check_fasta_py` with the line loop done by the library's packer in index mode, over
+    record-aligned chunks of the (decompressed) text: host memory is bounded by one chunk plus the set of
+    accessions, like the reference's line-by-line read (sequence.py:124-131)."""
+    seen, n = set(), 0
+    for chunk in iter_text_chunks(path, chunk_bytes):
+        acc, _, _ = _pack(chunk, strip_n=False, copy=False)
+        n += len(acc)
+        seen.update(acc)
+        if len(seen) != n:
+            return False
+    return n > 0
+
+
+def _decode_header(raw: bytes) -> str:
+    """Header bytes -> str.  The reference reads the file in text mode with the locale's encoding (UTF-8 in
+    practice, utils.py:152-168), so non-ASCII header text is legal; ``surrogateescape`` keeps undecodable
+    bytes round-trippable instead of raising on one rank of a multi-rank run."""
+    return raw.decode("utf-8", "surrogateescape")
 
 
 def window_spans(length: int, single_window: bool = False) -> List[Tuple[int, int]]:
@@ -170,7 +185,7 @@ def read_fasta_packed_py(path, strip_n: bool = True):
         if strip_n:
             s = s.strip(b"nN")
         if len(s):
-            names.append(accession(header.decode("ascii")))
+            names.append(accession(_decode_header(header)))
             chunks.append(s)
             lengths.append(len(s))
     offsets = np.zeros(len(lengths) + 1, dtype=np.int64)
@@ -241,6 +256,42 @@ def _read_text_array(path, byte_range=None) -> np.ndarray:
         return np.frombuffer(bytearray(fin.read()), dtype=np.uint8)
 
 
+def _open_binary(path):
+    kind = compression_of(path)
+    opener = {"gzip": gzip.open, "bzip2": bz2.open, "xz": lzma.open}.get(kind)
+    if kind == "zstd" and sys.version_info >= (3, 14):
+        from compression import zstd  # type: ignore
+        opener = zstd.open
+    return opener(path, "rb") if opener else open(path, "rb")
+
+
+def iter_text_chunks(path, chunk_bytes: int = 128 << 20):
+    """The decompressed file as writable uint8 arrays of about ``chunk_bytes``, each cut at a record start
+    (a line beginning with '>'), so that every chunk can be packed on its own and the chunks tile the
+    file.  A record longer than a chunk simply makes that chunk longer."""
+    with _open_binary(path) as fin:
+        carry = b""
+        while True:
+            block = fin.read(chunk_bytes)
+            if not block:
+                break
+            data = carry + block if carry else block
+            cut = data.rfind(b"\n>")
+            if cut < 0:
+                carry = data
+                continue
+            yield np.frombuffer(bytearray(data[:cut + 1]), dtype=np.uint8)
+            carry = data[cut + 1:]
+        if carry:
+            yield np.frombuffer(bytearray(carry), dtype=np.uint8)
+
+
+def pack_text(text: np.ndarray, strip_n: bool = True):
+    """(names, seq, offsets) of the records in a writable text array (consumed: packed in place)."""
+    names, seq, offsets = _pack(text, strip_n)
+    return (np.array(names) if names else np.zeros(0, dtype="<U1")), seq, offsets
+
+
 def _pack(text: np.ndarray, strip_n: bool, copy: bool = True):
     """Run gnn_fasta_scan / gnn_fasta_pack over a writable text array.  copy=True packs IN PLACE
     (``text`` is consumed) and returns (names, seq view, offsets); copy=False is the index mode."""
@@ -262,7 +313,7 @@ def _pack(text: np.ndarray, strip_n: bool, copy: bool = True):
     k = nrec.value
     offsets = offsets[:k + 1].copy()
     hraw = headers.tobytes()
-    names = [accession(hraw[hoff[i]:hoff[i + 1]].decode("ascii")) for i in range(k)]
+    names = [accession(_decode_header(hraw[hoff[i]:hoff[i + 1]])) for i in range(k)]
     return names, (text[:offsets[-1]] if copy else None), offsets
 
 

@@ -209,6 +209,27 @@ uint32_t gnn_crc32c(const void* data_host, size_t n_bytes);
 int gnn_debug_forward(gnn_ctx* ctx, const uint8_t* bases_host, int64_t n_windows, int precision,
                       float* scores_host, const gnn_taps* taps);
 
+/* ---- multi-GPU: one process per GPU, RCCL over xGMI ---------------------------------
+ * The path shards with no data-path collective: rank r classifies its own contiguous range of windows
+ * (or contigs) with the replicated weights; the only exchange is the END-OF-RUN gather of the 12 B/window
+ * class scores (the `predictions` the reference concatenates at nn_classification.py:316-319) to rank 0,
+ * plus small control messages.  librccl.so is dlopen()ed on first use.  All collectives are enqueued on
+ * the ctx stream; the host-buffer variants stage through device memory and synchronise before returning.
+ * Bootstrap: rank 0 calls gnn_comm_unique_id and hands the 128 bytes to the other ranks out of band
+ * (genomad_amd/rccl.py uses a file next to the launcher's rendezvous); every rank then calls gnn_comm_init. */
+#define GNN_COMM_ID_BYTES 128
+int gnn_comm_unique_id(uint8_t* id128);                                   /* ncclGetUniqueId */
+int gnn_comm_init(gnn_ctx* ctx, int n_ranks, int rank, const uint8_t* id128);   /* ncclCommInitRank on ctx's device */
+int gnn_comm_destroy(gnn_ctx* ctx);
+int gnn_comm_info(gnn_ctx* ctx, int* n_ranks, int* rank);                  /* (1, 0) without a communicator */
+/* ncclGather (rccl.h:745) of bytes_per_rank bytes from every rank to `root`: recv holds n_ranks blocks in rank
+ * order (ignored on other ranks).  _dev: device pointers, asynchronous on the ctx stream. */
+int gnn_comm_gather_dev(gnn_ctx* ctx, const void* send_dev, void* recv_dev, size_t bytes_per_rank, int root);
+int gnn_comm_gather(gnn_ctx* ctx, const void* send_host, void* recv_host, size_t bytes_per_rank, int root);
+int gnn_comm_allgather(gnn_ctx* ctx, const void* send_host, void* recv_host, size_t bytes_per_rank);
+int gnn_comm_allreduce_max(gnn_ctx* ctx, double* values_host, int n);      /* in place; used for max-over-ranks timing */
+int gnn_comm_barrier(gnn_ctx* ctx);
+
 /* ---- synthetic data + measurement ------------------------------------------------------ */
 /* windows first..first+n of the counter-based synthetic set (genomad_amd/synthetic.py) */
 int gnn_synth_windows_dev(gnn_ctx* ctx, uint64_t seed, int64_t first, int64_t n_windows,

@@ -162,17 +162,16 @@ def test_shard_ranges_cover_and_order():
 
 
 def _gloo_worker(rank, world, port, n, q):
-    import torch.distributed as dist
-    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from tests.gloo_comm import GlooComm
+    comm = GlooComm(rank, world, port)
     rng = np.random.default_rng(0)
     windows = rng.integers(65, 85, (n, 6000), dtype=np.uint8)
-    out = sharding.classify_sharded(windows, FakeBackend().score)
+    out = sharding.classify_sharded(windows, FakeBackend().score, comm)
     if rank == 0:
         q.put(out)
     else:
         assert out is None
-    dist.destroy_process_group()
+    comm.close()
 
 
 @pytest.mark.parametrize("n", [11, 4])
@@ -206,6 +205,22 @@ def _fake_contig_scores(seq, offsets):
         c = seq[offsets[i]:offsets[i + 1]]
         out[i] = [(c == b).mean() for b in (65, 67, 71)]
     return out, sequence.candidate_spans(offsets)[2]
+
+
+def test_gather_contig_parts_single_process_orders_pieces(tmp_path):
+    p = tmp_path / "meta.fna"
+    _write_sharding_fasta(p)
+    parts = []
+    for k in (2, 0, 1):
+        names, seq, offsets = sequence.read_fasta_packed(p, True, sequence.record_aligned_range(p, 0, 1, k, 3))
+        parts.append((k, names, *_fake_contig_scores(seq, offsets)))
+    names, preds, ids, total = sharding.gather_contig_parts(None, parts)
+    n1, s1, o1 = sequence.read_fasta_packed(p)
+    want_scores, want_ids = _fake_contig_scores(s1, o1)
+    assert list(names) == list(n1) and np.array_equal(preds, want_scores)
+    assert np.array_equal(ids, want_ids) and total == len(want_ids)
+    with pytest.raises(ValueError, match="duplicate"):
+        sharding.gather_contig_parts(None, [parts[0], parts[0]])
 
 
 def _write_sharding_fasta(path):
@@ -249,19 +264,21 @@ def test_record_aligned_byte_ranges_tile_the_file(tmp_path):
 
 
 def _gloo_contig_worker(rank, world, port, path, q):
-    import torch.distributed as dist
-    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
-                      LOCAL_RANK=str(rank))
-    assert sharding.ensure_process_group() == (rank, world)       # gloo: no GPU here
-    names, seq, offsets = sequence.read_fasta_packed(path, True, sequence.record_aligned_range(path, rank, world))
-    scores, ids = _fake_contig_scores(seq, offsets)
-    out = sharding.gather_contig_results(names, scores, ids)
+    from tests.gloo_comm import GlooComm
+    comm = GlooComm(rank, world, port)
+    # two pieces per rank, handed over out of order: rank 0 must put them back into file order
+    parts = []
+    for k in (1, 0):
+        names, seq, offsets = sequence.read_fasta_packed(path, True, sequence.record_aligned_range(path, rank, world, k, 2))
+        scores, ids = _fake_contig_scores(seq, offsets)
+        parts.append((rank * 64 + k, names, scores, ids))
+    out = sharding.gather_contig_parts(comm, parts)
     assert out[3] > 0
     if rank == 0:
         q.put(out)
     else:
         assert out[0] is None and out[1] is None and out[2] is None
-    dist.destroy_process_group()
+    comm.close()
 
 
 @pytest.mark.parametrize("world", [2, 3])
@@ -480,3 +497,112 @@ def test_resume_from_a_reference_encoded_directory(tmp_path):
             return FakeBackend.score(self, windows)
     nnc.main(fa, out, False, 128, False, 1, False, False, _backend=Check())
     assert np.array_equal(np.load(d / "r_nn_classification.npz")["predictions"], first)
+
+
+# ------------------------------------------------------------------ the drop-in seam (cli.py:772-774, :1367-1376)
+def test_install_rebinds_the_reference_entry_point_and_undoes_cuda_visible_devices(tmp_path, monkeypatch):
+    """The reference CLI calls ``genomad.nn_classification.main(input, output, single_window, batch_size,
+    restart, threads, verbose, cleanup)`` positionally (cli.py:772-774; end-to-end goes through the same
+    command, :1367-1376).  Importing the reference module exports CUDA_VISIBLE_DEVICES=-1
+    (modules/nn_classification.py:8), which HIP honours: install() and main() must remove it before any HIP
+    call.  Runs the REAL reference package namespace in place (numba stubbed, genomad/__init__.py bypassed)."""
+    from oracle import reference_harness as rh
+    if not rh.available():
+        pytest.skip("needs the reference checkout")
+    import importlib
+    rh.load_reference_sequence()
+    monkeypatch.delenv("CUDA_VISIBLE_DEVICES", raising=False)
+    ref_mod = importlib.import_module("genomad.modules.nn_classification")
+    importlib.reload(ref_mod)                                   # (re)runs its module-level os.environ writes
+    assert os.environ.get("CUDA_VISIBLE_DEVICES") == "-1"
+    import genomad
+    monkeypatch.setattr(genomad, "nn_classification", ref_mod, raising=False)   # what genomad/__init__.py:5-14 binds
+    monkeypatch.setitem(sys.modules, "genomad.modules.nn_classification", ref_mod)
+    try:
+        this = nnc.install()
+        assert this is nnc and genomad.nn_classification is nnc
+        assert sys.modules["genomad.modules.nn_classification"] is nnc
+        assert "CUDA_VISIBLE_DEVICES" not in os.environ
+        os.environ["CUDA_VISIBLE_DEVICES"] = "-1"              # e.g. another module re-imported the reference one
+        monkeypatch.setenv("GENOMAD_AMD_FRONT_END", "host")
+        monkeypatch.delenv("WORLD_SIZE", raising=False)
+        monkeypatch.setattr(nnc, "GpuBackend", lambda batch_size: FakeBackend())
+
+        def cli_nn_classification(input, output, single_window, batch_size, restart, threads, verbose, cleanup):
+            genomad.nn_classification.main(input, output, single_window, batch_size, restart, threads, verbose, cleanup)
+
+        from pathlib import Path
+        fa = tmp_path / "sample.fna"
+        _write_fasta(fa, [("c1 d", "ACGT" * 3000), ("c2", "GGCA" * 700)])
+        cli_nn_classification(Path(fa), Path(tmp_path / "out"), False, 128, False, 1, False, False)
+        assert "CUDA_VISIBLE_DEVICES" not in os.environ
+        z = np.load(tmp_path / "out" / "sample_nn_classification" / "sample_nn_classification.npz")
+        assert list(z["contig_names"]) == ["c1", "c2"] and z["predictions"].shape == (2, 3)
+        # end-to-end's keyword form resolves to the same positional call (click fills the defaults)
+        cli_nn_classification(input=Path(fa), output=Path(tmp_path / "out2"), single_window=False, batch_size=128,
+                              restart=False, threads=1, verbose=False, cleanup=True)
+        assert (tmp_path / "out2" / "sample_nn_classification" / "sample_nn_classification.tsv").exists()
+    finally:
+        os.environ.pop("CUDA_VISIBLE_DEVICES", None)
+        sys.modules["genomad.modules.nn_classification"] = ref_mod
+        import genomad.modules
+        genomad.modules.nn_classification = ref_mod
+
+
+def _gloo_main_worker(rank, world, port, fasta, out_dir, q):
+    os.environ["CUDA_VISIBLE_DEVICES"] = "-1"                  # as left behind by the reference module's import
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    from tests.gloo_comm import GlooComm
+    comm = GlooComm(rank, world, port)
+    for attempt in range(2):                                    # second pass: the resume path, decided on rank 0
+        nnc.main(fasta, out_dir, False, 128, False, 1, False, False, _backend=FakeBackend(), _comm=comm)
+        assert "CUDA_VISIBLE_DEVICES" not in os.environ
+    q.put(rank)
+    comm.close()
+
+
+def test_main_under_world_size_2_equals_single_process(tmp_path):
+    """main() with two ranks (gloo transport, fake scorer): rank 0 writes the same files as one process,
+    no rank hangs on the resume pass although only rank 0 reads the files that decide it, and the
+    CUDA_VISIBLE_DEVICES=-1 the reference leaves behind is gone before any device work."""
+    mp = pytest.importorskip("torch.multiprocessing")
+    import socket
+    fa = tmp_path / "meta.fna"
+    _write_sharding_fasta(fa)
+    nnc.main(fa, tmp_path / "single", False, 128, False, 1, False, False, _backend=FakeBackend())
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_gloo_main_worker, args=(r, 2, port, str(fa), str(tmp_path / "multi"), q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    done = sorted(q.get(timeout=180) for _ in procs)
+    for p in procs:
+        p.join(timeout=180)
+        assert p.exitcode == 0
+    assert done == [0, 1]
+    a = np.load(tmp_path / "single" / "meta_nn_classification" / "meta_nn_classification.npz")
+    b = np.load(tmp_path / "multi" / "meta_nn_classification" / "meta_nn_classification.npz")
+    assert list(a["contig_names"]) == list(b["contig_names"]) and np.array_equal(a["predictions"], b["predictions"])
+    assert ((tmp_path / "single" / "meta_nn_classification" / "meta_nn_classification.tsv").read_text()
+            == (tmp_path / "multi" / "meta_nn_classification" / "meta_nn_classification.tsv").read_text())
+    assert not list((tmp_path / "multi" / "meta_nn_classification").glob("*.tmp*"))
+
+
+def test_check_fasta_in_chunks_and_non_ascii_headers(tmp_path):
+    p = tmp_path / "u.fna"
+    p.write_bytes(">caf\xc3\xa9 one\nACGT\n>b\xff raw\nGG\nTT\n>c\nAC\n".replace("\\", "\\").encode("latin-1"))
+    names, seq, offsets = sequence.read_fasta_packed(p)
+    assert names[0] == "caf\u00e9" and len(names) == 3 and bytes(seq) == b"ACGTGGTTAC"
+    assert sequence.check_fasta(p) and sequence.check_fasta(p, chunk_bytes=8)
+    dup = tmp_path / "d.fna"
+    dup.write_text(">a\nAC\n" * 1 + ">b\nGG\n" * 50 + ">a\nTT\n")
+    assert not sequence.check_fasta(dup) and not sequence.check_fasta(dup, chunk_bytes=16)
+    big = tmp_path / "meta.fna"
+    _write_sharding_fasta(big)
+    whole = sequence.read_fasta_packed(big)
+    parts = [sequence.pack_text(c) for c in sequence.iter_text_chunks(big, 20000)]
+    assert len(parts) > 3 and [n for pt in parts for n in pt[0]] == list(whole[0])
+    assert b"".join(bytes(pt[1]) for pt in parts) == bytes(whole[1])
