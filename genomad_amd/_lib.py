@@ -68,6 +68,7 @@ SIGNATURES = {
     "gnn_segment_mean": (_int, [_vp, _vp, _vp, _i64, _i64, _vp]),
     "gnn_span_byte_count": (_int, [_vp, _vp, _vp, _vp, _i64, _int, _vp]),
     "gnn_classify_spans": (_int, [_vp, _vp, _vp, _vp, _i64, _int, _vp]),
+    "gnn_classify_contigs": (_int, [_vp, _vp, _int, _i64, _vp, _i64, _int, _int, _vp, _vp, _i64, C.POINTER(_i64)]),
     "gnn_debug_forward": (_int, [_vp, _vp, _i64, _int, _vp, C.POINTER(Taps)]),
     "gnn_synth_windows_dev": (_int, [_vp, _u64, _i64, _i64, _vp]),
     "gnn_profile_enable": (_int, [_vp, _int]),

@@ -90,29 +90,45 @@ static int ensure_ws(gnn_ctx* ctx, int64_t chunk, int64_t x_chunk) {
             p = static_cast<std::remove_reference_t<decltype(p)>>(q);
             return rc;
         };
-        int rc;
-        if ((rc = re(ws.mp, (size_t)chunk * 2 * NPAIR * sizeof(float)))) return rc;
-        if ((rc = re(ws.m, (size_t)chunk * 2 * NP * sizeof(float)))) return rc;
-        if ((rc = re(ws.yp, (size_t)chunk * 2 * POOLED * C * sizeof(float)))) return rc;
-        if ((rc = re(ws.logits, (size_t)chunk * 2 * POOLED * sizeof(float)))) return rc;
-        if ((rc = re(ws.alpha, (size_t)chunk * 2 * POOLED * sizeof(float)))) return rc;
-        if ((rc = re(ws.feat, (size_t)chunk * FEAT * sizeof(float)))) return rc;
+        // a failed allocation leaves NO workspace behind (chunk = x_chunk = 0), never a half-grown one whose
+        // stale size would let a later, smaller call launch kernels on null pointers
+        int rc = GNN_OK;
+        if (!rc) rc = re(ws.mp, (size_t)chunk * 2 * NPAIR * sizeof(float));
+        if (!rc) rc = re(ws.m, (size_t)chunk * 2 * NP * sizeof(float));
+        if (!rc) rc = re(ws.yp, (size_t)chunk * 2 * POOLED * C * sizeof(float));
+        if (!rc) rc = re(ws.logits, (size_t)chunk * 2 * POOLED * sizeof(float));
+        if (!rc) rc = re(ws.alpha, (size_t)chunk * 2 * POOLED * sizeof(float));
+        if (!rc) rc = re(ws.feat, (size_t)chunk * FEAT * sizeof(float));
+        if (rc) {
+            free_ws(ws);
+            return rc;
+        }
         ws.chunk = chunk;
     }
     if (ws.x_chunk < x_chunk) {
         GNN_HIP(hipStreamSynchronize(ctx->stream));
+        ws.x_chunk = 0;
         for (int i = 0; i < 3; ++i) {
             if (ws.x[i]) (void)hipFree(ws.x[i]);
             ws.x[i] = nullptr;
-            void* q = nullptr;
-            int rc = dev_buffer(ctx, (size_t)x_chunk * T * C * sizeof(float), &q);
-            if (rc) return rc;
-            ws.x[i] = static_cast<float*>(q);
         }
         if (ws.tokens) (void)hipFree(ws.tokens);
+        ws.tokens = nullptr;
+        for (int i = 0; i < 3; ++i) {
+            void* q = nullptr;
+            int rc = dev_buffer(ctx, (size_t)x_chunk * T * C * sizeof(float), &q);
+            if (rc) {
+                free_ws(ws);
+                return rc;
+            }
+            ws.x[i] = static_cast<float*>(q);
+        }
         void* q = nullptr;
         int rc = dev_buffer(ctx, (size_t)x_chunk * T * sizeof(uint16_t), &q);
-        if (rc) return rc;
+        if (rc) {
+            free_ws(ws);
+            return rc;
+        }
         ws.tokens = static_cast<uint16_t*>(q);
         ws.x_chunk = x_chunk;
     }
@@ -129,8 +145,7 @@ static int check_ctx(gnn_ctx* ctx) {
 }
 
 // One pass of the hot path over n windows whose bases are on the device.
-static int classify_chunks(gnn_ctx* ctx, const uint8_t* bases_dev, int64_t n, int precision,
-                           float* scores_dev) {
+int classify_chunks(gnn_ctx* ctx, const uint8_t* bases_dev, int64_t n, int precision, float* scores_dev) {
     if (!ctx->has_weights) {
         set_error("gnn_load_weights has not been called");
         return GNN_ERR_STATE;
@@ -253,6 +268,7 @@ int gnn_destroy(gnn_ctx* ctx) {
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
     if (ctx->comm || ctx->comm_scratch) (void)gnn_comm_destroy(ctx);
+    free_contig_ws(ctx);
     free_ws(ctx->ws);
     for (void* p : ctx->owned) (void)hipFree(p);
     for (auto& s : ctx->prof)

@@ -93,6 +93,8 @@ struct Workspace {
     float* feat = nullptr;      // (chunk, 256)
 };
 
+struct ContigWorkspace;
+
 struct ProfileSlot {
     double total_ms = 0.0;
     int64_t launches = 0;
@@ -115,6 +117,7 @@ struct gnn_ctx {
     std::vector<void*> owned;   // device allocations to free at destroy
     int cu_count = 0;
     unsigned long long* phase_cycles = nullptr;   // non-null: fused kernel runs its instrumented build
+    gnn::ContigWorkspace* contig_ws = nullptr;    // gnn_contigs.hip: persistent buffers of gnn_classify_contigs
     // RCCL communicator of this ctx (gnn_comm.hip); ncclComm_t kept opaque here
     void* comm = nullptr;
     int comm_ranks = 1, comm_rank = 0;
@@ -135,6 +138,9 @@ int launch_materialize(gnn_ctx* ctx, const uint8_t* seq, const int64_t* starts, 
 int launch_front_f32(gnn_ctx* ctx, const uint8_t* bases, int64_t n);         // -> ws.mp, ws.yp (+ ws.x)
 int launch_front_fused(gnn_ctx* ctx, const uint8_t* bases, int64_t n, int precision);  // -> ws.mp, ws.yp
 int launch_backend(gnn_ctx* ctx, int64_t n, int precision, float* scores_dev);   // ws.mp, ws.yp -> scores
+// one pass of the hot path over n windows whose padded bases are on the device (gnn_api.hip)
+int classify_chunks(gnn_ctx* ctx, const uint8_t* bases_dev, int64_t n, int precision, float* scores_dev);
+void free_contig_ws(gnn_ctx* ctx);     // gnn_contigs.hip
 
 int launch_front_c8(gnn_ctx* ctx, const uint8_t* bases, int64_t n);             // GNN_PREC_F16C8 -> ws.mp, ws.yp
 

@@ -120,7 +120,7 @@ class NNEngine:
             db.free()
             do.free()
 
-    def classify(self, bases, precision="bf16x3") -> np.ndarray:
+    def classify(self, bases, precision="f16c8") -> np.ndarray:
         """(n,6000) uint8 windows -> (n,3) float32 class scores (chromosome, plasmid, virus)."""
         b = self._check_bases(bases)
         out = np.empty((len(b), _lib.CLASSES), dtype=np.float32)
@@ -128,7 +128,7 @@ class NNEngine:
                                     out.ctypes.data))
         return out
 
-    def classify_dev(self, bases_ptr: int, n: int, scores_ptr: int, precision="bf16x3"):
+    def classify_dev(self, bases_ptr: int, n: int, scores_ptr: int, precision="f16c8"):
         """Asynchronous: device pointers in and out, enqueued on the engine's stream."""
         check(self.lib.gnn_classify_dev(self.ctx, bases_ptr, int(n), _lib.PRECISIONS[precision],
                                         scores_ptr))
@@ -150,28 +150,44 @@ class NNEngine:
         return scores, arrays
 
     def classify_contigs(self, seq: np.ndarray, offsets: np.ndarray, single_window: bool = False,
-                         precision="bf16x3"):
+                         precision="f16c8"):
         """Contig front end: packed raw contig bytes -> per-contig scores.
 
         Does what generate_data + the predict loop + segment_mean do (nn_classification.py:54-82,
-        :316-320) without per-window host objects: the packed buffer is uploaded once, candidate
-        windows are spans computed with numpy, the N-content rule is evaluated by a device kernel on
-        the raw bytes, kept spans are upper-cased/padded/tokenised/classified on the device and
-        averaged per contig on the device.  Returns (contig_scores (n_contigs,3), contig_ids of the
-        kept windows).
+        :316-320) in ONE library call (``gnn_classify_contigs``): candidate windows are cut in native code,
+        the packed buffer goes up in pieces on a copy stream while earlier pieces are classified, the
+        N-content rule, upper-casing, padding, tokenising, classification and the per-contig mean run on the
+        device and the window scores never leave it.  Returns (contig_scores (n_contigs, 3), contig ids of
+        the kept windows).
         """
         seq = np.ascontiguousarray(seq, dtype=np.uint8)
-        buf = self.alloc(max(seq.nbytes, 1))
-        try:
-            buf.upload(seq)
-            return self.classify_contigs_dev(buf.ptr, offsets, single_window, precision)
-        finally:
-            buf.free()
+        return self._classify_contigs(seq.ctypes.data, 1, seq.nbytes, offsets, single_window, precision)
 
     def classify_contigs_dev(self, seq_ptr: int, offsets: np.ndarray, single_window: bool = False,
-                             precision="bf16x3"):
+                             precision="f16c8"):
         """Same as :meth:`classify_contigs` for a packed contig buffer that is already resident in
         HBM (``seq_ptr`` = device address of byte 0, ``offsets`` = (n_contigs+1,) byte offsets)."""
+        offsets = np.ascontiguousarray(offsets, dtype=np.int64)
+        return self._classify_contigs(seq_ptr, 0, int(offsets[-1]) if len(offsets) else 0, offsets, single_window, precision)
+
+    def _classify_contigs(self, seq_ptr, on_host, seq_bytes, offsets, single_window, precision):
+        offsets = np.ascontiguousarray(offsets, dtype=np.int64)
+        if offsets.ndim != 1 or len(offsets) < 1:
+            raise ValueError("offsets must hold n_contigs + 1 byte offsets")
+        n_contigs = len(offsets) - 1
+        scores = np.zeros((n_contigs, _lib.CLASSES), dtype=np.float32)
+        cap = int(((np.diff(offsets) + _lib.WINDOW - 1) // _lib.WINDOW).sum()) if n_contigs else 0
+        ids = np.empty(max(cap, 1), dtype=np.int64)
+        n = C.c_int64()
+        check(self.lib.gnn_classify_contigs(self.ctx, seq_ptr, int(on_host), int(seq_bytes), offsets.ctypes.data, n_contigs,
+                                            int(bool(single_window)), _lib.PRECISIONS[precision], scores.ctypes.data,
+                                            ids.ctypes.data, cap, C.byref(n)))
+        return scores, ids[:n.value].copy()
+
+    def classify_contigs_spans(self, seq_ptr: int, offsets: np.ndarray, single_window: bool = False,
+                               precision="f16c8"):
+        """The same result assembled on the host from the span-level entry points (gnn_span_byte_count,
+        gnn_classify_spans, gnn_segment_mean) — kept as an independently coded cross-check for the tests."""
         from . import sequence as S
         offsets = np.ascontiguousarray(offsets, dtype=np.int64)
         n_contigs = len(offsets) - 1

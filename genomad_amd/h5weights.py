@@ -14,6 +14,17 @@ Keras weight names of model.py:14-45 / igloo.py:129-188, and assigns them by NAM
 
 Every schema tensor must be filled exactly once, otherwise a ValueError lists what is missing or
 ambiguous.  ``convert(h5_path, npz_path)`` writes the schema ``.npz`` that ``main()`` loads.
+
+Cross-check against what Keras itself would do.  ``load_weights`` on a legacy H5 file
+(nn_classification.py:310) does not match by name: it walks the root attribute ``layer_names`` and each
+layer group's ``weight_names`` attribute and hands the datasets, IN THAT ORDER, to the layers of the model in
+their order.  When the file carries these attributes (every file Keras wrote does), :func:`load_h5` reads
+them and verifies that (a) every dataset it assigned is one Keras would load, (b) no weight Keras would load
+is left unassigned, and (c) wherever the name + shape matching had to order two look-alikes (conv2 / conv3,
+IGLOO head A / B, the encoder's / the head's BatchNormalization) the attribute order says the same — a
+disagreement raises instead of silently swapping layers.  Weight names with and without the ``:0`` suffix
+(Keras 2 / Keras 3 writers) and nested-model groups (the encoder is a Model used as a layer, model.py:39) are
+handled.
 """
 import ctypes as C
 import ctypes.util
@@ -65,6 +76,14 @@ def _h5():
         "H5Dcreate2": (_hid, [_hid, C.c_char_p, _hid, _hid, _hid, _hid, _hid]),
         "H5Dwrite": (C.c_int, [_hid, _hid, _hid, _hid, _hid, C.c_void_p]), "H5Dclose": (C.c_int, [_hid]),
         "H5Lexists": (C.c_int, [_hid, C.c_char_p, _hid]),
+        "H5Aexists": (C.c_int, [_hid, C.c_char_p]), "H5Aopen": (_hid, [_hid, C.c_char_p, _hid]),
+        "H5Aclose": (C.c_int, [_hid]), "H5Aget_type": (_hid, [_hid]), "H5Aget_space": (_hid, [_hid]),
+        "H5Aread": (C.c_int, [_hid, _hid, C.c_void_p]), "H5Awrite": (C.c_int, [_hid, _hid, C.c_void_p]),
+        "H5Acreate2": (_hid, [_hid, C.c_char_p, _hid, _hid, _hid, _hid]),
+        "H5Tget_size": (C.c_size_t, [_hid]), "H5Tis_variable_str": (C.c_int, [_hid]),
+        "H5Tcopy": (_hid, [_hid]), "H5Tset_size": (C.c_int, [_hid, C.c_size_t]),
+        "H5Sget_simple_extent_npoints": (C.c_int64, [_hid]),
+        "H5Gopen2": (_hid, [_hid, C.c_char_p, _hid]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(lib, name)
@@ -116,7 +135,80 @@ def read_datasets(path) -> dict:
     return out
 
 
-def write_datasets(path, datasets: dict) -> None:
+def _read_str_attr(h, oid, name):
+    """A string-array attribute (fixed- or variable-length, as h5py / Keras write them) as a list of str; None
+    if the object has no such attribute."""
+    if h.H5Aexists(oid, name.encode()) <= 0:
+        return None
+    aid = h.H5Aopen(oid, name.encode(), _H5P_DEFAULT)
+    tid, sid = h.H5Aget_type(aid), h.H5Aget_space(aid)
+    n = max(int(h.H5Sget_simple_extent_npoints(sid)), 0)
+    out = []
+    if n:
+        if h.H5Tis_variable_str(tid) > 0:
+            buf = (C.c_char_p * n)()
+            if h.H5Aread(aid, tid, buf) < 0:
+                raise OSError(f"cannot read attribute {name}")
+            out = [(b or b"").decode("utf-8") for b in buf]
+        else:
+            size = int(h.H5Tget_size(tid))
+            raw = C.create_string_buffer(size * n)
+            if h.H5Aread(aid, tid, raw) < 0:
+                raise OSError(f"cannot read attribute {name}")
+            out = [raw.raw[i * size:(i + 1) * size].split(b"\0", 1)[0].decode("utf-8") for i in range(n)]
+    h.H5Sclose(sid)
+    h.H5Tclose(tid)
+    h.H5Aclose(aid)
+    return out
+
+
+def read_keras_order(path):
+    """Dataset paths in the order Keras' legacy ``load_weights`` consumes them: for every name in the root
+    attribute ``layer_names``, the entries of that group's ``weight_names`` attribute.  None if the file has
+    no ``layer_names`` attribute (not written by Keras).  A ``model_weights`` top-level group (full-model
+    ``model.save`` files) is looked into as well."""
+    h = _h5()
+    fid = h.H5Fopen(str(path).encode(), _H5F_ACC_RDONLY, _H5P_DEFAULT)
+    if fid < 0:
+        raise OSError(f"cannot open HDF5 file {path}")
+    try:
+        root, prefix = fid, ""
+        layers = _read_str_attr(h, fid, "layer_names")
+        gid = None
+        if layers is None and h.H5Lexists(fid, b"model_weights", _H5P_DEFAULT) > 0:
+            gid = h.H5Gopen2(fid, b"model_weights", _H5P_DEFAULT)
+            layers = _read_str_attr(h, gid, "layer_names")
+            root, prefix = gid, "model_weights/"
+        if layers is None:
+            if gid is not None:
+                h.H5Gclose(gid)
+            return None
+        order = []
+        for layer in layers:
+            g = h.H5Gopen2(root, layer.encode(), _H5P_DEFAULT)
+            if g < 0:
+                raise ValueError(f"layer_names lists '{layer}' but the file has no such group")
+            for wn in _read_str_attr(h, g, "weight_names") or []:
+                order.append(f"{prefix}{layer}/{wn}")
+            h.H5Gclose(g)
+        if gid is not None:
+            h.H5Gclose(gid)
+        return order
+    finally:
+        h.H5Fclose(fid)
+
+
+def write_keras_legacy(path, layers) -> None:
+    """Write a weights file the way Keras' legacy HDF5 saver lays it out (tests only): ``layers`` = list of
+    (layer_name, [(weight_name, array), ...]); root attribute ``layer_names``, one group per layer with the
+    attribute ``weight_names`` and one dataset per weight at <layer_name>/<weight_name>."""
+    write_datasets(path, {f"{ln}/{wn}": a for ln, ws in layers for wn, a in ws},
+                   _attrs=[("", "layer_names", [ln for ln, _ in layers])] +
+                          [(ln, "weight_names", [wn for wn, _ in ws]) for ln, ws in layers],
+                   _groups=[ln for ln, _ in layers])
+
+
+def write_datasets(path, datasets: dict, _attrs=(), _groups=()) -> None:
     """Write {dataset path: array} (float32 / int32) creating intermediate groups — used by the tests
     to build Keras-shaped fixtures; not part of the product path."""
     h = _h5()
@@ -139,6 +231,25 @@ def write_datasets(path, datasets: dict) -> None:
         h.H5Dwrite(did, t, 0, 0, _H5P_DEFAULT, a.ctypes.data)
         h.H5Dclose(did)
         h.H5Sclose(sid)
+    for g in _groups:                                   # layers without weights still get their (empty) group
+        if h.H5Lexists(fid, g.encode(), _H5P_DEFAULT) <= 0:
+            h.H5Gclose(h.H5Gcreate2(fid, g.encode(), _H5P_DEFAULT, _H5P_DEFAULT, _H5P_DEFAULT))
+    c_s1 = _hid.in_dll(h, "H5T_C_S1_g").value
+    for group, name, strings in _attrs:                 # numpy 'S' arrays, as h5py stores them: fixed-length strings
+        enc = [s_.encode("utf-8") for s_ in strings]
+        size = max([len(e) for e in enc] + [1])
+        tid = h.H5Tcopy(c_s1)
+        h.H5Tset_size(tid, size)
+        dims = (C.c_uint64 * 1)(len(enc))
+        sid = h.H5Screate_simple(1, dims, None)
+        oid = h.H5Oopen(fid, (group or "/").encode(), _H5P_DEFAULT)
+        aid = h.H5Acreate2(oid, name.encode(), tid, sid, _H5P_DEFAULT, _H5P_DEFAULT)
+        buf = C.create_string_buffer(b"".join(e.ljust(size, b"\0") for e in enc), max(size * len(enc), 1))
+        h.H5Awrite(aid, tid, buf)
+        h.H5Aclose(aid)
+        h.H5Oclose(oid)
+        h.H5Sclose(sid)
+        h.H5Tclose(tid)
     h.H5Fclose(fid)
 
 
@@ -146,19 +257,35 @@ def _natural(s):
     return [int(t) if t.isdigit() else t for t in re.split(r"(\d+)", s)]
 
 
-def assign(datasets: dict) -> dict:
-    """Map {h5 path: array} to the repo's weight schema by leaf name + shape (see module docstring)."""
+def assign(datasets: dict, keras_order=None) -> dict:
+    """Map {h5 path: array} to the repo's weight schema by leaf name + shape (see module docstring);
+    ``keras_order`` (from :func:`read_keras_order`) switches on the cross-check against the order Keras'
+    own loader would follow."""
     items = []
     for path, arr in datasets.items():
         leaf = path.rsplit("/", 1)[-1].split(":")[0]
         if leaf in _LEAVES:
             items.append((path.rsplit("/", 1)[0] if "/" in path else "", leaf, arr))
 
+    used = {}                       # id(array) -> schema key, to report what was (not) consumed
+    path_of = {id(a): p for p, a in datasets.items()}
+    rank = {p: i for i, p in enumerate(keras_order)} if keras_order is not None else None
+
     def pick(leaf, shape):
         # order by LAYER name (last group component: conv1d_1 < conv1d_2, batch_normalization <
         # batch_normalization_1), not by full path: the encoder's layers may sit in a nested group
-        return sorted([(g, a) for g, l, a in items if l == leaf and tuple(a.shape) == shape],
-                      key=lambda x: (_natural(x[0].rsplit("/", 1)[-1]), _natural(x[0])))
+        c = sorted([(g, a) for g, l, a in items if l == leaf and tuple(a.shape) == shape],
+                   key=lambda x: (_natural(x[0].rsplit("/", 1)[-1]), _natural(x[0])))
+        if rank is not None and len(c) > 1:
+            # Keras assigns look-alike layers in the order of layer_names / weight_names: it must agree
+            pos = [rank.get(path_of[id(a)]) for _, a in c]
+            if None in pos:
+                raise ValueError(f"'{leaf}' {shape}: a candidate dataset is not listed in the file's weight_names")
+            if pos != sorted(pos):
+                raise ValueError(
+                    f"'{leaf}' {shape}: layer-name order {[g for g, _ in c]} disagrees with the order of the file's "
+                    f"layer_names/weight_names attributes (positions {pos}) — refusing to guess which is which")
+        return c
 
     def one(leaf, shape, what):
         c = pick(leaf, shape)
@@ -201,11 +328,22 @@ def assign(datasets: dict) -> dict:
         out[f"{name}_beta"] = in_group(g, "beta", (512,), name)
         out[f"{name}_mean"] = in_group(g, "moving_mean", (512,), name)
         out[f"{name}_var"] = in_group(g, "moving_variance", (512,), name)
+    if rank is not None:
+        assigned = {path_of[id(a)] for a in out.values() if id(a) in path_of}
+        stray = sorted(assigned - set(rank))
+        if stray:
+            raise ValueError(f"datasets assigned by name + shape but absent from weight_names (Keras would not load them): {stray}")
+        unassigned = sorted(p for p in rank if p in datasets and p not in assigned)
+        if unassigned:
+            raise ValueError(f"weights Keras would load but the name + shape matching did not place: {unassigned}")
+        missing = sorted(p for p in rank if p not in datasets)
+        if missing:
+            raise ValueError(f"weight_names lists datasets the file does not contain: {missing}")
     return W.validate(out)
 
 
 def load_h5(path) -> dict:
-    return assign(read_datasets(path))
+    return assign(read_datasets(path), read_keras_order(path))
 
 
 def convert(h5_path, npz_path) -> None:

@@ -168,6 +168,21 @@ int gnn_span_byte_count(gnn_ctx* ctx, const uint8_t* seq_dev, const int64_t* sta
 int gnn_classify_spans(gnn_ctx* ctx, const uint8_t* seq_dev, const int64_t* starts_host,
                        const int32_t* lens_host, int64_t n_spans, int precision, float* scores_host);
 
+/* The whole contig front end in one call: replaces generate_data (window cutting seq_windows(seq, 6000, 2500,
+ * max_windows), the skip rule, upper-casing, padding, tokenising: nn_classification.py:54-82), the predict loop
+ * (:316-318) and tf.math.segment_mean (:320) for a packed buffer of raw contig bytes: contig c =
+ * seq[offsets[c] .. offsets[c+1]) (n_contigs + 1 offsets, non-decreasing).  seq is a HOST pointer when
+ * seq_on_host != 0 (uploaded in pieces on a copy stream while earlier pieces are classified) and a device
+ * pointer otherwise.  contig_scores_host[n_contigs][3] = mean class scores of the contig's kept windows;
+ * window_ids_host (capacity >= number of CANDIDATE windows, sum over contigs of ceil(len / 6000) is enough)
+ * receives the contig index of every KEPT window in order, *n_windows_out their number — the `contig_ids` the
+ * reference stores in <prefix>_seq_window_id.npz.  Window scores never leave the device; every buffer is
+ * persistent in the ctx.  Synchronous (returns when the scores are on the host). */
+int gnn_classify_contigs(gnn_ctx* ctx, const uint8_t* seq, int seq_on_host, int64_t seq_bytes,
+                         const int64_t* offsets_host, int64_t n_contigs, int single_window, int precision,
+                         float* contig_scores_host, int64_t* window_ids_host, int64_t ids_capacity,
+                         int64_t* n_windows_out);
+
 /* ---- host-side FASTA record packer (no GPU needed) ------------------------------------------------ */
 /* replaces the line loop of sequence.read_fasta(path, strip_n) (genomad/sequence.py:96-121) on an
  * in-memory text buffer (already decompressed, newlines normalised to '\n').

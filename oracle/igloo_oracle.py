@@ -54,12 +54,12 @@ def conv1_gather(tokens, kernel, bias):
     return out
 
 
-def conv1_dense_onehot(tokens, kernel, bias):
+def conv1_dense_onehot(tokens, kernel, bias, conv=None):
     """Reference-faithful conv1: materialise tf.one_hot(depth=257) and contract (model.py:11)."""
     B, T = tokens.shape
     oh = np.zeros((B, T, ONE_HOT_DEPTH), dtype=kernel.dtype)
     np.put_along_axis(oh, tokens[..., None], 1, axis=2)
-    return causal_conv(oh, kernel, bias)
+    return (conv or causal_conv)(oh, kernel, bias)
 
 
 def causal_conv(x, kernel, bias):
@@ -71,6 +71,21 @@ def causal_conv(x, kernel, bias):
     cols = np.lib.stride_tricks.as_strided(xp, shape=(B, T, K, C), strides=(s0, s1, s1, s2))
     out = cols.reshape(B * T, K * C) @ kernel.reshape(K * C, F)
     return out.reshape(B, T, F) + bias
+
+
+def causal_conv_shifted(x, kernel, bias):
+    """Same convolution as :func:`causal_conv` without the im2col copy: one (B*T, C) @ (C, F) product per tap,
+    accumulated into the rows it reaches (tap k of output row t reads input row t + k - (K-1)).  Used by the
+    timed CPU baseline (bench.py); differs from causal_conv only in the f32 summation order."""
+    B, T, C = x.shape
+    K, _, F = kernel.shape
+    out = np.empty((B, T, F), dtype=x.dtype)
+    out[...] = bias
+    for k in range(K):
+        shift = K - 1 - k
+        y = (x[:, :T - shift].reshape(-1, C) @ kernel[k]).reshape(B, T - shift, F)
+        out[:, shift:] += y
+    return out
 
 
 def igloo_kernel_literal(y, patches, w_mult, w_summer, w_bias, w_qk, w_v, taps=None):
@@ -113,7 +128,8 @@ def _bn(x, gamma, beta, mean, var):
     return gamma * (x - mean) / np.sqrt(var + np.asarray(BN_EPS, dtype=x.dtype)) + beta
 
 
-def forward(tokens, weights, dtype=np.float32, dense_onehot=False, literal=True, return_taps=False):
+def forward(tokens, weights, dtype=np.float32, dense_onehot=False, literal=True, return_taps=False,
+            shifted_conv=False):
     """Scores (B, 3) for ``tokens`` (B, 5997) ints in [0, 256].
 
     dtype        np.float32 ("reference-like") or np.float64 ("truth")
@@ -121,14 +137,18 @@ def forward(tokens, weights, dtype=np.float32, dense_onehot=False, literal=True,
     literal      use the op-for-op IGLOO kernel (else the closed form)
     return_taps  also return a dict of intermediates
                  (x1, x2, x3, mA, alphaA, ypA, mB, alphaB, ypB, f, h1, h2, logits)
+    shifted_conv convolutions as six shifted matrix products instead of im2col (faster; bench.py baseline)
     """
     tokens = np.asarray(tokens, dtype=np.int64)
     w = {k: (np.asarray(v).astype(dtype) if np.asarray(v).dtype.kind == "f" else np.asarray(v))
          for k, v in weights.items()}
-    c1 = conv1_dense_onehot if dense_onehot else conv1_gather
-    x1 = _lrelu(c1(tokens, w["conv1_kernel"], w["conv1_bias"]))
-    x2 = _lrelu(causal_conv(x1, w["conv2_kernel"], w["conv2_bias"]))
-    x3 = _lrelu(causal_conv(x2, w["conv3_kernel"], w["conv3_bias"]))
+    conv = causal_conv_shifted if shifted_conv else causal_conv
+    if dense_onehot:
+        x1 = _lrelu(conv1_dense_onehot(tokens, w["conv1_kernel"], w["conv1_bias"], conv))
+    else:
+        x1 = _lrelu(conv1_gather(tokens, w["conv1_kernel"], w["conv1_bias"]))
+    x2 = _lrelu(conv(x1, w["conv2_kernel"], w["conv2_bias"]))
+    x3 = _lrelu(conv(x2, w["conv3_kernel"], w["conv3_bias"]))
     ig = igloo_kernel_literal if literal else igloo_kernel_closed
     tA, tB = {}, {}
     fA = ig(x1, w["iglooA_patches"], w["iglooA_w_mult"], w["iglooA_w_summer"], w["iglooA_w_bias"],

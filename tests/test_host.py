@@ -433,6 +433,116 @@ def test_keras_h5_weight_ingestion_roundtrip(synth_weights, tmp_path):
         h5.load_h5(tmp_path / "bad.h5")
 
 
+def _keras_legacy_layers(w, suffix=":0", swap_convs=False):
+    """The reference classifier (model.py:34-45) as Keras' legacy HDF5 saver lays it out: the encoder is a
+    nested Model -> ONE group holding all its weights, trainable ones first in layer order, then the
+    non-trainable ones (random_patches of both IGLOO kernels, igloo.py:129-135; BatchNormalization moving
+    statistics); Dense / BatchNormalization of the head are layers of the outer model; layers without weights
+    (input, activations, dropout) are listed with empty groups."""
+    def igloo(layer, h):
+        return [(f"{layer}/{k}{suffix}", w[f"{h}_{k}"]) for k in ("w_mult", "w_summer", "w_bias", "w_qk", "w_v")]
+    c2, c3 = ("conv1d_2", "conv1d_1") if swap_convs else ("conv1d_1", "conv1d_2")
+    enc = ([(f"conv1d/kernel{suffix}", w["conv1_kernel"]), (f"conv1d/bias{suffix}", w["conv1_bias"])]
+           + igloo("igloo1d_kernel", "iglooA")
+           + [(f"{c2}/kernel{suffix}", w["conv2_kernel"]), (f"{c2}/bias{suffix}", w["conv2_bias"]),
+              (f"{c3}/kernel{suffix}", w["conv3_kernel"]), (f"{c3}/bias{suffix}", w["conv3_bias"])]
+           + igloo("igloo1d_kernel_1", "iglooB")
+           + [(f"dense/kernel{suffix}", w["enc_dense_kernel"]), (f"dense/bias{suffix}", w["enc_dense_bias"]),
+              (f"batch_normalization/gamma{suffix}", w["enc_bn_gamma"]), (f"batch_normalization/beta{suffix}", w["enc_bn_beta"]),
+              (f"igloo1d_kernel/random_patches{suffix}", w["iglooA_patches"]),
+              (f"igloo1d_kernel_1/random_patches{suffix}", w["iglooB_patches"]),
+              (f"batch_normalization/moving_mean{suffix}", w["enc_bn_mean"]),
+              (f"batch_normalization/moving_variance{suffix}", w["enc_bn_var"])])
+    return [("input_2", []), ("model", enc),
+            ("dense_1", [(f"dense_1/kernel{suffix}", w["head_dense_kernel"]), (f"dense_1/bias{suffix}", w["head_dense_bias"])]),
+            ("batch_normalization_1", [(f"batch_normalization_1/gamma{suffix}", w["head_bn_gamma"]),
+                                       (f"batch_normalization_1/beta{suffix}", w["head_bn_beta"]),
+                                       (f"batch_normalization_1/moving_mean{suffix}", w["head_bn_mean"]),
+                                       (f"batch_normalization_1/moving_variance{suffix}", w["head_bn_var"])]),
+            ("activation_1", []), ("dropout_2", []),
+            ("dense_2", [(f"dense_2/kernel{suffix}", w["out_dense_kernel"]), (f"dense_2/bias{suffix}", w["out_dense_bias"])])]
+
+
+def test_keras_legacy_saver_layout_and_attribute_cross_check(synth_weights, tmp_path):
+    """A file laid out like Keras' legacy saver writes it (root attribute layer_names, per-layer weight_names,
+    nested encoder group; weight names with ':0' as Keras 2 writes them and without as Keras 3 does) is read
+    into the schema, and the order Keras' own loader would follow (layer_names / weight_names) is cross-checked
+    against the name + shape matching: a file whose attribute order contradicts the layer-name order, a dataset
+    Keras would not load, and a listed-but-absent weight are all rejected loudly."""
+    h5 = pytest.importorskip("genomad_amd.h5weights")
+    try:
+        h5._h5()
+    except RuntimeError as exc:
+        pytest.skip(str(exc))
+    w = synth_weights
+    for suffix in (":0", ""):
+        path = tmp_path / f"nn_classifier{len(suffix)}.h5"
+        h5.write_keras_legacy(path, _keras_legacy_layers(w, suffix))
+        order = h5.read_keras_order(path)
+        assert order[0] == f"model/conv1d/kernel{suffix}" and order[-1] == f"dense_2/dense_2/bias{suffix}" and len(order) == 32
+        got = h5.load_h5(path)
+        assert set(got) == set(w) and all(np.array_equal(got[k], w[k]) for k in w)
+    # conv2's tensors stored under the name conv1d_2 and conv3's under conv1d_1, while the attribute order still
+    # lists conv2's first: name order and Keras' order disagree -> refuse
+    bad = tmp_path / "swapped.h5"
+    h5.write_keras_legacy(bad, _keras_legacy_layers(w, ":0", swap_convs=True))
+    with pytest.raises(ValueError, match="disagrees"):
+        h5.load_h5(bad)
+    # a look-alike dataset that is not in weight_names (Keras would never load it)
+    layers = _keras_legacy_layers(w)
+    stray = tmp_path / "stray.h5"
+    h5.write_datasets(stray, {**{f"{ln}/{wn}": a for ln, ws in layers for wn, a in ws},
+                              "model/conv1d_9/kernel:0": w["conv3_kernel"]},
+                      _attrs=[("", "layer_names", [ln for ln, _ in layers])] +
+                             [(ln, "weight_names", [wn for wn, _ in ws]) for ln, ws in layers],
+                      _groups=[ln for ln, _ in layers])
+    with pytest.raises(ValueError, match="weight_names"):
+        h5.load_h5(stray)
+    # weight_names lists a weight whose dataset is missing
+    layers = _keras_legacy_layers(w)
+    short = tmp_path / "short.h5"
+    h5.write_datasets(short, {f"{ln}/{wn}": a for ln, ws in layers for wn, a in ws if wn != "dense_2/bias:0"},
+                      _attrs=[("", "layer_names", [ln for ln, _ in layers])] +
+                             [(ln, "weight_names", [wn for wn, _ in ws]) for ln, ws in layers],
+                      _groups=[ln for ln, _ in layers])
+    with pytest.raises(ValueError):
+        h5.load_h5(short)
+    # files without the attributes (not written by Keras) still load by name + shape alone
+    plain = tmp_path / "plain.h5"
+    h5.write_datasets(plain, {f"{ln}/{wn}": a for ln, ws in layers for wn, a in ws})
+    assert h5.read_keras_order(plain) is None
+    assert all(np.array_equal(h5.load_h5(plain)[k], w[k]) for k in w)
+
+
+def test_gen_patches_follows_the_reference_initializer():
+    """synthetic.gen_patches restates gen_filters_igloo(4, 2100, 5997, return_sequences=False,
+    build_backbone=False) (igloo.py:220-302, the initializer of `random_patches`, :106-115).  The reference
+    function is pure numpy, so it is RUN IN PLACE here: same shape and dtype kind, every patch = 4 distinct
+    positions in [0, 5997) sorted ascending, and — both being uniform draws — matching position statistics."""
+    from oracle import reference_harness as rh
+    if not rh.available():
+        pytest.skip("needs the reference checkout")
+    from genomad_amd import synthetic
+    nn = rh.load_reference_network()
+    import importlib
+    igloo = importlib.import_module("genomad.neural_network.igloo")
+    np.random.seed(5)
+    ref = np.asarray(igloo.gen_filters_igloo(4, 2100, 5997, return_sequences=False, build_backbone=False))
+    mine = synthetic.gen_patches(np.random.default_rng(5))
+    assert ref.shape == mine.shape == (2100, 4, 1)
+    for p in (ref.astype(np.int64), mine.astype(np.int64)):
+        flat = p[:, :, 0]
+        assert flat.min() >= 0 and flat.max() < 5997
+        assert (np.diff(flat, axis=1) > 0).all()                 # 4 DISTINCT positions, ascending
+    r, m = ref[:, :, 0].astype(np.float64), mine[:, :, 0].astype(np.float64)
+    # order statistics of 4 uniform draws without replacement from [0, 5997): E = 5997 * k / 5
+    for k in range(4):
+        expect = 5997 * (k + 1) / 5
+        assert abs(r[:, k].mean() - expect) < 120 and abs(m[:, k].mean() - expect) < 120
+    assert abs(r.std() - m.std()) < 60
+    assert nn is not None
+
+
 def test_tfrecord_wire_format(tmp_path):
     """TFRecord framing + tf.train.Example encoding without TensorFlow."""
     from genomad_amd import _lib, synthetic, tfrecord
