@@ -151,7 +151,7 @@ int classify_chunks(gnn_ctx* ctx, const uint8_t* bases_dev, int64_t n, int preci
         return GNN_ERR_STATE;
     }
     if (precision != GNN_PREC_F32 && precision != GNN_PREC_BF16X3 && precision != GNN_PREC_BF16 &&
-        precision != GNN_PREC_F16C8) {
+        precision != GNN_PREC_F16C8 && precision != GNN_PREC_F16X3) {
         set_error("unknown precision " + std::to_string(precision));
         return GNN_ERR_ARG;
     }

@@ -356,7 +356,7 @@ int launch_backend(gnn_ctx* ctx, int64_t n, int precision, float* scores_dev) {
         hipLaunchKernelGGL(logits_mfma_kernel<3>, qk_grid, dim3(256), 0, ctx->stream, ws.m, qf0, qf1, (int)n, ws.logits);
     else if (precision == GNN_PREC_BF16)
         hipLaunchKernelGGL(logits_mfma_kernel<1>, qk_grid, dim3(256), 0, ctx->stream, ws.m, qf0, qf1, (int)n, ws.logits);
-    else    // GNN_PREC_F32: exact f32 FMAs
+    else    // GNN_PREC_F32 and GNN_PREC_F16X3 (the accuracy-first fused mode): exact f32 FMAs
         hipLaunchKernelGGL(logits_kernel, dim3((POOLED + LQ - 1) / LQ, (unsigned)((n + LW - 1) / LW), 2), dim3(256), 0,
                            ctx->stream, ws.m, d.w_qk[0], d.w_qk[1], (int)n, ws.logits);
     hipLaunchKernelGGL(attn_kernel, dim3((unsigned)n, 2), dim3(256), 0, ctx->stream, ws.logits, ws.yp, ws.alpha,

@@ -17,11 +17,28 @@
 // (7e-3) and fp16 (1e-3) miss.  Weights are pre-split and pre-shuffled on the host into MFMA
 // fragment order, so a wave loads a fragment as one coalesced 1 KiB global_load_dwordx4 straight
 // into VGPRs (L2 resident); wave w owns output channels 32w..32w+31 for all 128 rows.
+//
+// F16 = true (GNN_PREC_F16X3) runs the same three passes on v_mfma_f32_32x32x16_f16 with f16 limbs:
+// hi = f16(x), lo = f16(x - hi) carry 11 + 11 significant bits instead of 8 + 8, which puts the result
+// in f32 class (emulation: max |dscore| 6.5e-7 against 1.6e-5 for the bf16 split, profiles/
+// r02_precision_study.json) at the same cost; the price is the f16 range (|activation| < 65504).
 #include <cstring>
 
 #include "gnn_fused_common.h"
 
 namespace gnn {
+
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+
+// one 32x32x16 MFMA on 16-bit operands given as raw 128-bit fragments
+template <bool F16>
+__device__ __forceinline__ f32x16 mma16(uint4 a, uint4 b, f32x16 c) {
+    if constexpr (F16)
+        return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+    else
+        return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+}
 
 // One GEMM tile of the wave: 4 m-blocks (128 rows of the LDS buffer) x 1 n-block (32 columns),
 // K = NTAPS * 128.  SWAP: D = W^T X^T (columns of D are positions; used by the convs so that a
@@ -59,36 +76,24 @@ __device__ __forceinline__ void load_x(XFrag<PASSES>& f, const unsigned char* __
     }
 }
 
-template <bool SWAP, int PASSES>
+template <bool SWAP, int PASSES, bool F16>
 __device__ __forceinline__ void mfma_block(const WFrag<PASSES>& w, const XFrag<PASSES>& x, f32x16 (&acc)[4]) {
-    const bf16x8 wh = __builtin_bit_cast(bf16x8, w.v[0]);
+    const uint4 wh = w.v[0];
     if constexpr (PASSES == 3) {
-        const bf16x8 wl = __builtin_bit_cast(bf16x8, w.v[1]);
+        const uint4 wl = w.v[1];
 #pragma unroll
-        for (int mb = 0; mb < 4; ++mb) {
-            const bf16x8 xh = __builtin_bit_cast(bf16x8, x.v[mb][0]);
-            acc[mb] = SWAP ? __builtin_amdgcn_mfma_f32_32x32x16_bf16(wl, xh, acc[mb], 0, 0, 0)
-                           : __builtin_amdgcn_mfma_f32_32x32x16_bf16(xh, wl, acc[mb], 0, 0, 0);
-        }
+        for (int mb = 0; mb < 4; ++mb) acc[mb] = SWAP ? mma16<F16>(wl, x.v[mb][0], acc[mb]) : mma16<F16>(x.v[mb][0], wl, acc[mb]);
 #pragma unroll
-        for (int mb = 0; mb < 4; ++mb) {
-            const bf16x8 xl = __builtin_bit_cast(bf16x8, x.v[mb][1]);
-            acc[mb] = SWAP ? __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh, xl, acc[mb], 0, 0, 0)
-                           : __builtin_amdgcn_mfma_f32_32x32x16_bf16(xl, wh, acc[mb], 0, 0, 0);
-        }
+        for (int mb = 0; mb < 4; ++mb) acc[mb] = SWAP ? mma16<F16>(wh, x.v[mb][1], acc[mb]) : mma16<F16>(x.v[mb][1], wh, acc[mb]);
     }
 #pragma unroll
-    for (int mb = 0; mb < 4; ++mb) {
-        const bf16x8 xh = __builtin_bit_cast(bf16x8, x.v[mb][0]);
-        acc[mb] = SWAP ? __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh, xh, acc[mb], 0, 0, 0)
-                       : __builtin_amdgcn_mfma_f32_32x32x16_bf16(xh, wh, acc[mb], 0, 0, 0);
-    }
+    for (int mb = 0; mb < 4; ++mb) acc[mb] = SWAP ? mma16<F16>(wh, x.v[mb][0], acc[mb]) : mma16<F16>(x.v[mb][0], wh, acc[mb]);
 }
 
 // One k-step region: the MFMAs of k-step k (fragments WCUR, XCUR) with the loads of later k-steps
 // spread between them (activations of k+1 from LDS, weights of k+3 from L2), so that the matrix
 // pipe never waits for a block of loads to issue.  The sched_group_barriers spell the interleave.
-template <bool SWAP, int PASSES>
+template <bool SWAP, int PASSES, bool F16>
 __device__ __forceinline__ void gemm_region(const WFrag<PASSES>& wcur, WFrag<PASSES>& wload, const XFrag<PASSES>& xcur,
                                             XFrag<PASSES>& xload, const unsigned char* __restrict__ xl,
                                             const uint4* __restrict__ wfrag, int ks_x, int ks_w, f32x16 (&acc)[4]) {
@@ -100,7 +105,7 @@ __device__ __forceinline__ void gemm_region(const WFrag<PASSES>& wcur, WFrag<PAS
 #ifndef GNN_ABL_NOW
     load_w(wload, wfrag, ks_w);
 #endif
-    mfma_block<SWAP, PASSES>(wcur, xcur, acc);
+    mfma_block<SWAP, PASSES, F16>(wcur, xcur, acc);
     if constexpr (PASSES == 3) {
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
@@ -124,7 +129,7 @@ __device__ __forceinline__ void gemm_region(const WFrag<PASSES>& wcur, WFrag<PAS
     __builtin_amdgcn_sched_barrier(0);
 }
 
-template <bool SWAP, int NTAPS, int PASSES>
+template <bool SWAP, int NTAPS, int PASSES, bool F16>
 __device__ __forceinline__ void gemm_tile(const unsigned char* __restrict__ xbuf,   // row of u=0, tap 0
                                           const uint4* __restrict__ wfrag,           // + nblk*2*64 + lane
                                           f32x16 (&acc)[4], int lane) {
@@ -140,32 +145,41 @@ __device__ __forceinline__ void gemm_tile(const unsigned char* __restrict__ xbuf
 #pragma unroll 1
     for (int ks = 0; ks < NK; ks += 4) {
         // clamped indices: the prefetches past the end are harmless re-reads
-        gemm_region<SWAP, PASSES>(w0, w3, xa, xb, xl, wfrag, ks + 1, min(ks + 3, NK - 1), acc);
-        gemm_region<SWAP, PASSES>(w1, w0, xb, xa, xl, wfrag, ks + 2, min(ks + 4, NK - 1), acc);
-        gemm_region<SWAP, PASSES>(w2, w1, xa, xb, xl, wfrag, ks + 3, min(ks + 5, NK - 1), acc);
-        gemm_region<SWAP, PASSES>(w3, w2, xb, xa, xl, wfrag, min(ks + 4, NK - 1), min(ks + 6, NK - 1), acc);
+        gemm_region<SWAP, PASSES, F16>(w0, w3, xa, xb, xl, wfrag, ks + 1, min(ks + 3, NK - 1), acc);
+        gemm_region<SWAP, PASSES, F16>(w1, w0, xb, xa, xl, wfrag, ks + 2, min(ks + 4, NK - 1), acc);
+        gemm_region<SWAP, PASSES, F16>(w2, w1, xa, xb, xl, wfrag, ks + 3, min(ks + 5, NK - 1), acc);
+        gemm_region<SWAP, PASSES, F16>(w3, w2, xb, xa, xl, wfrag, min(ks + 4, NK - 1), min(ks + 6, NK - 1), acc);
     }
 }
 
 typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 
-// LeakyReLU + split of two values into packed bf16 hi / lo words.  Written on pairs so that hipcc
-// selects the packed forms (v_pk_mul_f32, v_cvt_pk_bf16_f32 on both halves, v_pk_add_f32): 8 VALU
-// ops per pair instead of 14 for the scalar form.  hi = bf16(x) (RNE), lo = bf16(x - hi).
+// LeakyReLU + split of two values into packed 16-bit hi / lo words.  Written on pairs so that hipcc
+// selects the packed forms (v_pk_mul_f32, v_cvt_pk_bf16_f32 / v_cvt_pk_f16_f32 on both halves,
+// v_pk_add_f32).  hi = round16(x) (RNE), lo = round16(x - hi).
+template <bool F16>
 __device__ __forceinline__ void lrelu_split2(f32x2 v, uint32_t& hi, uint32_t& lo) {
     const f32x2 s = v * LRELU;
     v = f32x2{fmaxf(v[0], s[0]), fmaxf(v[1], s[1])};
-    hi = __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2));
-    const f32x2 back = {__uint_as_float(hi << 16), __uint_as_float(hi & 0xFFFF0000u)};
-    lo = __builtin_bit_cast(uint32_t, __builtin_convertvector(v - back, bf16x2));
+    if constexpr (F16) {
+        const f16x2 h = __builtin_convertvector(v, f16x2);
+        hi = __builtin_bit_cast(uint32_t, h);
+        const f32x2 back = {(float)h[0], (float)h[1]};
+        lo = __builtin_bit_cast(uint32_t, __builtin_convertvector(v - back, f16x2));
+    } else {
+        hi = __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2));
+        const f32x2 back = {__uint_as_float(hi << 16), __uint_as_float(hi & 0xFFFF0000u)};
+        lo = __builtin_bit_cast(uint32_t, __builtin_convertvector(v - back, bf16x2));
+    }
 }
 
-// conv1 gather epilogue of this kernel: 4 channels of one position -> bf16 hi / lo planes
-struct StoreBf16x2 {
+// conv1 gather epilogue of this kernel: 4 channels of one position -> 16-bit hi / lo planes
+template <bool F16>
+struct StoreSplit16 {
     static __device__ __forceinline__ void put(unsigned char* __restrict__ row, int cq, f32x4 v) {
         uint2 h, l;
-        lrelu_split2(f32x2{v[0], v[1]}, h.x, l.x);
-        lrelu_split2(f32x2{v[2], v[3]}, h.y, l.y);
+        lrelu_split2<F16>(f32x2{v[0], v[1]}, h.x, l.x);
+        lrelu_split2<F16>(f32x2{v[2], v[3]}, h.y, l.y);
         *reinterpret_cast<uint2*>(row + cq * 8) = h;
         *reinterpret_cast<uint2*>(row + cq * 8 + LO_OFF) = l;
     }
@@ -187,6 +201,7 @@ __device__ __forceinline__ void acc_init_bias(f32x16 (&acc)[4], const float* __r
 // conv epilogue: LeakyReLU (the bias is already in the accumulators), split to bf16 hi/lo, write
 // rows 5..132 of the output buffer.
 // C/D layout of 32x32 MFMA: column = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5).
+template <bool F16>
 __device__ __forceinline__ void conv_epilogue(unsigned char* __restrict__ obuf, const f32x16 (&acc)[4], int wave, int lane) {
 #pragma unroll
     for (int rg = 0; rg < 4; ++rg) {
@@ -194,8 +209,8 @@ __device__ __forceinline__ void conv_epilogue(unsigned char* __restrict__ obuf, 
 #pragma unroll
         for (int mb = 0; mb < 4; ++mb) {
             uint2 h, l;
-            lrelu_split2(f32x2{acc[mb][rg * 4], acc[mb][rg * 4 + 1]}, h.x, l.x);
-            lrelu_split2(f32x2{acc[mb][rg * 4 + 2], acc[mb][rg * 4 + 3]}, h.y, l.y);
+            lrelu_split2<F16>(f32x2{acc[mb][rg * 4], acc[mb][rg * 4 + 1]}, h.x, l.x);
+            lrelu_split2<F16>(f32x2{acc[mb][rg * 4 + 2], acc[mb][rg * 4 + 3]}, h.y, l.y);
             unsigned char* o = obuf + (CARRY + mb * 32 + (lane & 31)) * ROWB + f0 * 2;
             *reinterpret_cast<uint2*>(o) = h;
             *reinterpret_cast<uint2*>(o + LO_OFF) = l;
@@ -204,7 +219,7 @@ __device__ __forceinline__ void conv_epilogue(unsigned char* __restrict__ obuf, 
 }
 
 // y @ w_v on the current 128 rows + MaxPool1D(8) -> yp rows (igloo.py:208-210)
-template <int PASSES>
+template <int PASSES, bool F16>
 __device__ __forceinline__ void wv_pool(const unsigned char* __restrict__ xbuf, const uint4* __restrict__ wfrag,
                                         float* __restrict__ yp_w, int t0, int wave, int lane) {
     f32x16 acc[4];
@@ -212,7 +227,7 @@ __device__ __forceinline__ void wv_pool(const unsigned char* __restrict__ xbuf, 
     for (int mb = 0; mb < 4; ++mb)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[mb][r] = 0.f;
-    gemm_tile<false, 1, PASSES>(xbuf + CARRY * ROWB, wfrag, acc, lane);
+    gemm_tile<false, 1, PASSES, F16>(xbuf + CARRY * ROWB, wfrag, acc, lane);
     // rows 8rg..8rg+3 of a 32-row block sit in lanes 0-31, rows 8rg+4..8rg+7 in lanes 32-63: the
     // 8-row max is 4 registers + one exchange with lane^32 (v_permlane32_swap, no LDS round trip).
     // All 16 pooled values are reduced first, then stored under one predicate.
@@ -240,6 +255,7 @@ __device__ __forceinline__ void wv_pool(const unsigned char* __restrict__ xbuf, 
 // channels per lane; 4 entries per lane group are in flight at once (their loads are independent:
 // weights stream linearly in entry order, rows come from LDS) so the L2 latency is paid once per
 // batch.  Results are written in entry order (contiguous), the back end un-permutes.
+template <bool F16>
 __device__ __forceinline__ void m_partials(const unsigned char* __restrict__ xbuf, const float* __restrict__ weff,
                                            const int32_t* __restrict__ pos, int t0, int e_begin, int e_end,
                                            float* __restrict__ mp_w, int wave, int lane) {
@@ -274,8 +290,15 @@ __device__ __forceinline__ void m_partials(const unsigned char* __restrict__ xbu
             float s = 0.f;
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
-                const float x0 = __uint_as_float(hv[k] << 16) + __uint_as_float(lv[k] << 16);
-                const float x1 = __uint_as_float(hv[k] & 0xFFFF0000u) + __uint_as_float(lv[k] & 0xFFFF0000u);
+                float x0, x1;
+                if constexpr (F16) {
+                    const f16x2 hh = __builtin_bit_cast(f16x2, hv[k]), ll = __builtin_bit_cast(f16x2, lv[k]);
+                    x0 = (float)hh[0] + (float)ll[0];
+                    x1 = (float)hh[1] + (float)ll[1];
+                } else {
+                    x0 = __uint_as_float(hv[k] << 16) + __uint_as_float(lv[k] << 16);
+                    x1 = __uint_as_float(hv[k] & 0xFFFF0000u) + __uint_as_float(lv[k] & 0xFFFF0000u);
+                }
                 s = fmaf(x0, wv[2 * k], s);
                 s = fmaf(x1, wv[2 * k + 1], s);
             }
@@ -297,7 +320,7 @@ __device__ __forceinline__ void m_partials(const unsigned char* __restrict__ xbu
 //   B2  MFMA: conv3 loop [read bufY]               helpers: conv1 gather of step s+1 -> bufX rows 5..132
 //   B3  MFMA: conv3 epilogue -> bufY (x3)          helpers: x2 carry rows -> bufY rows 0..4
 //   B4  MFMA: w_v B [read bufY]
-template <int PASSES, bool PROF>
+template <int PASSES, bool PROF, bool F16>
 __global__ __launch_bounds__(512, 2) void fused_front_kernel(FusedArgs a) {
     __shared__ __attribute__((aligned(16))) unsigned char smem[SMEM_BYTES];
     unsigned char* bufX = smem;
@@ -327,7 +350,7 @@ __global__ __launch_bounds__(512, 2) void fused_front_kernel(FusedArgs a) {
         toks[j] = (uint16_t)pair_row(token_state(bases, t), token_state(bases, t + 1));
     }
     __syncthreads();
-    if (helper) conv1_gather<0, FT / 8, StoreBf16x2>(bufX, toks, a.conv1_k, a.conv1_b, 0, ht);
+    if (helper) conv1_gather<0, FT / 8, StoreSplit16<F16>>(bufX, toks, a.conv1_k, a.conv1_b, 0, ht);
     // static priority for the matrix waves (measured neutral against no priority and against
     // prioritising the helpers; kept so the matrix pipe never loses an issue slot to a helper)
     else __builtin_amdgcn_s_setprio(2);
@@ -342,31 +365,31 @@ __global__ __launch_bounds__(512, 2) void fused_front_kernel(FusedArgs a) {
         if constexpr (PROF) tick_ = step == 0 ? __builtin_readcyclecounter() : tick_;
         if (!helper) {
             GNN_TICK(7)
-            wv_pool<PASSES>(bufX, vfrag[0], yp_w[0], t0, hw, lane);
+            wv_pool<PASSES, F16>(bufX, vfrag[0], yp_w[0], t0, hw, lane);
             GNN_TICK(0)
             f32x16 acc[4];
             acc_init_bias(acc, a.conv_b[0], hw, lane);
-            gemm_tile<true, KS, PASSES>(bufX, cfrag[0], acc, lane);
+            gemm_tile<true, KS, PASSES, F16>(bufX, cfrag[0], acc, lane);
             GNN_TICK(1)
             __syncthreads();                                                     // ---- B1
             GNN_TICK(2)
-            conv_epilogue(bufY, acc, hw, lane);
+            conv_epilogue<F16>(bufY, acc, hw, lane);
             __syncthreads();                                                     // ---- B2
             GNN_TICK(3)
             acc_init_bias(acc, a.conv_b[1], hw, lane);
-            gemm_tile<true, KS, PASSES>(bufY, cfrag[1], acc, lane);
+            gemm_tile<true, KS, PASSES, F16>(bufY, cfrag[1], acc, lane);
             GNN_TICK(4)
             __syncthreads();                                                     // ---- B3
             GNN_TICK(5)
-            conv_epilogue(bufY, acc, hw, lane);
+            conv_epilogue<F16>(bufY, acc, hw, lane);
             __syncthreads();                                                     // ---- B4
             GNN_TICK(6)
-            wv_pool<PASSES>(bufY, vfrag[1], yp_w[1], t0, hw, lane);
+            wv_pool<PASSES, F16>(bufY, vfrag[1], yp_w[1], t0, hw, lane);
         } else {
             if (step > 0)
-                m_partials(bufY, a.weff[1], a.pos_sorted[1], t0 - FT, a.bucket_ptr[1][step - 1], a.bucket_ptr[1][step],
+                m_partials<F16>(bufY, a.weff[1], a.pos_sorted[1], t0 - FT, a.bucket_ptr[1][step - 1], a.bucket_ptr[1][step],
                            mp_w[1], hw, lane);
-            m_partials(bufX, a.weff[0], a.pos_sorted[0], t0, a.bucket_ptr[0][step], a.bucket_ptr[0][step + 1], mp_w[0], hw, lane);
+            m_partials<F16>(bufX, a.weff[0], a.pos_sorted[0], t0, a.bucket_ptr[0][step], a.bucket_ptr[0][step + 1], mp_w[0], hw, lane);
             uint4 carry = make_uint4(0, 0, 0, 0);
             const int cr = ht >> 5, cc = ht & 31;        // 5 rows x 32 chunks of 16 B (hi+lo = 512 B)
             if (ht < CARRY * 32) carry = *reinterpret_cast<const uint4*>(bufX + (FT + cr) * ROWB + cc * 16);
@@ -375,10 +398,10 @@ __global__ __launch_bounds__(512, 2) void fused_front_kernel(FusedArgs a) {
             if (ht < CARRY * 32) *reinterpret_cast<uint4*>(bufX + cr * ROWB + cc * 16) = carry;
             // bufX is free from B1 on: the first part of the next step's gather runs while the matrix
             // waves are in their conv2 epilogue (no MFMA traffic to compete with), the rest beside conv3
-            if (step + 1 < FSTEPS) conv1_gather<0, GNN_GATHER_EARLY, StoreBf16x2>(bufX, toks, a.conv1_k, a.conv1_b, t0 + FT, ht);
+            if (step + 1 < FSTEPS) conv1_gather<0, GNN_GATHER_EARLY, StoreSplit16<F16>>(bufX, toks, a.conv1_k, a.conv1_b, t0 + FT, ht);
             __syncthreads();                                                     // ---- B2
             if constexpr (PROF) tick_ = __builtin_readcyclecounter();
-            if (step + 1 < FSTEPS) conv1_gather<GNN_GATHER_EARLY, FT / 8, StoreBf16x2>(bufX, toks, a.conv1_k, a.conv1_b, t0 + FT, ht);
+            if (step + 1 < FSTEPS) conv1_gather<GNN_GATHER_EARLY, FT / 8, StoreSplit16<F16>>(bufX, toks, a.conv1_k, a.conv1_b, t0 + FT, ht);
             if (ht < CARRY * 32) carry = *reinterpret_cast<const uint4*>(bufY + (FT + cr) * ROWB + cc * 16);
             GNN_TICK(9)
             __syncthreads();                                                     // ---- B3
@@ -388,7 +411,7 @@ __global__ __launch_bounds__(512, 2) void fused_front_kernel(FusedArgs a) {
         }
     }
     if (helper)
-        m_partials(bufY, a.weff[1], a.pos_sorted[1], (FSTEPS - 1) * FT, a.bucket_ptr[1][FSTEPS - 1], a.bucket_ptr[1][FSTEPS],
+        m_partials<F16>(bufY, a.weff[1], a.pos_sorted[1], (FSTEPS - 1) * FT, a.bucket_ptr[1][FSTEPS - 1], a.bucket_ptr[1][FSTEPS],
                    mp_w[1], hw, lane);
     if constexpr (PROF) {
         if (tid == 0)
@@ -415,7 +438,19 @@ static inline float bf16_to_f32(uint16_t h) {
 // Wmat (K x N, row major) -> [kstep Kpad/16][nblk Npad/32][plane hi,lo][lane 64][8] bf16 in the operand
 // layout of v_mfma_f32_32x32x16_bf16: lane l holds W[kstep*16 + (l>>5)*8 + e][nblk*32 + (l&31)];
 // rows >= K and columns >= N are zero.
-static std::vector<uint16_t> pack_frags(const float* wmat, int K, int N) {
+static uint16_t f16_bits(float f) {
+    const _Float16 h = (_Float16)f;          // round to nearest even
+    uint16_t u;
+    memcpy(&u, &h, 2);
+    return u;
+}
+static float f16_value(uint16_t u) {
+    _Float16 h;
+    memcpy(&h, &u, 2);
+    return (float)h;
+}
+
+static std::vector<uint16_t> pack_frags(const float* wmat, int K, int N, bool f16 = false) {
     const int ksteps = (K + 15) / 16, nblks = (N + 31) / 32;
     std::vector<uint16_t> out((size_t)ksteps * nblks * 2 * 64 * 8, 0);
     for (int ks = 0; ks < ksteps; ++ks)
@@ -425,8 +460,8 @@ static std::vector<uint16_t> pack_frags(const float* wmat, int K, int N) {
                     const int k = ks * 16 + (l >> 5) * 8 + e, n = nb * 32 + (l & 31);
                     if (k >= K || n >= N) continue;
                     const float v = wmat[(size_t)k * N + n];
-                    const uint16_t hi = bf16_rne(v);
-                    const uint16_t lo = bf16_rne(v - bf16_to_f32(hi));
+                    const uint16_t hi = f16 ? f16_bits(v) : bf16_rne(v);
+                    const uint16_t lo = f16 ? f16_bits(v - f16_value(hi)) : bf16_rne(v - bf16_to_f32(hi));
                     const size_t base = ((size_t)(ks * nblks + nb) * 2) * 64 * 8;
                     out[base + (size_t)l * 8 + e] = hi;
                     out[base + 64 * 8 + (size_t)l * 8 + e] = lo;
@@ -453,20 +488,23 @@ int pack_fused_weights(gnn_ctx* ctx, const gnn_weights* w) {
         if ((rc = upload_vec(ctx, pack_frags(ck[i], KS * C, C), &d.conv_frag[i]))) return rc;
         if ((rc = upload_vec(ctx, pack_frags(ig[i]->w_v, C, C), &d.wv_frag[i]))) return rc;
         if ((rc = upload_vec(ctx, pack_frags(ig[i]->w_qk, NP, POOLED), &d.wqk_frag[i]))) return rc;
+        if ((rc = upload_vec(ctx, pack_frags(ck[i], KS * C, C, true), &d.conv_frag_h[i]))) return rc;
+        if ((rc = upload_vec(ctx, pack_frags(ig[i]->w_v, C, C, true), &d.wv_frag_h[i]))) return rc;
     }
     return GNN_OK;
 }
 
 int launch_front_fused(gnn_ctx* ctx, const uint8_t* bases, int64_t n, int precision) {
     const DeviceWeights& d = ctx->w;
+    const bool f16 = precision == GNN_PREC_F16X3;
     FusedArgs a;
     a.bases = bases;
     a.conv1_k = d.conv1_pairs;
     a.conv1_b = d.conv1_b;
     for (int i = 0; i < 2; ++i) {
-        a.conv_frag[i] = reinterpret_cast<const uint4*>(d.conv_frag[i]);
+        a.conv_frag[i] = reinterpret_cast<const uint4*>(f16 ? d.conv_frag_h[i] : d.conv_frag[i]);
         a.conv_b[i] = d.conv_b[i];
-        a.wv_frag[i] = reinterpret_cast<const uint4*>(d.wv_frag[i]);
+        a.wv_frag[i] = reinterpret_cast<const uint4*>(f16 ? d.wv_frag_h[i] : d.wv_frag[i]);
         a.weff[i] = d.weff_sorted[i];
         a.pos_sorted[i] = d.pos_sorted[i];
         a.bucket_ptr[i] = d.bucket_ptr[i];
@@ -475,12 +513,16 @@ int launch_front_fused(gnn_ctx* ctx, const uint8_t* bases, int64_t n, int precis
     a.yp = ctx->ws.yp;
     a.cycles = ctx->phase_cycles;
     const bool prof = ctx->phase_cycles != nullptr;
-    if (precision == GNN_PREC_BF16X3) {
-        if (prof) hipLaunchKernelGGL((fused_front_kernel<3, true>), dim3((unsigned)n), dim3(512), 0, ctx->stream, a);
-        else hipLaunchKernelGGL((fused_front_kernel<3, false>), dim3((unsigned)n), dim3(512), 0, ctx->stream, a);
+    const dim3 grid((unsigned)n), block(512);
+    if (f16) {
+        if (prof) hipLaunchKernelGGL((fused_front_kernel<3, true, true>), grid, block, 0, ctx->stream, a);
+        else hipLaunchKernelGGL((fused_front_kernel<3, false, true>), grid, block, 0, ctx->stream, a);
+    } else if (precision == GNN_PREC_BF16X3) {
+        if (prof) hipLaunchKernelGGL((fused_front_kernel<3, true, false>), grid, block, 0, ctx->stream, a);
+        else hipLaunchKernelGGL((fused_front_kernel<3, false, false>), grid, block, 0, ctx->stream, a);
     } else {
-        if (prof) hipLaunchKernelGGL((fused_front_kernel<1, true>), dim3((unsigned)n), dim3(512), 0, ctx->stream, a);
-        else hipLaunchKernelGGL((fused_front_kernel<1, false>), dim3((unsigned)n), dim3(512), 0, ctx->stream, a);
+        if (prof) hipLaunchKernelGGL((fused_front_kernel<1, true, false>), grid, block, 0, ctx->stream, a);
+        else hipLaunchKernelGGL((fused_front_kernel<1, false, false>), grid, block, 0, ctx->stream, a);
     }
     GNN_HIP(hipGetLastError());
     return GNN_OK;

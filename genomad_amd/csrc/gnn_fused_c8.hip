@@ -20,8 +20,8 @@
 //  * fp8 operands of 32x32x64: lane l = row (or column) l & 31; its bytes 0-15 are elements
 //    16*(l>>5) .. +15 of K block 0 and its bytes 16-31 the same elements of K block 1; the scale of
 //    block 0 comes from lanes 0-31, the scale of block 1 from lanes 32-63 (byte OPSEL of the scale VGPR).
-//  * v_cvt_pk_fp8_f32 rounds to nearest even, saturates only up to 464 and returns NaN above: inputs
-//    are clamped to +-448 first.  v_cvt_scalef32_pk_fp8_f32 converts x / scale.
+//  * v_cvt_pk_fp8_f32 rounds to nearest even, saturates only up to 464 and returns NaN above, and so does
+//    v_cvt_scalef32_pk_fp8_f32 (which converts x / scale): inputs are clamped to +-448 first.
 //
 // LDS row (528 B, same stride as the bf16 kernel): 128 ch f16 | 128 ch e4m3(x) | 128 ch e4m3((x - f16 x) 2^11) | pad
 #include <cmath>
@@ -238,11 +238,13 @@ __device__ __forceinline__ void lrelu_split4_c8(f32x4 v, uint2& h, uint32_t& x8,
     int p = __builtin_amdgcn_cvt_pk_fp8_f32(__builtin_amdgcn_fmed3f(x0, -lim, lim), __builtin_amdgcn_fmed3f(x1, -lim, lim), 0, false);
     p = __builtin_amdgcn_cvt_pk_fp8_f32(__builtin_amdgcn_fmed3f(x2, -lim, lim), __builtin_amdgcn_fmed3f(x3, -lim, lim), p, true);
     x8 = (uint32_t)p;
-    // x / scale with scale = 2^-11: the residual times 2^11 (|.| <= |x| / 2, no overflow when x8 has none)
-    const float inv = 1.0f / (float)(1 << XL_SHIFT);
+    // x / scale with scale = 2^-11: the residual times 2^11.  |residual| <= half an f16 ulp = 2^(E-11) for
+    // x in [2^E, 2^(E+1)), so the scaled residual reaches 2^E: beyond the e4m3 range once |x| >= 512 — clamped
+    // like x8 (the conversion returns NaN, not the largest finite value, above 464)
+    const float inv = 1.0f / (float)(1 << XL_SHIFT), rlim = lim * inv;
     i16x2 q = {0, 0};
-    q = __builtin_amdgcn_cvt_scalef32_pk_fp8_f32(q, r0, r1, inv, false);
-    q = __builtin_amdgcn_cvt_scalef32_pk_fp8_f32(q, r2, r3, inv, true);
+    q = __builtin_amdgcn_cvt_scalef32_pk_fp8_f32(q, __builtin_amdgcn_fmed3f(r0, -rlim, rlim), __builtin_amdgcn_fmed3f(r1, -rlim, rlim), inv, false);
+    q = __builtin_amdgcn_cvt_scalef32_pk_fp8_f32(q, __builtin_amdgcn_fmed3f(r2, -rlim, rlim), __builtin_amdgcn_fmed3f(r3, -rlim, rlim), inv, true);
     xl8 = __builtin_bit_cast(uint32_t, q);
 }
 

@@ -8,8 +8,10 @@ bytes in a file in the node-local temp directory; the other ranks read it; every
 ``ncclCommInitRank`` on its own device.  (One node, as the bench contract says; a shared directory can be
 named with GENOMAD_AMD_RDZV_DIR otherwise.)
 """
+import contextlib
 import ctypes as C
 import os
+import sys
 import tempfile
 import time
 from pathlib import Path
@@ -53,6 +55,20 @@ def _id_file(seq: int) -> Path:
     return base / f"genomad_amd_rccl_{tag}.id"
 
 
+@contextlib.contextmanager
+def _c_stdout_to_stderr():
+    """RCCL prints a version banner to the C-level stdout when the first communicator is created; callers such
+    as bench.py promise exactly one JSON line there.  File descriptor 1 is pointed at stderr for the duration."""
+    sys.stdout.flush()
+    saved = os.dup(1)
+    try:
+        os.dup2(2, 1)
+        yield
+    finally:
+        os.dup2(saved, 1)
+        os.close(saved)
+
+
 class RcclComm:
     """Transport over ``gnn_comm_*`` for the engine's context (see sharding.py for the interface)."""
 
@@ -64,7 +80,8 @@ class RcclComm:
         _SEQ += 1
         uid = (C.c_uint8 * ID_BYTES)()
         if self.rank == 0:
-            check(self.lib.gnn_comm_unique_id(uid))
+            with _c_stdout_to_stderr():
+                check(self.lib.gnn_comm_unique_id(uid))
             tmp = path.with_suffix(f".tmp{os.getpid()}")
             tmp.write_bytes(bytes(uid))
             os.replace(tmp, path)
@@ -75,8 +92,9 @@ class RcclComm:
                     raise TimeoutError(f"rank {self.rank}: no RCCL unique id at {path} after {timeout:.0f} s")
                 time.sleep(0.01)
             C.memmove(uid, path.read_bytes(), ID_BYTES)
-        check(self.lib.gnn_comm_init(self.ctx, self.world, self.rank, uid))
-        self.barrier()
+        with _c_stdout_to_stderr():
+            check(self.lib.gnn_comm_init(self.ctx, self.world, self.rank, uid))
+            self.barrier()
         if self.rank == 0:
             try:
                 path.unlink()

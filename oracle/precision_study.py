@@ -102,8 +102,11 @@ def int_limbs(x, n, axis_scale):
 # A scheme turns (x rows, w matrix) into a list of (x_limb, w_limb) products to be summed, and says
 # how the activations are stored (what the pair-product path reads back).
 class Scheme:
-    def __init__(self, name, cost, xsplit, wsplit, terms, note=""):
+    def __init__(self, name, cost, xsplit, wsplit, terms, note="", stored=None):
         self.name, self.cost, self.xsplit, self.wsplit, self.terms, self.note = name, cost, xsplit, wsplit, terms, note
+        # what the pair-product path reads back from LDS: by default the sum of all activation limbs; the
+        # correction schemes keep [hi, coarse image of x, image of the residual] and read hi + residual image
+        self.stored = stored or (lambda limbs: sum(l for l in limbs if l is not None))
 
 
 def _float_scheme(name, fmt, terms, cost, note=""):
@@ -121,12 +124,38 @@ def _corr_x(lo_fmt, mx):
     return f
 
 
+_HI_PLUS_RESIDUAL = lambda l: l[0] + l[2]   # noqa: E731
+
+
 def _corr_w(lo_fmt):
     """weights (static): [fp16 hi, MX image of w, MX image of the fp16 residual], blocks along K"""
     def f(w):
         hi = rnd(w, "fp16")
         return [hi, rnd_mx(w, lo_fmt, axis=0), rnd_mx(w - hi, lo_fmt, axis=0)]
     return f
+
+
+def _corr_w_best(w):
+    """f16(w) may be either neighbour of w: pick, per weight, the one whose residual the MX-e4m3 image represents
+    with the smaller error (block scales from the round-to-nearest residuals, so the choice is local)."""
+    w = np.asarray(w, dtype=np.float64)
+    near = rnd(w, "fp16")
+    ulp = np.exp2(np.maximum(np.floor(np.log2(np.maximum(np.abs(near), 1e-300))), -14) - 10)
+    other = near + np.where(w >= near, ulp, -ulp)
+    best_h, best_l, best_e = near, None, None
+    for cand in (near, other):
+        res = w - cand
+        img = rnd_mx(res, "e4m3", axis=0)
+        err = np.abs(res - img)
+        if best_e is None:
+            best_h, best_l, best_e = cand.copy(), img.copy(), err
+        else:
+            take = err < best_e
+            best_h = np.where(take, cand, best_h)
+            best_l = np.where(take, img, best_l)
+            best_e = np.minimum(err, best_e)
+    # one consistent MX image of the final residuals (block scales follow the chosen residuals)
+    return [best_h, rnd_mx(w, "e4m3", axis=0), rnd_mx(w - best_h, "e4m3", axis=0)]
 
 
 HH, HL, LH, LL = (0, 0), (0, 1), (1, 0), (1, 1)
@@ -141,22 +170,35 @@ SCHEMES = [
     _float_scheme("fp16x2 (hh+hl: x 1 limb, w 2)", "fp16", [HH, HL], 2.0),
     _float_scheme("fp16x3", "fp16", [HH, HL, LH], 3.0),
     Scheme("fp16 + e4m3 corrections (x8*wl8 + xl8*w8)", 2.0, _corr_x("e4m3", False), _corr_w("e4m3"),
-           [(0, 0), (1, 2), (2, 1)], "MX fp8 MFMA, K-concatenated: one 32x32x64 per 32 channels"),
-    Scheme("fp16 + e5m2 corrections", 2.0, _corr_x("e5m2", False), _corr_w("e5m2"), [(0, 0), (1, 2), (2, 1)]),
+           [(0, 0), (1, 2), (2, 1)], "MX fp8 MFMA, K-concatenated: one 32x32x64 per 32 channels", _HI_PLUS_RESIDUAL),
+    Scheme("fp16 + e5m2 corrections", 2.0, _corr_x("e5m2", False), _corr_w("e5m2"), [(0, 0), (1, 2), (2, 1)], "", _HI_PLUS_RESIDUAL),
     Scheme("fp16 + e2m3 (fp6, MX both sides) corrections", 1.5, _corr_x("e2m3", True), _corr_w("e2m3"),
-           [(0, 0), (1, 2), (2, 1)]),
+           [(0, 0), (1, 2), (2, 1)], "", _HI_PLUS_RESIDUAL),
     Scheme("fp16 + e3m2 (bf6, MX both sides) corrections", 1.5, _corr_x("e3m2", True), _corr_w("e3m2"),
-           [(0, 0), (1, 2), (2, 1)]),
+           [(0, 0), (1, 2), (2, 1)], "", _HI_PLUS_RESIDUAL),
     Scheme("fp16 + e2m1 (fp4, MX both sides) corrections", 1.5, _corr_x("e2m1", True), _corr_w("e2m1"),
-           [(0, 0), (1, 2), (2, 1)]),
+           [(0, 0), (1, 2), (2, 1)], "", _HI_PLUS_RESIDUAL),
     Scheme("fp16 + e4m3 correction of x only (xl8*w8)", 1.5, _corr_x("e4m3", False), _corr_w("e4m3"),
-           [(0, 0), (2, 1)], "w single fp16"),
+           [(0, 0), (2, 1)], "w single fp16", _HI_PLUS_RESIDUAL),
     Scheme("fp16 + e4m3 correction of w only (x8*wl8)", 1.5, _corr_x("e4m3", False), _corr_w("e4m3"),
-           [(0, 0), (1, 2)], "x single fp16"),
+           [(0, 0), (1, 2)], "x single fp16", _HI_PLUS_RESIDUAL),
     Scheme("bf16 + e4m3 corrections", 2.0,
            lambda x: [rnd(x, "bf16"), rnd(x, "e4m3"), rnd((x - rnd(x, "bf16")) * 256.0, "e4m3") / 256.0],
            lambda w: [rnd(w, "bf16"), rnd_mx(w, "e4m3", 0), rnd_mx(w - rnd(w, "bf16"), "e4m3", 0)],
-           [(0, 0), (1, 2), (2, 1)]),
+           [(0, 0), (1, 2), (2, 1)], "", _HI_PLUS_RESIDUAL),
+    # 2.25-pass variants: one of the two residual terms in a second f16 pass (no scaling needed: f16 holds the
+    # residual directly, in its subnormal range for small weights), the other one in fp8 (K = 64 covers 64 channels)
+    Scheme("fp16 x (w 2 limbs) + e4m3 correction of x (xh*wh + xh*wl16 + xl8*w8)", 2.25,
+           lambda x: [rnd(x, "fp16"), None, rnd((x - rnd(x, "fp16")) * 2048.0, "e4m3") / 2048.0],
+           lambda w: [rnd(w, "fp16"), rnd_mx(w, "e4m3", 0), rnd(w - rnd(w, "fp16"), "fp16")],
+           [(0, 0), (0, 2), (2, 1)], "", _HI_PLUS_RESIDUAL),
+    Scheme("fp16 x (x 2 limbs) + e4m3 correction of w (xh*wh + xl16*wh + x8*wl8)", 2.25,
+           lambda x: [rnd(x, "fp16"), rnd(x, "e4m3"), rnd(x - rnd(x, "fp16"), "fp16")],
+           lambda w: [rnd(w, "fp16"), None, rnd_mx(w - rnd(w, "fp16"), "e4m3", 0)],
+           [(0, 0), (2, 0), (1, 2)], "", _HI_PLUS_RESIDUAL),
+    Scheme("fp16 + e4m3 corrections, weights rounded to the f16 neighbour with the better e4m3 residual", 2.0,
+           _corr_x("e4m3", False), lambda w: _corr_w_best(w), [(0, 0), (1, 2), (2, 1)],
+           "free at run time: the choice is made when the weights are packed", _HI_PLUS_RESIDUAL),
     # fixed point on the i8 MFMA: x scaled per window-step tile is not emulated here; per-row scale for x
     # (optimistic: the accumulator cannot mix row scales across conv taps) and per-column scale for w
     Scheme("int8 limbs x2/w2, 3 products (optimistic per-row x scale)", 1.5,
@@ -198,12 +240,7 @@ def forward(tokens, W, layer_scheme):
     x1 = f32(IO._lrelu(IO.conv1_gather(tokens, w["conv1_kernel"], w["conv1_bias"])))
 
     def stored(x, sch):            # what the LDS holds = what the pair products read back
-        l = sch.xsplit(x)
-        if len(l) == 1:
-            return l[0]
-        if len(l) == 2:
-            return l[0] + l[1]
-        return l[0] + l[2]         # fp16 hi + low-precision residual image
+        return sch.stored(sch.xsplit(x))
 
     def conv(x, name, sch):
         xl, wl = sch.xsplit(x), sch.wsplit(w[f"{name}_kernel"].reshape(6 * 128, 128))
@@ -275,6 +312,7 @@ def main():
     ap.add_argument("--windows", type=int, default=48)
     ap.add_argument("--seeds", type=int, nargs="+", default=[42, 43])
     ap.add_argument("--quick", action="store_true", help="only the headline schemes")
+    ap.add_argument("--only", nargs="+", default=None, help="substrings selecting schemes (no per-layer mixes)")
     ap.add_argument("--out", default=os.path.join(ROOT, "profiles", "r02_precision_study.json"))
     args = ap.parse_args()
     names = [s.name for s in SCHEMES]
@@ -283,6 +321,9 @@ def main():
                  ("fp16 + e2m3 (fp6, MX both sides) corrections", "fp16 + e4m3 corrections (x8*wl8 + xl8*w8)")]
     if args.quick:
         names = [n for n in names if n.startswith(("bf16x3", "fp16x3", "fp16 + e4m3 corrections", "fp16 + e2m3"))]
+        per_layer = []
+    if args.only:
+        names = [n for n in names if any(o in n for o in args.only)]
         per_layer = []
     rows = run(args.windows, args.seeds, names, per_layer)
     with open(args.out, "w") as f:

@@ -27,7 +27,7 @@ try:
     m = 64
     bases = synthetic.synth_windows(0, m)
     want = igloo_oracle.classify_windows(bases, W, np.float64)
-    for prec in ("f32", "bf16x3", "f16c8"):
+    for prec in ("f32", "bf16x3", "f16c8", "f16x3"):
         got = eng.classify(bases, prec)
         print(f"{prec}: max |dscore| vs fp64 oracle on {m} windows = {np.abs(got - want).max():.3e}")
 except Exception as exc:  # noqa: BLE001
@@ -46,7 +46,7 @@ for prec in ('bf16x3', 'f16c8'):
     print(f"{prec}: max |dscore| vs f32 device path on {mref} windows = {np.abs(ref - got).max():.3e}")
 names = ["wvA", "conv2 loop", "wait B1", "conv2 epi+B2", "conv3 loop", "wait B3", "conv3 epi+B4", "wvB+wait B0",
          "helper m-partials", "helper gather"]
-for prec in ('bf16x3', 'f16c8', 'bf16x3', 'f16c8'):
+for prec in ('bf16x3', 'f16c8', 'f16x3', 'bf16x3', 'f16c8', 'f16x3'):
     eng.classify_dev(bases.ptr, n, scores.ptr, prec); eng.sync()
     eng.profile_enable(True); eng.profile_reset()
     t = time.time()
