@@ -56,7 +56,7 @@ timed(E.DeviceBuffer, "upload", "upload packed contigs (H2D)")
 timed(E.NNEngine, "segment_mean")
 timed(nnc, "write_tsv"); timed(np, "savez_compressed")
 eng = nnc._engine()
-for name in ("gnn_span_byte_count", "gnn_classify_spans"):
+for name in ("gnn_classify_contigs",):
     timed(eng.lib, name)
 t = time.time()
 nnc.main(fa, tmp / "out_t", False, 128, True, 1, False, False)
