@@ -76,13 +76,25 @@ struct XC8 {
 __device__ __forceinline__ const uint4* wptr(const uint4* __restrict__ base, uint32_t lane_off, int frag) {
     return reinterpret_cast<const uint4*>(reinterpret_cast<const unsigned char*>(base) + lane_off + frag * 1024);
 }
+// GNN_W_NT: measurement variant — weight fragments with the non-temporal policy (they are streamed: a CU
+// re-reads a fragment only one step = 1.3 MB of other traffic later, far beyond its 32 KB L1)
+#ifdef GNN_W_NT
+typedef unsigned int u32x4_nt __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ uint4 nt_load(const uint4* p) {
+    const u32x4_nt v = __builtin_nontemporal_load(reinterpret_cast<const u32x4_nt*>(p));
+    return make_uint4(v[0], v[1], v[2], v[3]);
+}
+#define GNN_WLOAD(p) nt_load(p)
+#else
+#define GNN_WLOAD(p) (*(p))
+#endif
 __device__ __forceinline__ void load_w_h(WStep& w, const uint4* __restrict__ base, uint32_t lane_off) {
-    w.h0 = *wptr(base, lane_off, 0);
-    w.h1 = *wptr(base, lane_off, 1);
+    w.h0 = GNN_WLOAD(wptr(base, lane_off, 0));
+    w.h1 = GNN_WLOAD(wptr(base, lane_off, 1));
 }
 __device__ __forceinline__ void load_w_c(WStep& w, const uint4* __restrict__ base, uint32_t lane_off) {
-    w.c0 = *wptr(base, lane_off, 2);
-    w.c1 = *wptr(base, lane_off, 3);
+    w.c0 = GNN_WLOAD(wptr(base, lane_off, 2));
+    w.c1 = GNN_WLOAD(wptr(base, lane_off, 3));
 }
 // keeps memory operations inside their scheduling region: sched_barrier only binds the machine scheduler,
 // instruction selection is otherwise free to emit the (independent) loads of a basic block in any order
@@ -146,9 +158,17 @@ template <bool SWAP, int J, int JN, bool LW, bool LX>
 __device__ __forceinline__ void k32_step(const WStep& wcur, WStep& wload, XF16& xf, XC8& xc,
                                          const unsigned char* __restrict__ xt, const unsigned char* __restrict__ xt_next,
                                          const uint4* __restrict__ wnext, uint32_t lane_off, int ws, int sx, f32x16 (&acc)[4]) {
+    // GNN_ABL_*: measurement-only ablations (scripts/mkvariant.sh) that compile parts of the work out — wrong
+    // results by construction, used to see what the launch time is made of (profiles/README.md)
+#ifndef GNN_ABL_NOX
     load_xc<J>(xc, xt);
+#endif
+#ifndef GNN_ABL_NOW
     if constexpr (LW) load_w_h(wload, wnext, lane_off);
+#endif
+#ifndef GNN_ABL_NOF16
     mfma_f16_phase<SWAP>(wcur, xf, acc);
+#endif
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
         __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);   // 1 MFMA
@@ -156,9 +176,15 @@ __device__ __forceinline__ void k32_step(const WStep& wcur, WStep& wload, XF16& 
         if (LW && (i == 1 || i == 5)) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);   // 1 VMEM read
     }
     GNN_REGION_END();
+#ifndef GNN_ABL_NOX
     if constexpr (LX) load_xf<JN>(xf, xt_next);
+#endif
+#ifndef GNN_ABL_NOW
     if constexpr (LW) load_w_c(wload, wnext, lane_off);
+#endif
+#ifndef GNN_ABL_NOC8
     mfma_c8_phase<SWAP, J>(wcur, xc, ws, sx, acc);
+#endif
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
@@ -492,7 +518,9 @@ __global__ __launch_bounds__(512, 2) void fused_front_c8_kernel(FusedArgsC8 a) {
                 const PairJob jb = {bufY, a.weff[1], a.pos_sorted[1], mp_w[1], t0 - FT,
                                     step > 0 ? a.bucket_ptr[1][sb] : 0, step > 0 ? a.bucket_ptr[1][sb + 1] : 0};
                 const PairJob ja = {bufX, a.weff[0], a.pos_sorted[0], mp_w[0], t0, a.bucket_ptr[0][step], a.bucket_ptr[0][step + 1]};
+#ifndef GNN_ABL_NOHELP
                 m_partials2_c8(jb, ja, hw, lane);
+#endif
             }
             uint4 carry = make_uint4(0, 0, 0, 0);
             const int cr = ht >> 5, cc = ht & 31;        // 5 rows x 32 chunks of 16 B (the three planes = 512 B)
@@ -500,7 +528,11 @@ __global__ __launch_bounds__(512, 2) void fused_front_c8_kernel(FusedArgsC8 a) {
             GNN_TICK(8)
             __syncthreads();                                                     // ---- B1
             if (ht < CARRY * 32) *reinterpret_cast<uint4*>(bufX + cr * ROWB + cc * 16) = carry;
+#ifndef GNN_ABL_NOHELP
             const bool more = step + 1 < FSTEPS;
+#else
+            const bool more = false;
+#endif
             if (more) conv1_gather<0, 4, StoreF16C8, 4>(bufX, toks, a.conv1_k, a.conv1_b, t0 + FT, ht);
             __syncthreads();                                                     // ---- B2
             if (more) conv1_gather<4, 12, StoreF16C8, 8>(bufX, toks, a.conv1_k, a.conv1_b, t0 + FT, ht);
