@@ -186,7 +186,7 @@ extern "C" {
 
 const char* gnn_last_error(void) { return g_last_error.c_str(); }
 
-int gnn_version(void) { return 100; }
+int gnn_version(void) { return 200; }
 
 // CRC-32C (Castagnoli, reflected polynomial 0x82F63B78) of a host buffer — the checksum of the
 // TFRecord framing the reference writes its encoded windows with (nn_classification.py:43-52).

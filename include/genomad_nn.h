@@ -53,13 +53,14 @@ typedef enum gnn_precision {
     GNN_PREC_BF16X3 = 1,     /* fused path: split-bf16 (hi+lo), 3 MFMA passes, f32 accumulate */
     GNN_PREC_BF16 = 2,       /* fused path: single bf16 MFMA pass (fails the 1e-4 tolerance;
                                 for roofline experiments only)                                */
-    GNN_PREC_F16X3 = 4,      /* fused path: split-f16 (hi+lo, 11+11 significant bits), 3 MFMA passes, exact-f32 logits
+    GNN_PREC_F16C8 = 3,      /* fused path: one f16 MFMA pass + MX-scaled fp8 (e4m3) MFMA corrections of
+                                both operands' f16 rounding residuals = 2.0 pass equivalents; inside the
+                                1e-4 tolerance on BASELINE config 2 with little head-room (DESIGN.md §2,
+                                profiles/r02_precision_study.json); the fastest mode and the default of
+                                bench.py / main(); needs |activation| < 65504 (f16 range)                */
+    GNN_PREC_F16X3 = 4       /* fused path: split-f16 (hi+lo, 11+11 significant bits), 3 MFMA passes, exact-f32 logits
                                 GEMM: f32-class accuracy (25x below bf16x3) at bf16x3's speed; needs
                                 |activation| < 65504 (f16 range)                                   */
-    GNN_PREC_F16C8 = 3       /* fused path: one f16 MFMA pass + MX-scaled fp8 (e4m3) MFMA corrections of
-                                both operands' f16 rounding residuals = 2.0 pass equivalents; inside the
-                                1e-4 tolerance (profiles/r02_precision_study.json); needs |activation| <
-                                65504 (f16 range)                                                 */
 } gnn_precision;
 
 typedef enum gnn_onehot_dtype { GNN_OH_U8 = 0, GNN_OH_BF16 = 1, GNN_OH_F32 = 2 } gnn_onehot_dtype;
