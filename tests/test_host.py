@@ -716,3 +716,73 @@ def test_check_fasta_in_chunks_and_non_ascii_headers(tmp_path):
     parts = [sequence.pack_text(c) for c in sequence.iter_text_chunks(big, 20000)]
     assert len(parts) > 3 and [n for pt in parts for n in pt[0]] == list(whole[0])
     assert b"".join(bytes(pt[1]) for pt in parts) == bytes(whole[1])
+
+
+# ------------------------------------------------------------------ RCCL bootstrap without GPUs
+class _FakeCommLib:
+    """Stands in for libgenomad_nn_hip.so's gnn_comm_* (tests only): records what the bootstrap hands to
+    ncclCommInitRank and implements the collectives over a shared directory."""
+
+    def __init__(self, box):
+        self.box = box
+
+    def gnn_comm_unique_id(self, uid):
+        import ctypes as C
+        C.memmove(uid, bytes((i * 7 + 3) % 256 for i in range(128)), 128)
+        return 0
+
+    def gnn_comm_init(self, ctx, world, rank, uid):
+        # like ncclCommInitRank, returns only once every rank has joined
+        import time
+        from pathlib import Path
+        self.box["init"] = (world, rank, bytes(uid))
+        side = Path(self.box["side"])
+        (side / f"joined_{rank}").write_text("x")
+        deadline = time.time() + 30
+        while len(list(side.glob("joined_*"))) < world:
+            assert time.time() < deadline
+            time.sleep(0.01)
+        return 0
+
+    def gnn_comm_barrier(self, ctx):
+        self.box["barriers"] = self.box.get("barriers", 0) + 1
+        return 0
+
+    def gnn_comm_destroy(self, ctx):
+        return 0
+
+
+def _rccl_bootstrap_worker(rank, world, port, rdzv_dir, q):
+    import time
+    os.environ.update(MASTER_PORT=str(port), GENOMAD_AMD_RDZV_DIR=rdzv_dir, TORCHELASTIC_RUN_ID="t1")
+    from genomad_amd import rccl
+    box = {"side": os.path.join(os.path.dirname(rdzv_dir), "side")}
+    eng = type("E", (), {"lib": _FakeCommLib(box), "ctx": object()})()
+    if rank == 0:
+        time.sleep(0.3)                       # the other ranks are already polling for the id file
+    comm = rccl.RcclComm(eng, rank, world, timeout=30)
+    q.put((rank, box["init"], box["barriers"], sorted(os.listdir(rdzv_dir)) if rank == 0 else None))
+    comm.close()
+
+
+def test_rccl_unique_id_bootstrap_with_three_ranks(tmp_path):
+    """The part of the multi-GPU path that cannot run on a one-GPU box: rank 0 publishes ncclGetUniqueId's 128
+    bytes in a file keyed by launcher port / run id / parent pid, the other ranks wait for it, every rank calls
+    ncclCommInitRank with the same id and its own rank, and rank 0 removes the file after the first barrier."""
+    import multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    d = tmp_path / "rdzv"
+    d.mkdir()
+    (tmp_path / "side").mkdir()
+    procs = [ctx.Process(target=_rccl_bootstrap_worker, args=(r, 3, 29999, str(d), q)) for r in range(3)]
+    for p in procs:
+        p.start()
+    got = sorted(q.get(timeout=60) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    want_id = bytes((i * 7 + 3) % 256 for i in range(128))
+    assert [g[1] for g in got] == [(3, r, want_id) for r in range(3)]
+    assert all(g[2] >= 1 for g in got)
+    assert got[0][3] == []                     # the id file is gone once everybody has joined
