@@ -57,14 +57,19 @@ def _id_file(seq: int) -> Path:
 
 @contextlib.contextmanager
 def _c_stdout_to_stderr():
-    """RCCL prints a version banner to the C-level stdout when the first communicator is created; callers such
-    as bench.py promise exactly one JSON line there.  File descriptor 1 is pointed at stderr for the duration."""
+    """RCCL prints a version banner with C stdio when the first communicator is created; callers such as bench.py
+    promise exactly one JSON line on stdout.  File descriptor 1 is pointed at stderr for the duration, and the C
+    library's buffers are flushed on both sides of the switch (with stdout redirected to a file, stdio holds the
+    banner back until exit otherwise, and it would land behind the JSON line)."""
+    libc = C.CDLL(None)
     sys.stdout.flush()
+    libc.fflush(None)
     saved = os.dup(1)
     try:
         os.dup2(2, 1)
         yield
     finally:
+        libc.fflush(None)
         os.dup2(saved, 1)
         os.close(saved)
 

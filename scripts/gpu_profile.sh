@@ -15,6 +15,7 @@ timeout 300 python $ROOT/bench.py --steps 8 --force-dist --cpu-sample 0 > $OUT/b
 timeout 300 env WORLD_SIZE=1 RANK=0 LOCAL_RANK=0 MASTER_ADDR=127.0.0.1 MASTER_PORT=29544 \
   python $ROOT/bench.py --steps 8 --scaling weak --force-dist --cpu-sample 0 > $OUT/bench_weak.json 2>> $OUT/bench_force_dist.err
 timeout 600 python $ROOT/bench.py --workload metagenome --gbp-total 3 --cpu-sample 0 > $OUT/bench_metagenome_3gbp.json 2> $OUT/bench_metagenome.err
+timeout 900 python $ROOT/bench.py --workload metagenome --gbp-total 60 --cpu-sample 0 > $OUT/bench_metagenome_60gbp.json 2>> $OUT/bench_metagenome.err
 # 1b. accuracy tails of the fused arithmetic options against the exact f32 device path
 (cd $ROOT && timeout 200 python scripts/seed_check.py 10000 42 43; timeout 300 python scripts/seed_check.py 100000 42 43) > $OUT/tails.txt 2>&1
 # 2. kernel trace + stats of the default command (shorter)
