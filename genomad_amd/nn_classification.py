@@ -22,7 +22,6 @@ writes the files.
 """
 import concurrent.futures
 import hashlib
-import io
 import json
 import os
 import shutil
