@@ -15,7 +15,8 @@ every weight seed given.  Everything else (conv1 gather, pair products, softmax,
 except that the IGLOO pair products read the activations as the scheme stores them in LDS.
 
 Cost model ("passes"): one v_mfma_f32_32x32x16_{bf16,f16} pass over the K range = 1.0; i8 MFMA = 0.5;
-MX-scaled fp8 (v_mfma_scale_f32_32x32x64_f8f6f4, e4m3/e5m2) = 0.5; MX fp6/fp4 = 0.25
+a 32-element K block of the MX-scaled v_mfma_scale_f32_32x32x64_f8f6f4 = 0.5 in fp8 (e4m3/e5m2; the schemes
+below use two blocks = one instruction per 32 channels = 1.0) and 0.25 in fp6/fp4
 (/opt/skills/guides/MI355X_MICROARCH.md "Matrix cores": 2382 / 4404 / 4686 / 8939 / 9099 TFLOP/s measured).
 """
 import argparse
@@ -186,13 +187,13 @@ SCHEMES = [
            lambda x: [rnd(x, "bf16"), rnd(x, "e4m3"), rnd((x - rnd(x, "bf16")) * 256.0, "e4m3") / 256.0],
            lambda w: [rnd(w, "bf16"), rnd_mx(w, "e4m3", 0), rnd_mx(w - rnd(w, "bf16"), "e4m3", 0)],
            [(0, 0), (1, 2), (2, 1)], "", _HI_PLUS_RESIDUAL),
-    # 2.25-pass variants: one of the two residual terms in a second f16 pass (no scaling needed: f16 holds the
-    # residual directly, in its subnormal range for small weights), the other one in fp8 (K = 64 covers 64 channels)
-    Scheme("fp16 x (w 2 limbs) + e4m3 correction of x (xh*wh + xh*wl16 + xl8*w8)", 2.25,
+    # 2.5-pass variants: one of the two residual terms in a second f16 pass (1.0; no scaling needed: f16 holds the
+    # residual directly, in its subnormal range for small weights), the other one in ONE fp8 K block (0.5)
+    Scheme("fp16 x (w 2 limbs) + e4m3 correction of x (xh*wh + xh*wl16 + xl8*w8)", 2.5,
            lambda x: [rnd(x, "fp16"), None, rnd((x - rnd(x, "fp16")) * 2048.0, "e4m3") / 2048.0],
            lambda w: [rnd(w, "fp16"), rnd_mx(w, "e4m3", 0), rnd(w - rnd(w, "fp16"), "fp16")],
            [(0, 0), (0, 2), (2, 1)], "", _HI_PLUS_RESIDUAL),
-    Scheme("fp16 x (x 2 limbs) + e4m3 correction of w (xh*wh + xl16*wh + x8*wl8)", 2.25,
+    Scheme("fp16 x (x 2 limbs) + e4m3 correction of w (xh*wh + xl16*wh + x8*wl8)", 2.5,
            lambda x: [rnd(x, "fp16"), rnd(x, "e4m3"), rnd(x - rnd(x, "fp16"), "fp16")],
            lambda w: [rnd(w, "fp16"), None, rnd_mx(w - rnd(w, "fp16"), "e4m3", 0)],
            [(0, 0), (2, 0), (1, 2)], "", _HI_PLUS_RESIDUAL),
