@@ -273,6 +273,61 @@ def test_main_end_to_end_on_gpu(engine, synth_weights, tmp_path, monkeypatch):
     assert not (out / "mini_nn_classification" / "mini_encoded_sequences").exists()   # --cleanup
 
 
+def test_main_compressed_chunked_input_provirus_pass_and_resume_on_gpu(engine, synth_weights, tmp_path, monkeypatch):
+    """Product path of main() on a gzip FASTA read as a stream of record-aligned chunks (several chunks forced),
+    with the find-proviruses outputs present (second classification pass, one weight upload) and a second call
+    that must resume from the files: same NPZ as the uncompressed file in one piece, nothing recomputed."""
+    import gzip
+    import json
+    from genomad_amd import nn_classification as nnc
+    from genomad_amd import weights as W
+    rng = np.random.default_rng(10)
+    recs = [(f"c{i} note", "".join(rng.choice(list("ACGTN"), int(rng.integers(2000, 30000)), p=[.245, .245, .245, .245, .02])))
+            for i in range(9)]
+    text = "".join(f">{n}\n" + "\n".join(s[j:j + 61] for j in range(0, len(s), 61)) + "\n" for n, s in recs)
+    plain, gz = tmp_path / "meta.fna", tmp_path / "metaz.fna.gz"
+    plain.write_text(text)
+    with gzip.open(gz, "wt") as f:
+        f.write(text)
+    wpath = tmp_path / "w.npz"
+    W.save_npz(wpath, synth_weights)
+    monkeypatch.setenv("GENOMAD_AMD_WEIGHTS", str(wpath))
+    monkeypatch.setattr(nnc, "_ENGINE", engine)
+    real_chunks = sequence.iter_text_chunks
+    seen = []
+
+    def small_chunks(path, chunk_bytes=128 << 20):
+        for c in real_chunks(path, 40000):
+            seen.append(len(c))
+            yield c
+    monkeypatch.setattr(sequence, "iter_text_chunks", small_chunks)
+    out_p, out_z = tmp_path / "op", tmp_path / "oz"
+    fp = out_z / "metaz_find_proviruses"
+    fp.mkdir(parents=True)
+    (fp / "metaz_find_proviruses.json").write_text(json.dumps({"input_md5": nnc.get_md5(gz), "module": "x", "parameters": {}}))
+    (fp / "metaz_provirus.tsv").write_text("h\nc1|provirus_1_5000\n")
+    (fp / "metaz_provirus.fna").write_text(">c1|provirus_1_5000\n" + recs[1][1][:5000] + "\n")
+    (fp / "metaz_provirus_proteins.faa").write_text("")
+    (fp / "metaz_provirus_genes.tsv").write_text("")
+    nnc.main(plain, out_p, False, 128, False, 1, False, False)
+    nnc.main(gz, out_z, False, 128, False, 1, False, False)
+    assert len(seen) >= 3                                        # the stream really came in several chunks
+    a = np.load(out_p / "meta_nn_classification" / "meta_nn_classification.npz")
+    b = np.load(out_z / "metaz_nn_classification" / "metaz_nn_classification.npz")
+    assert list(a["contig_names"]) == list(b["contig_names"]) == [f"c{i}" for i in range(9)]
+    assert np.array_equal(a["predictions"], b["predictions"])
+    wa = np.load(out_p / "meta_nn_classification" / "meta_encoded_sequences" / "meta_seq_window_id.npz")
+    wb = np.load(out_z / "metaz_nn_classification" / "metaz_encoded_sequences" / "metaz_seq_window_id.npz")
+    assert np.array_equal(wa["contig_ids"], wb["contig_ids"])
+    pz = np.load(out_z / "metaz_nn_classification" / "metaz_provirus_nn_classification.npz")
+    assert list(pz["provirus_names"]) == ["c1|provirus_1_5000"] and pz["predictions"].shape == (1, 3)
+    # resume: same input and parameters -> both passes are skipped, the files are reused
+    monkeypatch.setattr(type(engine), "classify_contigs", lambda *a, **k: (_ for _ in ()).throw(AssertionError("recomputed")))
+    nnc.main(gz, out_z, False, 128, False, 1, False, False)
+    c = np.load(out_z / "metaz_nn_classification" / "metaz_nn_classification.npz")
+    assert np.array_equal(b["predictions"], c["predictions"])
+
+
 def test_main_device_path_invalid_fasta_leaves_nothing_behind(engine, synth_weights, tmp_path, monkeypatch):
     """The device front end validates the FASTA concurrently with the classification; an input with a
     duplicated identifier must still end like in the reference (error, exit 1) and must not leave an
