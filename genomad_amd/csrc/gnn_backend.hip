@@ -308,7 +308,9 @@ __global__ __launch_bounds__(512) void dense_kernel(const float* __restrict__ fe
         for (int w = 0; w < DW; ++w) acc[w] = fmaf(f[w][k], wv, acc[w]);
     }
 #pragma unroll
-    for (int w = 0; w < DW; ++w) h1[w][j] = fmaxf(acc[w], 0.f);
+    // ReLU written so that NaN stays NaN (fmaxf would turn it into 0 and hide an overflow of the f16-operand
+    // front ends behind plausible finite scores; main() relies on non-finite scores to fall back to bf16x3)
+    for (int w = 0; w < DW; ++w) h1[w][j] = acc[w] < 0.f ? 0.f : acc[w];
     __syncthreads();
 #pragma unroll
     for (int w = 0; w < DW; ++w) acc[w] = d2b[j];
@@ -318,7 +320,7 @@ __global__ __launch_bounds__(512) void dense_kernel(const float* __restrict__ fe
         for (int w = 0; w < DW; ++w) acc[w] = fmaf(h1[w][k], wv, acc[w]);
     }
 #pragma unroll
-    for (int w = 0; w < DW; ++w) h2[w][j] = fmaxf(acc[w], 0.f);
+    for (int w = 0; w < DW; ++w) h2[w][j] = acc[w] < 0.f ? 0.f : acc[w];
     __syncthreads();
     // output layer: DW*3 dot products of length 512; one wave per (window, class) pair, 8 waves
     const int wave = j >> 6, lane = j & 63;

@@ -219,6 +219,29 @@ def _engine():
     return _ENGINE
 
 
+F16_MODES = ("f16c8", "f16x3")     # their operands are f16: activations beyond 65504 overflow to inf -> NaN scores
+_WARNED = set()
+
+
+def _range_fallback(console, what):
+    """The f16-operand modes cannot represent activations beyond 65504; scores that come back
+    non-finite are recomputed with the split-bf16 kernel, which has the f32 range.  Said once per run."""
+    if what not in _WARNED:
+        _WARNED.add(what)
+        msg = (f"Non-finite class scores from the f16 arithmetic ({what}): activations left the f16 range; "
+               "recomputing the affected batch with bf16x3.")
+        (console.log if console is not None else print)(msg)
+
+
+def classify_contigs_safely(eng, seq, offsets, single_window, precision, console=None):
+    """NNEngine.classify_contigs with the range fallback of :func:`_range_fallback`."""
+    pr, wid = eng.classify_contigs(seq, offsets, single_window, precision)
+    if precision in F16_MODES and not np.isfinite(pr).all():
+        _range_fallback(console, precision)
+        pr, wid = eng.classify_contigs(seq, offsets, single_window, "bf16x3")
+    return pr, wid
+
+
 class GpuBackend:
     """Scores windows and averages them per contig on the GPU (libgenomad_nn_hip.so)."""
 
@@ -228,8 +251,13 @@ class GpuBackend:
         self.precision = os.environ.get("GENOMAD_AMD_PRECISION", DEFAULT_PRECISION)
 
     def score(self, windows: np.ndarray) -> np.ndarray:
-        out = [self.eng.classify(windows[a:a + self.chunk], self.precision)
-               for a in range(0, len(windows), self.chunk)]
+        out = []
+        for a in range(0, len(windows), self.chunk):
+            s = self.eng.classify(windows[a:a + self.chunk], self.precision)
+            if self.precision in F16_MODES and not np.isfinite(s).all():
+                _range_fallback(None, self.precision)
+                s = self.eng.classify(windows[a:a + self.chunk], "bf16x3")
+            out.append(s)
         return np.concatenate(out) if out else np.zeros((0, 3), np.float32)
 
     def segment_mean(self, scores, ids, n_segments) -> np.ndarray:
@@ -422,7 +450,7 @@ def main(input_path, output_path, single_window, batch_size, restart, threads, v
                         nm, sq, off = nxt.result()
                         if k + 1 < pieces:
                             nxt = pool.submit(read, k + 1)
-                        pr, wid = eng.classify_contigs(sq, off, single_window, precision)
+                        pr, wid = classify_contigs_safely(eng, sq, off, single_window, precision, console)
                         parts.append((rank * 64 + k, nm, pr, wid))
             else:
                 # compressed streams cannot be read by byte range: every rank decompresses the stream
@@ -431,7 +459,7 @@ def main(input_path, output_path, single_window, batch_size, restart, threads, v
                     if i % world != rank:
                         continue
                     nm, sq, off = sequence.pack_text(chunk, strip_n=True)
-                    pr, wid = eng.classify_contigs(sq, off, single_window, precision)
+                    pr, wid = classify_contigs_safely(eng, sq, off, single_window, precision, console)
                     parts.append((i, nm, pr, wid))
             names, predictions, ids, n_windows = sharding.gather_contig_parts(comm, parts)
             gate()

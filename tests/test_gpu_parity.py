@@ -237,6 +237,38 @@ def test_f16c8_large_activations_saturate_instead_of_nan(synth_weights):
     assert np.abs(got - exact).max() <= 1e-3
 
 
+def test_f16_modes_overflow_is_detected_and_main_falls_back_to_bf16x3(synth_weights, tmp_path, monkeypatch):
+    """Activations beyond the f16 range (65504): the f16-operand modes return non-finite scores — never silently
+    wrong finite ones — and main() recomputes the affected batch with the split-bf16 kernel (f32 range)."""
+    from genomad_amd import nn_classification as nnc
+    from genomad_amd import weights as W
+    from genomad_amd.engine import NNEngine
+    w = dict(synth_weights)
+    for k, f in (("conv1_kernel", 3e4), ("conv1_bias", 3e4), ("conv2_kernel", 1 / 3e4),
+                 ("iglooA_w_mult", 1 / 3e4), ("iglooA_w_v", 1 / 3e4)):      # the same network, |x1| up to ~7e4
+        w[k] = synth_weights[k] * np.float32(f)
+    bases = synthetic.synth_windows(0, 8)
+    rng = np.random.default_rng(3)
+    fa = tmp_path / "s.fna"
+    fa.write_text("".join(f">c{i}\n{''.join(rng.choice(list('ACGT'), 9000))}\n" for i in range(3)))
+    with NNEngine(0, w) as e2:
+        exact, wide = e2.classify(bases, "f32"), e2.classify(bases, "bf16x3")
+        assert np.isfinite(wide).all() and np.abs(wide - exact).max() <= 1e-3
+        for prec in ("f16c8", "f16x3"):
+            assert not np.isfinite(e2.classify(bases, prec)).all()
+        wpath = tmp_path / "w.npz"
+        W.save_npz(wpath, w)
+        monkeypatch.setenv("GENOMAD_AMD_WEIGHTS", str(wpath))
+        monkeypatch.setenv("GENOMAD_AMD_PRECISION", "f16c8")
+        monkeypatch.setattr(nnc, "_ENGINE", e2)
+        nnc.main(fa, tmp_path / "out", False, 128, False, 1, False, False)
+        z = np.load(tmp_path / "out" / "s_nn_classification" / "s_nn_classification.npz")
+        names, seq, off = sequence.read_fasta_packed(fa)
+        want, _ = e2.classify_contigs(seq, off, False, "bf16x3")
+    assert np.isfinite(z["predictions"]).all() and np.array_equal(z["predictions"], want)
+    assert "recomputing" in (tmp_path / "out" / "s_nn_classification.log").read_text()
+
+
 def test_single_pass_bf16_is_outside_tolerance_but_sane(engine, oracle16):
     """GNN_PREC_BF16 exists for roofline experiments; document that it misses the 1e-4 tolerance."""
     bases, scores64, _ = oracle16
