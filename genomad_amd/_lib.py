@@ -14,8 +14,9 @@ LIB_PATH = Path(os.environ.get("GENOMAD_AMD_LIB", _HERE / "csrc" / "libgenomad_n
 WINDOW, TOKENS, DEPTH, CH = 6000, 5997, 257, 128
 PATCHES, PATCH_SIZE, POOLED, FEAT, HIDDEN, CLASSES = 2100, 4, 749, 256, 512, 3
 
-PREC_F32, PREC_BF16X3, PREC_BF16, PREC_F16C8, PREC_F16X3 = 0, 1, 2, 3, 4
-PRECISIONS = {"f32": PREC_F32, "bf16x3": PREC_BF16X3, "bf16": PREC_BF16, "f16c8": PREC_F16C8, "f16x3": PREC_F16X3}
+PREC_F32, PREC_BF16X3, PREC_BF16, PREC_F16C8, PREC_F16X3, PREC_F16C6 = 0, 1, 2, 3, 4, 5
+PRECISIONS = {"f32": PREC_F32, "bf16x3": PREC_BF16X3, "bf16": PREC_BF16, "f16c8": PREC_F16C8, "f16x3": PREC_F16X3,
+              "f16c6": PREC_F16C6}
 OH_U8, OH_BF16, OH_F32 = 0, 1, 2
 K_FUSED, K_BACKEND, K_ENCODER, K_F32_FRONT = 0, 1, 2, 3
 

@@ -144,6 +144,37 @@ static int check_ctx(gnn_ctx* ctx) {
     return GNN_OK;
 }
 
+// conv1 pair tables.  conv1 on the one-hot input is sum_k W1[k][tok[t-5+k]] (model.py:11 +
+// igloo.py:45-47).  Tokens of adjacent positions share 3 bases, so the pair (tok[s], tok[s+1])
+// has only 1795 possible values (PAIR_ROWS, see pair_row() in gnn_fused_common.h); tabulating
+// W1[2j][a] + W1[2j+1][b] for the three tap pairs j halves the rows the fused kernels gather.
+void build_conv1_pair_tables(const float* k1, std::vector<float>& pt) {
+    pt.assign((size_t)3 * PAIR_ROWS * C, 0.f);
+    auto row = [&](int j, int r) { return &pt[((size_t)j * PAIR_ROWS + r) * C]; };
+    auto add = [&](float* dst, int k, int tok) {
+        const float* src = k1 + ((size_t)k * GNN_DEPTH + tok) * C;
+        for (int c = 0; c < C; ++c) dst[c] += src[c];
+    };
+    for (int j = 0; j < 3; ++j) {
+        for (int code5 = 0; code5 < 1024; ++code5) {          // both 4-mers valid: a 5-mer
+            add(row(j, code5), 2 * j, 1 + (code5 >> 2));
+            add(row(j, code5), 2 * j + 1, 1 + (code5 & 255));
+        }
+        for (int b = 1; b <= 256; ++b) {                       // first 4-mer has an N (token 0)
+            add(row(j, 1024 + b - 1), 2 * j, 0);
+            add(row(j, 1024 + b - 1), 2 * j + 1, b);
+        }
+        for (int a = 1; a <= 256; ++a) {                       // second 4-mer has an N
+            add(row(j, 1280 + a - 1), 2 * j, a);
+            add(row(j, 1280 + a - 1), 2 * j + 1, 0);
+        }
+        add(row(j, 1536), 2 * j, 0);                           // both have an N
+        add(row(j, 1536), 2 * j + 1, 0);
+        // row 1537: both positions before the window start (causal zero padding) -> zeros
+        for (int b = 0; b <= 256; ++b) add(row(j, 1538 + b), 2 * j + 1, b);   // only the first is absent
+    }
+}
+
 // One pass of the hot path over n windows whose bases are on the device.
 int classify_chunks(gnn_ctx* ctx, const uint8_t* bases_dev, int64_t n, int precision, float* scores_dev) {
     if (!ctx->has_weights) {
@@ -151,7 +182,7 @@ int classify_chunks(gnn_ctx* ctx, const uint8_t* bases_dev, int64_t n, int preci
         return GNN_ERR_STATE;
     }
     if (precision != GNN_PREC_F32 && precision != GNN_PREC_BF16X3 && precision != GNN_PREC_BF16 &&
-        precision != GNN_PREC_F16C8 && precision != GNN_PREC_F16X3) {
+        precision != GNN_PREC_F16C8 && precision != GNN_PREC_F16X3 && precision != GNN_PREC_F16C6) {
         set_error("unknown precision " + std::to_string(precision));
         return GNN_ERR_ARG;
     }
@@ -167,8 +198,10 @@ int classify_chunks(gnn_ctx* ctx, const uint8_t* bases_dev, int64_t n, int preci
             if ((rc = launch_front_f32(ctx, b, m))) return rc;
         } else {
             ProfScope ps(ctx, GNN_K_FUSED);
-            if ((rc = precision == GNN_PREC_F16C8 ? launch_front_c8(ctx, b, m) : launch_front_fused(ctx, b, m, precision)))
-                return rc;
+            rc = precision == GNN_PREC_F16C6   ? launch_front_c6(ctx, b, m)
+                 : precision == GNN_PREC_F16C8 ? launch_front_c8(ctx, b, m)
+                                               : launch_front_fused(ctx, b, m, precision);
+            if (rc) return rc;
         }
         {
             ProfScope ps(ctx, GNN_K_BACKEND);
@@ -382,35 +415,8 @@ int gnn_load_weights(gnn_ctx* ctx, const gnn_weights* w) {
         if ((rc = upload(ctx, g->w_v, (size_t)C * C, &d.w_v[h]))) return rc;
     }
     {
-        // conv1 pair tables.  conv1 on the one-hot input is sum_k W1[k][tok[t-5+k]] (model.py:11 +
-        // igloo.py:45-47).  Tokens of adjacent positions share 3 bases, so the pair (tok[s], tok[s+1])
-        // has only 1795 possible values (PAIR_ROWS, see pair_row() in gnn_fused.hip); tabulating
-        // W1[2j][a] + W1[2j+1][b] for the three tap pairs j halves the rows the fused kernel gathers.
-        const float* k1 = w->conv1_kernel;
-        std::vector<float> pt((size_t)3 * PAIR_ROWS * C, 0.f);
-        auto row = [&](int j, int r) { return &pt[((size_t)j * PAIR_ROWS + r) * C]; };
-        auto add = [&](float* dst, int k, int tok) {
-            const float* src = k1 + ((size_t)k * GNN_DEPTH + tok) * C;
-            for (int c = 0; c < C; ++c) dst[c] += src[c];
-        };
-        for (int j = 0; j < 3; ++j) {
-            for (int code5 = 0; code5 < 1024; ++code5) {          // both 4-mers valid: a 5-mer
-                add(row(j, code5), 2 * j, 1 + (code5 >> 2));
-                add(row(j, code5), 2 * j + 1, 1 + (code5 & 255));
-            }
-            for (int b = 1; b <= 256; ++b) {                       // first 4-mer has an N (token 0)
-                add(row(j, 1024 + b - 1), 2 * j, 0);
-                add(row(j, 1024 + b - 1), 2 * j + 1, b);
-            }
-            for (int a = 1; a <= 256; ++a) {                       // second 4-mer has an N
-                add(row(j, 1280 + a - 1), 2 * j, a);
-                add(row(j, 1280 + a - 1), 2 * j + 1, 0);
-            }
-            add(row(j, 1536), 2 * j, 0);                           // both have an N
-            add(row(j, 1536), 2 * j + 1, 0);
-            // row 1537: both positions before the window start (causal zero padding) -> zeros
-            for (int b = 0; b <= 256; ++b) add(row(j, 1538 + b), 2 * j + 1, b);   // only the first is absent
-        }
+        std::vector<float> pt;
+        build_conv1_pair_tables(w->conv1_kernel, pt);
         if ((rc = upload(ctx, pt.data(), pt.size(), &d.conv1_pairs))) return rc;
     }
     // Fold BatchNormalization (inference statistics) into the preceding Dense (model.py:28-30, 40-42):
@@ -432,6 +438,7 @@ int gnn_load_weights(gnn_ctx* ctx, const gnn_weights* w) {
     if ((rc = upload(ctx, w->out_bias, (size_t)GNN_CLASSES, &d.d3_b))) return rc;
     if ((rc = pack_fused_weights(ctx, w))) return rc;
     if ((rc = pack_fused_c8_weights(ctx, w))) return rc;
+    if ((rc = pack_fused_c6_weights(ctx, w))) return rc;
     ctx->has_weights = true;
     return GNN_OK;
 }

@@ -354,7 +354,7 @@ int launch_backend(gnn_ctx* ctx, int64_t n, int precision, float* scores_dev) {
     const dim3 qk_grid(QK_NBLK / 8, (unsigned)((n + 63) / 64), 2);
     const uint4* qf0 = reinterpret_cast<const uint4*>(d.wqk_frag[0]);
     const uint4* qf1 = reinterpret_cast<const uint4*>(d.wqk_frag[1]);
-    if (precision == GNN_PREC_BF16X3 || precision == GNN_PREC_F16C8)   // the logits GEMM keeps split-bf16 x 3
+    if (precision == GNN_PREC_BF16X3 || precision == GNN_PREC_F16C8 || precision == GNN_PREC_F16C6)   // the logits GEMM keeps split-bf16 x 3
         hipLaunchKernelGGL(logits_mfma_kernel<3>, qk_grid, dim3(256), 0, ctx->stream, ws.m, qf0, qf1, (int)n, ws.logits);
     else if (precision == GNN_PREC_BF16)
         hipLaunchKernelGGL(logits_mfma_kernel<1>, qk_grid, dim3(256), 0, ctx->stream, ws.m, qf0, qf1, (int)n, ws.logits);

@@ -1,0 +1,723 @@
+// Fused front end, GNN_PREC_F16C6: the streaming structure of gnn_fused_c8.hip (one workgroup = one window,
+// steps of FT6 positions, activations resident in LDS, 4 matrix waves + 4 helper waves) with the two
+// correction products on the MX-fp6 (e2m3) rate of the matrix pipe: 1.5 instead of 2.0 f16-pass equivalents.
+//
+//   x * w  ~=  f16(x) * f16(w)                           v_mfma_f32_32x32x16_f16, K = 16 per instruction (32 cycles)
+//            + e2m3_mx(x) * e2m3_mx(w - f16(w))          \  one v_mfma_scale_f32_32x32x64_f8f6f4 (cbsz = blgp = 2: fp6,
+//            + e2m3_mx(x - f16(x)) * e2m3_mx(w)          /  32 cycles instead of the 64 of fp8) per 32 channels
+//
+// e2m3 has the 4 significant bits of e4m3 but only 2 exponent bits, so BOTH operands are block scaled (OCP MX: 32
+// consecutive K elements share one E8M0 exponent): weights per (32 k, output column) at packing time, activations per
+// (row, 32 channels) when a row is produced — the largest |x| (and the largest residual) of the block puts its
+// exponent into the scale byte the MFMA reads with the fragment.  Emulation (oracle/precision_study.py, "fp16 + e2m3
+// (fp6, MX both sides)"): max |dscore| 3.7e-5 / 5.7e-5 on the two weight seeds, the class of f16c8 (4.1e-5 / 6.6e-5).
+//
+// Everything that touches an activation row works on (row, 32-channel block) units held by ONE lane, because that is
+// the granularity of the hardware's fp6 conversions (v_cvt_scalef32_pk32_fp6_f16: 32 values -> 24 bytes, natural
+// order: scripts/probe_mx.hip) and of the MX scale: the conv epilogues bring a row's 32 channels together with 16
+// v_permlane32_swap, the conv1 gather and the IGLOO pair products are mapped 4 lanes per row.
+//
+// Operand layout facts (scripts/probe_mx.hip -> profiles/r02_probe_mx.txt): an fp6 operand of 32x32x64 is 6 dwords
+// per lane: lane l = row (or column) l & 31, K block l >> 5, element i of the block in bits [6i, 6i+6); the scale of
+// block 0 is read from lanes 0-31, that of block 1 from lanes 32-63, byte OPSEL of the scale VGPR.
+//
+// LDS row (464 B = 29 x 16: odd multiple of 16 B keeps the 16-lane groups of ds_read_b128 on distinct slots):
+//   [0,256) 128 ch f16 | [256,320) x6: first 16 B of the 4 blocks | [320,352) x6: last 8 B of the 4 blocks |
+//   [352,416) [416,448) the same for the residual image | [448,452) E8M0 of x6 per block | [452,456) E8M0 of the
+//   residual image per block | pad
+// The narrower row (464 instead of 528 B) is what lets a step hold FT6 = 160 rows (GNN_C6_NMB = 5) in 160 KB.
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+
+#include "gnn_fused_common.h"
+
+namespace gnn {
+namespace c6 {
+
+#ifndef GNN_C6_NMB
+#define GNN_C6_NMB 4
+#endif
+constexpr int NMB = GNN_C6_NMB;              // 32-row blocks per step
+constexpr int FT6 = 32 * NMB;                // rows per step
+constexpr int STEPS6 = (T + FT6 - 1) / FT6;
+constexpr int ROW6 = 464;
+constexpr int X6A = 256, X6B = 320, L6A = 352, L6B = 416, SXO = 448, SLO = 452;
+constexpr int BUF6_ROWS = CARRY + FT6;
+constexpr int BUF6_BYTES = BUF6_ROWS * ROW6;
+constexpr int PROW_OFF = 2 * BUF6_BYTES;
+constexpr int PROW_N = FT6 + 4;              // pair rows a step's conv1 gather reads
+constexpr int SMEM6 = PROW_OFF + ((PROW_N * 2 + 15) / 16) * 16;
+constexpr int XL_SHIFT = 11;                 // the residual is converted from f16((x - f16 x) * 2^11)
+constexpr int WNBLK_B = 3584;                // weight bytes per (k32 step, n-block): f16 k16 even | f16 k16 odd | fp6 16-B parts | fp6 8-B parts
+constexpr int WSTEP_B = 4 * WNBLK_B;         // per k32 step
+constexpr int ROW_U4 = ROW6 / 16;            // 29
+static_assert(SMEM6 <= 160 * 1024, "LDS budget");
+static_assert(PROW_N <= 256, "one helper thread per pair row");
+
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+typedef _Float16 f16x32 __attribute__((ext_vector_type(32)));
+typedef float f32x32 __attribute__((ext_vector_type(32)));
+typedef int i32x8 __attribute__((ext_vector_type(8)));
+typedef int i32x6 __attribute__((ext_vector_type(6)));
+
+struct Args {
+    const uint8_t* bases;
+    const float* conv1_k;             // (3, PAIR_ROWS, 128) f32 pair tables, channel 32p + 4i + e at i*16 + p*4 + e, bias folded into table 0
+    const unsigned char* conv_w[2];   // [k32 step 24][nblk 4][3584 B]
+    const uint32_t* conv_s[2];        // [tap 6][nblk 4][lane 64] u32: byte j = E8M0 scale of k32 step 4*tap + j
+    const float* conv_b[2];
+    const unsigned char* wv_w[2];     // same layouts, 4 k32 steps / 1 tap
+    const uint32_t* wv_s[2];
+    const float* weff[2];
+    const int32_t* pos_sorted[2];
+    const int32_t* bucket_ptr[2];     // (STEPS6 + 1,) entry ranges per step of FT6 rows
+    float* mp;
+    float* yp;
+};
+
+struct WStep {
+    uint4 h0, h1;      // f16 fragments of the two k16 halves
+    uint4 c0;          // fp6 fragment dwords 0-3 (lanes 0-31: K block 0 = e2m3_mx(w - f16 w), lanes 32-63: K block 1 = e2m3_mx(w))
+    uint2 c1;          // fp6 fragment dwords 4-5
+};
+struct XF {
+    uint4 v[2][NMB];   // [k16 half][m-block]
+};
+struct XC {
+    i32x8 v[NMB];      // fp6 fragment dwords 0-5 (lanes 0-31: x image, lanes 32-63: residual image), 6-7 unused
+};
+
+#define GNN_REGION_END()               \
+    __builtin_amdgcn_sched_barrier(0); \
+    asm volatile("" ::: "memory")
+
+// Weight fragments come through buffer loads: resource descriptor (SGPRs) + 32-bit lane offset (VGPR) + wave-uniform
+// step offset (SGPR) + immediate, so no 64-bit per-lane address ever lives in VGPRs (with global loads the compiler
+// kept one address pair per (step, fragment) of the ring: 73 dwords of spills).
+typedef __amdgpu_buffer_rsrc_t wrsrc_t;
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ wrsrc_t make_wrsrc(const unsigned char* base, int bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned char*>(base), 0, bytes, 0x00020000);
+}
+__device__ __forceinline__ void load_w_h(WStep& w, wrsrc_t r, uint32_t l16, int soff) {
+    const u32x4 a = __builtin_amdgcn_raw_buffer_load_b128(r, l16, soff, 0);
+    const u32x4 b = __builtin_amdgcn_raw_buffer_load_b128(r, l16 + 1024, soff, 0);
+    w.h0 = make_uint4(a[0], a[1], a[2], a[3]);
+    w.h1 = make_uint4(b[0], b[1], b[2], b[3]);
+}
+__device__ __forceinline__ void load_w_c(WStep& w, wrsrc_t r, uint32_t l16, int soff) {
+    const u32x4 a = __builtin_amdgcn_raw_buffer_load_b128(r, l16 + 2048, soff, 0);
+    const u32x2 b = __builtin_amdgcn_raw_buffer_load_b64(r, (l16 >> 1) + 3072, soff, 0);
+    w.c0 = make_uint4(a[0], a[1], a[2], a[3]);
+    w.c1 = make_uint2(b[0], b[1]);
+}
+// xh = lane base of the tap row's f16 plane (row l & 31, + 16 B for lanes 32-63); J = k32 step inside the tap
+template <int J>
+__device__ __forceinline__ void load_xf(XF& f, const unsigned char* __restrict__ xh) {
+#pragma unroll
+    for (int s = 0; s < 2; ++s)
+#pragma unroll
+        for (int mb = 0; mb < NMB; ++mb) f.v[s][mb] = *reinterpret_cast<const uint4*>(xh + mb * 32 * ROW6 + (J * 2 + s) * 32);
+}
+// xq = lane base of the tap row's fp6 planes (x image for lanes 0-31, residual image for lanes 32-63)
+template <int J>
+__device__ __forceinline__ void load_xc(XC& f, const unsigned char* __restrict__ xq) {
+#pragma unroll
+    for (int mb = 0; mb < NMB; ++mb) {
+        const uint4 a = *reinterpret_cast<const uint4*>(xq + mb * 32 * ROW6 + J * 16);
+        const uint2 b = *reinterpret_cast<const uint2*>(xq + mb * 32 * ROW6 + (X6B - X6A) + J * 8);
+        f.v[mb] = i32x8{(int)a.x, (int)a.y, (int)a.z, (int)a.w, (int)b.x, (int)b.y, 0, 0};
+    }
+}
+// activation scale words of the tap row (4 bytes = the row's 4 blocks; OPSEL picks the k32 step's)
+__device__ __forceinline__ void load_sx(int (&sx)[NMB], const unsigned char* __restrict__ xs) {
+#pragma unroll
+    for (int mb = 0; mb < NMB; ++mb) sx[mb] = *reinterpret_cast<const int*>(xs + mb * 32 * ROW6);
+}
+
+template <bool SWAP>
+__device__ __forceinline__ void mfma_f16_phase(const WStep& w, const XF& x, f32x16 (&acc)[NMB]) {
+    const f16x8 w0 = __builtin_bit_cast(f16x8, w.h0), w1 = __builtin_bit_cast(f16x8, w.h1);
+#pragma unroll
+    for (int mb = 0; mb < NMB; ++mb) {
+        const f16x8 xv = __builtin_bit_cast(f16x8, x.v[0][mb]);
+        acc[mb] = SWAP ? __builtin_amdgcn_mfma_f32_32x32x16_f16(w0, xv, acc[mb], 0, 0, 0)
+                       : __builtin_amdgcn_mfma_f32_32x32x16_f16(xv, w0, acc[mb], 0, 0, 0);
+    }
+#pragma unroll
+    for (int mb = 0; mb < NMB; ++mb) {
+        const f16x8 xv = __builtin_bit_cast(f16x8, x.v[1][mb]);
+        acc[mb] = SWAP ? __builtin_amdgcn_mfma_f32_32x32x16_f16(w1, xv, acc[mb], 0, 0, 0)
+                       : __builtin_amdgcn_mfma_f32_32x32x16_f16(xv, w1, acc[mb], 0, 0, 0);
+    }
+}
+
+// J selects the byte of both scale words (OPSEL): the weight word holds the 4 k32 steps of the tap, the activation
+// word the 4 blocks of the row
+template <bool SWAP, int J>
+__device__ __forceinline__ void mfma_c6_phase(const WStep& w, const XC& x, int ws, const int (&sx)[NMB], f32x16 (&acc)[NMB]) {
+    const i32x8 wv = {(int)w.c0.x, (int)w.c0.y, (int)w.c0.z, (int)w.c0.w, (int)w.c1.x, (int)w.c1.y, 0, 0};
+#pragma unroll
+    for (int mb = 0; mb < NMB; ++mb) {
+        const i32x8 xv = x.v[mb];
+        acc[mb] = SWAP ? __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(wv, xv, acc[mb], 2, 2, J, ws, J, sx[mb])
+                       : __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(xv, wv, acc[mb], 2, 2, J, sx[mb], J, ws);
+    }
+}
+
+// One k32 step = two scheduling regions.  Region F: the 2*NMB f16 MFMAs of step j, with the fp6 activation fragments
+// of the SAME step (2*NMB LDS reads, + the tap's NMB scale words when J == 0) and the f16 weight fragments of step
+// j+3 (2 L2 loads) issued between them.  Region C: the NMB fp6 MFMAs (32 cycles each), with the f16 activation
+// fragments of step j+1 and the fp6 weight fragment of step j+3.
+template <bool SWAP, int J, int JN, bool LW, bool LX>
+__device__ __forceinline__ void k32_step(const WStep& wcur, WStep& wload, XF& xf, XC& xc, int (&sx)[NMB],
+                                         const unsigned char* __restrict__ xh_next, const unsigned char* __restrict__ xq,
+                                         const unsigned char* __restrict__ xs, wrsrc_t wr, int wnext,
+                                         uint32_t l16, int ws, f32x16 (&acc)[NMB]) {
+    load_xc<J>(xc, xq);
+    if constexpr (J == 0) load_sx(sx, xs);
+    if constexpr (LW) load_w_h(wload, wr, l16, wnext);
+    mfma_f16_phase<SWAP>(wcur, xf, acc);
+#pragma unroll
+    for (int i = 0; i < 2 * NMB; ++i) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                           // 1 MFMA
+        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                           // 1 DS read
+        if (J == 0 && i < NMB) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);    // + the tap's scale words
+        if (LW && (i == 1 || i == 5)) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);   // 1 VMEM read
+    }
+    GNN_REGION_END();
+    if constexpr (LX) load_xf<JN>(xf, xh_next);
+    if constexpr (LW) load_w_c(wload, wr, l16, wnext);
+    mfma_c6_phase<SWAP, J>(wcur, xc, ws, sx, acc);
+#pragma unroll
+    for (int i = 0; i < NMB; ++i) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        if (LX) __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+        if (LW && (i == 0 || i == 2)) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+    }
+    GNN_REGION_END();
+}
+
+// First three k32 steps of a tile's weights + its first scale word, loaded BEFORE the epilogue and barrier that
+// precede the tile (as in gnn_fused_c8.hip).
+struct WRing {
+    WStep w0, w1, w2;
+    int ws;
+};
+__device__ __forceinline__ void prefetch_w(WRing& r, wrsrc_t wr, int woff, const uint32_t* __restrict__ sbase, int lane) {
+    const uint32_t l16 = (uint32_t)lane * 16u;
+    load_w_h(r.w0, wr, l16, woff);
+    load_w_c(r.w0, wr, l16, woff);
+    load_w_h(r.w1, wr, l16, woff + WSTEP_B);
+    load_w_c(r.w1, wr, l16, woff + WSTEP_B);
+    load_w_h(r.w2, wr, l16, woff + 2 * WSTEP_B);
+    load_w_c(r.w2, wr, l16, woff + 2 * WSTEP_B);
+    r.ws = *reinterpret_cast<const int*>(reinterpret_cast<const unsigned char*>(sbase) + (uint32_t)lane * 4u);
+    asm volatile("" ::: "memory");
+}
+
+// FT6 rows x 32 columns, K = NTAPS * 128, as NTAPS * 4 k32 steps; weight ring of four k32 steps, the first three
+// already in flight (prefetch_w).  SWAP: D = W^T X^T for the convs (a lane ends up with 16 channels of one row),
+// D = X W for y @ w_v (a lane ends up with 16 rows of one channel: the max-pool is register local).
+template <bool SWAP, int NTAPS>
+__device__ __forceinline__ void gemm_tile(const unsigned char* __restrict__ xbuf, wrsrc_t wr, int woff,
+                                          const uint32_t* __restrict__ sbase, WRing& ring, f32x16 (&acc)[NMB], int lane) {
+    constexpr int NK = NTAPS * 4;
+    const unsigned char* xrow = xbuf + (lane & 31) * ROW6;
+    const unsigned char* xh = xrow + (lane >> 5) * 16;
+    const unsigned char* xq = xrow + X6A + (lane >> 5) * (L6A - X6A);
+    const unsigned char* xs = xrow + SXO + (lane >> 5) * (SLO - SXO);
+    const uint32_t l16 = (uint32_t)lane * 16u, lane_s = (uint32_t)lane * 4u;
+    WStep w3;
+    XF xf;
+    XC xc;
+    int sx[NMB];
+    int ws = ring.ws;
+    load_xf<0>(xf, xh);
+    GNN_REGION_END();
+#pragma unroll 1
+    for (int t = 0; t < NTAPS - 1; ++t) {
+        const int k = t * 4;
+        const unsigned char *th = xh + t * ROW6, *tq = xq + t * ROW6, *ts = xs + t * ROW6;
+        const int ws_next = *reinterpret_cast<const int*>(reinterpret_cast<const unsigned char*>(sbase + (t + 1) * 256) + lane_s);
+        k32_step<SWAP, 0, 1, true, true>(ring.w0, w3, xf, xc, sx, th, tq, ts, wr, woff + (k + 3) * WSTEP_B, l16, ws, acc);
+        k32_step<SWAP, 1, 2, true, true>(ring.w1, ring.w0, xf, xc, sx, th, tq, ts, wr, woff + (k + 4) * WSTEP_B, l16, ws, acc);
+        k32_step<SWAP, 2, 3, true, true>(ring.w2, ring.w1, xf, xc, sx, th, tq, ts, wr, woff + (k + 5) * WSTEP_B, l16, ws, acc);
+        k32_step<SWAP, 3, 0, true, true>(w3, ring.w2, xf, xc, sx, th + ROW6, tq, ts, wr, woff + (k + 6) * WSTEP_B, l16, ws, acc);
+        ws = ws_next;
+    }
+    {
+        const unsigned char *th = xh + (NTAPS - 1) * ROW6, *tq = xq + (NTAPS - 1) * ROW6, *ts = xs + (NTAPS - 1) * ROW6;
+        k32_step<SWAP, 0, 1, true, true>(ring.w0, w3, xf, xc, sx, th, tq, ts, wr, woff + (NK - 1) * WSTEP_B, l16, ws, acc);
+        k32_step<SWAP, 1, 2, false, true>(ring.w1, ring.w0, xf, xc, sx, th, tq, ts, wr, woff, l16, ws, acc);
+        k32_step<SWAP, 2, 3, false, true>(ring.w2, ring.w1, xf, xc, sx, th, tq, ts, wr, woff, l16, ws, acc);
+        k32_step<SWAP, 3, 0, false, false>(w3, ring.w2, xf, xc, sx, th, tq, ts, wr, woff, l16, ws, acc);
+    }
+}
+
+// biased f16 exponent (at least 1: the subnormal range shares the exponent of the smallest normals) of a
+// non-negative f32 value rounded to f16
+__device__ __forceinline__ uint32_t f16_exp(float amax) {
+    const _Float16 h = (_Float16)amax;
+    const uint32_t e = ((uint32_t)__builtin_bit_cast(unsigned short, h) >> 10) & 31u;
+    return e > 1u ? e : 1u;
+}
+
+// One (row, 32-channel block) unit, x[] = the block's activations after LeakyReLU in channel order -> the row's
+// operand images: h = f16(x) (RNE), x6 = e2m3(h / 2^(E-2)) with E = exponent of the block's largest |h|, and
+// xl6 = e2m3 of the f16 rounding residual, block scaled the same way (converted from f16((x - h) * 2^11), exact
+// up to f16's 11 bits; the 2^11 goes into the scale byte).  The scale bytes are what the MFMA multiplies the
+// fragments with (2^(byte - 127)).
+__device__ __forceinline__ void store_block32(unsigned char* __restrict__ row, int blk, const float (&x)[32]) {
+    f16x32 hv, rv;
+    float ax = 0.f, ar = 0.f;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        const f16x2 h = __builtin_convertvector(f32x2{x[2 * i], x[2 * i + 1]}, f16x2);
+        const float r0 = (x[2 * i] - (float)h[0]) * (float)(1 << XL_SHIFT), r1 = (x[2 * i + 1] - (float)h[1]) * (float)(1 << XL_SHIFT);
+        const f16x2 r = __builtin_convertvector(f32x2{r0, r1}, f16x2);
+        hv[2 * i] = h[0];
+        hv[2 * i + 1] = h[1];
+        rv[2 * i] = r[0];
+        rv[2 * i + 1] = r[1];
+        ax = fmaxf(ax, fmaxf(fabsf(x[2 * i]), fabsf(x[2 * i + 1])));
+        ar = fmaxf(ar, fmaxf(fabsf(r0), fabsf(r1)));
+    }
+    // E8M0 byte b <-> scale 2^(b - 127); e2m3 tops out at 7.5 = 1.875 * 2^2, so the block maximum (exponent e =
+    // E - 15) is divided by 2^(e - 2): b = E - 15 - 2 + 127
+    const uint32_t bx = f16_exp(ax) + 110u, br = f16_exp(ar) + 110u;
+    const i32x6 x6 = __builtin_amdgcn_cvt_scalef32_pk32_fp6_f16(hv, __uint_as_float(bx << 23));
+    const i32x6 l6 = __builtin_amdgcn_cvt_scalef32_pk32_fp6_f16(rv, __uint_as_float(br << 23));
+    uint4* hp = reinterpret_cast<uint4*>(row + blk * 64);
+    const uint4* hs = reinterpret_cast<const uint4*>(&hv);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) hp[i] = hs[i];
+    *reinterpret_cast<uint4*>(row + X6A + blk * 16) = make_uint4((uint32_t)x6[0], (uint32_t)x6[1], (uint32_t)x6[2], (uint32_t)x6[3]);
+    *reinterpret_cast<uint2*>(row + X6B + blk * 8) = make_uint2((uint32_t)x6[4], (uint32_t)x6[5]);
+    *reinterpret_cast<uint4*>(row + L6A + blk * 16) = make_uint4((uint32_t)l6[0], (uint32_t)l6[1], (uint32_t)l6[2], (uint32_t)l6[3]);
+    *reinterpret_cast<uint2*>(row + L6B + blk * 8) = make_uint2((uint32_t)l6[4], (uint32_t)l6[5]);
+    row[SXO + blk] = (unsigned char)bx;
+    row[SLO + blk] = (unsigned char)(br - XL_SHIFT);
+}
+
+// bias pre-loaded into the accumulators, D = W^T X^T layout: register r of lane l = channel 8 (r >> 2) + 4 (l >> 5) + (r & 3)
+__device__ __forceinline__ void acc_init_bias(f32x16 (&acc)[NMB], const float* __restrict__ bias, int wave, int lane) {
+#pragma unroll
+    for (int rg = 0; rg < 4; ++rg) {
+        const f32x4 b = *reinterpret_cast<const f32x4*>(bias + wave * 32 + rg * 8 + (lane >> 5) * 4);
+#pragma unroll
+        for (int mb = 0; mb < NMB; ++mb)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc[mb][rg * 4 + e] = b[e];
+    }
+}
+
+// The wave's 32 output channels are one block of the row.  A lane holds 16 of them (the other 16 sit in lane ^ 32),
+// so the m-blocks are taken in pairs: after 16 v_permlane32_swap lanes 0-31 hold all 32 channels of m-block p's row
+// l, lanes 32-63 all 32 channels of m-block p+1's row l & 31.
+__device__ __forceinline__ void conv_epilogue(unsigned char* __restrict__ obuf, const f32x16 (&acc)[NMB], int wave, int lane) {
+#pragma unroll
+    for (int p = 0; p < NMB; p += 2) {
+        const bool pair = p + 1 < NMB;
+        float v[32];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const unsigned a = __float_as_uint(acc[p][r]);
+            const unsigned b = __float_as_uint(acc[pair ? p + 1 : p][r]);
+            const auto sw = __builtin_amdgcn_permlane32_swap(a, b, false, false);   // {[a lanes 0-31 | b lanes 0-31], [a lanes 32-63 | b lanes 32-63]}
+            v[8 * (r >> 2) + (r & 3)] = lrelu_f(__uint_as_float(sw[0]));
+            v[8 * (r >> 2) + 4 + (r & 3)] = lrelu_f(__uint_as_float(sw[1]));
+        }
+        if (pair || lane < 32) store_block32(obuf + (CARRY + (p + (lane >> 5)) * 32 + (lane & 31)) * ROW6, wave, v);
+    }
+}
+
+__device__ __forceinline__ void wv_mfma(const unsigned char* __restrict__ xbuf, wrsrc_t wr, int woff,
+                                        const uint32_t* __restrict__ sbase, WRing& ring, f32x16 (&acc)[NMB], int lane) {
+#pragma unroll
+    for (int mb = 0; mb < NMB; ++mb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[mb][r] = 0.f;
+    gemm_tile<false, 1>(xbuf + CARRY * ROW6, wr, woff, sbase, ring, acc, lane);
+}
+// MaxPool1D(8) -> yp rows (igloo.py:209-210), as in gnn_fused_c8.hip
+__device__ __forceinline__ void wv_pool_store(const f32x16 (&acc)[NMB], float* __restrict__ yp_w, int t0, int wave, int lane) {
+    float m[4 * NMB];
+#pragma unroll
+    for (int i = 0; i < 4 * NMB; ++i) {
+        const int mb = i >> 2, rg = i & 3;
+        const float v = fmaxf(fmaxf(acc[mb][rg * 4], acc[mb][rg * 4 + 1]), fmaxf(acc[mb][rg * 4 + 2], acc[mb][rg * 4 + 3]));
+        const unsigned bits = __float_as_uint(v);
+        const auto sw = __builtin_amdgcn_permlane32_swap(bits, bits, false, false);
+        m[i] = fmaxf(v, __uint_as_float(lane < 32 ? sw[1] : sw[0]));
+    }
+    const int q0 = t0 / GNN_POOL;
+    const int nq = min(4 * NMB, POOLED - q0);
+    if (lane < 32) {
+        float* dst = yp_w + (size_t)q0 * C + wave * 32 + lane;
+#pragma unroll
+        for (int i = 0; i < 4 * NMB; ++i)
+            if (i < nq) dst[(size_t)i * C] = m[i];
+    }
+}
+
+// conv1 + LeakyReLU of one (row, block) unit: conv1 on a one-hot input is a row gather-sum of its kernel (model.py:11 +
+// igloo.py:45-48), 3 rows with the pair tables (gnn_fused_common.h).  The tables of this kernel are stored so that a
+// lane's 32 channels come as 8 loads of 16 B of which the 4 lanes of a row read 64 contiguous bytes each time.
+struct GatherUnit {
+    f32x4 v[3][8];
+};
+__device__ __forceinline__ void gather_issue(GatherUnit& g, const uint16_t* __restrict__ prow, const float* __restrict__ pt, int u, int p) {
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+        const uint32_t r = prow[u + 2 * j];
+        const float* src = pt + ((size_t)j * PAIR_ROWS + r) * C + p * 4;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) g.v[j][i] = *reinterpret_cast<const f32x4*>(src + i * 16);
+    }
+}
+__device__ __forceinline__ void gather_finish(const GatherUnit& g, unsigned char* __restrict__ xbuf, int u, int p) {
+    float x[32];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const f32x4 s = g.v[0][i] + g.v[1][i] + g.v[2][i];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) x[4 * i + e] = lrelu_f(s[e]);
+    }
+    store_block32(xbuf + (CARRY + u) * ROW6, p, x);
+}
+
+// IGLOO pair dot products (igloo.py:192-204 with w_mult * w_summer folded) of head B for the previous step's x3 rows
+// and of head A for this step's x1 rows in ONE loop: 4 lanes per entry, one 32-channel block per lane.  A row is read
+// back as f16 + residual image (x = f16 + e2m3 * 2^(scale byte - 127)); the hardware unpacks the 32 fp6 values.
+struct PairJob {
+    const unsigned char* xbuf;
+    const float* weff;
+    const int32_t* pos;
+    float* mp;
+    int t0, e, e_end;
+};
+__device__ __forceinline__ void m_partials2(PairJob jb, PairJob ja, int wave, int lane) {
+    const int p = lane & 3;
+    PairJob job[2] = {jb, ja};
+    int u[2];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        job[h].e += wave * 16 + (lane >> 2);
+        u[h] = job[h].e < job[h].e_end ? job[h].pos[job[h].e] : job[h].t0;
+    }
+    // the 4 lanes of an entry share e: a lane group enters / leaves together and the width-4 shuffles only read active lanes
+    while (job[0].e < job[0].e_end || job[1].e < job[1].e_end) {
+        float4 w[2][8];
+        uint4 hx[2][4], la[2];
+        uint2 lb[2];
+        uint32_t sb[2];
+        int un[2];
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int ei = max(min(job[h].e, job[h].e_end - 1), 0);   // clamped duplicates are computed, not stored
+            const float* wr = job[h].weff + (size_t)ei * C + p * 32;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) w[h][i] = *reinterpret_cast<const float4*>(wr + i * 4);
+        }
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const unsigned char* xr = job[h].xbuf + (CARRY + u[h] - job[h].t0) * ROW6;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) hx[h][i] = *reinterpret_cast<const uint4*>(xr + p * 64 + i * 16);
+            la[h] = *reinterpret_cast<const uint4*>(xr + L6A + p * 16);
+            lb[h] = *reinterpret_cast<const uint2*>(xr + L6B + p * 8);
+            sb[h] = xr[SLO + p];
+        }
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int en = job[h].e + 64;
+            un[h] = en < job[h].e_end ? job[h].pos[en] : job[h].t0;
+        }
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const i32x6 l6 = {(int)la[h].x, (int)la[h].y, (int)la[h].z, (int)la[h].w, (int)lb[h].x, (int)lb[h].y};
+            const f32x32 q = __builtin_amdgcn_cvt_scalef32_pk32_f32_fp6(l6, 1.0f);
+            float s = 0.f, r = 0.f;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const f16x8 hh = __builtin_bit_cast(f16x8, hx[h][i]);
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    const int c = i * 8 + k;
+                    const float4 wq = w[h][c >> 2];
+                    const float wc = (c & 3) == 0 ? wq.x : ((c & 3) == 1 ? wq.y : ((c & 3) == 2 ? wq.z : wq.w));
+                    s = fmaf((float)hh[k], wc, s);
+                    r = fmaf(q[c], wc, r);
+                }
+            }
+            s = fmaf(r, __uint_as_float(sb[h] << 23), s);
+            s += __shfl_xor(s, 1, 4);
+            s += __shfl_xor(s, 2, 4);
+            if (p == 0 && job[h].e < job[h].e_end) job[h].mp[job[h].e] = s;
+            u[h] = un[h];
+        }
+        job[0].e += 64;
+        job[1].e += 64;
+    }
+}
+
+// Barriers B1..B4 per step exactly as in gnn_fused_c8.hip:
+//   matrix : w_v A(s), conv2 loop [bufX] | B1 | epilogue -> bufY (x2) | B2 | conv3 loop [bufY] | B3 |
+//            epilogue -> bufY (x3) | B4 | w_v B(s) [bufY]   -> straight into step s+1
+//   helpers: pair rows of step s+1, pair products B(s-1) [bufY] and A(s) [bufX] | B1 | x1 carry rows, gather(s+1) loads
+//            of the first unit | B2 | gather(s+1) -> bufX, read x2 carry | B3 | x2 carry rows -> bufY | B4
+__global__ __launch_bounds__(512, 2) void fused_front_c6_kernel(Args a) {
+    __shared__ __attribute__((aligned(16))) unsigned char smem[SMEM6];
+    unsigned char* bufX = smem;
+    unsigned char* bufY = smem + BUF6_BYTES;
+    uint16_t* prow = reinterpret_cast<uint16_t*>(smem + PROW_OFF);
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const bool helper = wave >= 4;
+    const int hw = wave & 3;
+    const int ht = tid & 255;
+    const int64_t wi = blockIdx.x;
+    const uint8_t* bases = a.bases + wi * W;
+    float* mp_w[2] = {a.mp + (wi * 2 + 0) * NPAIR, a.mp + (wi * 2 + 1) * NPAIR};
+    float* yp_w[2] = {a.yp + (wi * 2 + 0) * (size_t)POOLED * C, a.yp + (wi * 2 + 1) * (size_t)POOLED * C};
+    const int woff = hw * WNBLK_B;                       // this wave's n-block inside every k32 step
+    const uint32_t* cs[2] = {a.conv_s[0] + hw * 64, a.conv_s[1] + hw * 64};
+    const uint32_t* vs[2] = {a.wv_s[0] + hw * 64, a.wv_s[1] + hw * 64};
+
+    // carry rows of the first step = the causal zero padding (zero fragments, scale bytes irrelevant but finite)
+    for (int i = tid; i < CARRY * ROW_U4; i += 512) {
+        reinterpret_cast<uint4*>(bufX)[i] = make_uint4(0, 0, 0, 0);
+        reinterpret_cast<uint4*>(bufY)[i] = make_uint4(0, 0, 0, 0);
+    }
+    // pair rows of step 0: prow[i] = pair row of positions (t0 - 5 + i, t0 - 4 + i)
+    if (tid < PROW_N) prow[tid] = (uint16_t)pair_row(token_state(bases, tid - CARRY), token_state(bases, tid - CARRY + 1));
+    __syncthreads();
+    const int gp = ht & 3, gu = ht >> 2;                 // conv1 gather unit of this helper thread: block, row (+ 64 per round)
+    constexpr int GROUNDS = (FT6 + 63) / 64;
+
+    if (!helper) {
+        __builtin_amdgcn_s_setprio(2);
+        const wrsrc_t cw[2] = {make_wrsrc(a.conv_w[0], KS * 4 * WSTEP_B), make_wrsrc(a.conv_w[1], KS * 4 * WSTEP_B)};
+        const wrsrc_t vw[2] = {make_wrsrc(a.wv_w[0], 4 * WSTEP_B), make_wrsrc(a.wv_w[1], 4 * WSTEP_B)};
+        WRing ring;
+        prefetch_w(ring, vw[0], woff, vs[0], lane);
+        __syncthreads();                                                         // x1 of step 0 is in bufX
+#pragma unroll 1
+        for (int step = 0; step < STEPS6; ++step) {
+            const int t0 = step * FT6;
+            f32x16 acc[NMB];
+            wv_mfma(bufX, vw[0], woff, vs[0], ring, acc, lane);
+            prefetch_w(ring, cw[0], woff, cs[0], lane);                                // conv2 weights, hidden by the pooling
+            wv_pool_store(acc, yp_w[0], t0, hw, lane);
+            acc_init_bias(acc, a.conv_b[0], hw, lane);
+            gemm_tile<true, KS>(bufX, cw[0], woff, cs[0], ring, acc, lane);
+            prefetch_w(ring, cw[1], woff, cs[1], lane);                                // conv3 weights, hidden by epilogue + barriers
+            __syncthreads();                                                     // ---- B1
+            conv_epilogue(bufY, acc, hw, lane);
+            __syncthreads();                                                     // ---- B2
+            acc_init_bias(acc, a.conv_b[1], hw, lane);
+            gemm_tile<true, KS>(bufY, cw[1], woff, cs[1], ring, acc, lane);
+            prefetch_w(ring, vw[1], woff, vs[1], lane);                                // w_v of head B
+            __syncthreads();                                                     // ---- B3
+            conv_epilogue(bufY, acc, hw, lane);
+            __syncthreads();                                                     // ---- B4
+            wv_mfma(bufY, vw[1], woff, vs[1], ring, acc, lane);
+            prefetch_w(ring, vw[0], woff, vs[0], lane);                                // w_v of head A for the next step
+            wv_pool_store(acc, yp_w[1], t0, hw, lane);
+        }
+    } else {
+        {
+            GatherUnit g;
+#pragma unroll
+            for (int k = 0; k < GROUNDS; ++k)
+                if (gu + 64 * k < FT6) {
+                    gather_issue(g, prow, a.conv1_k, gu + 64 * k, gp);
+                    gather_finish(g, bufX, gu + 64 * k, gp);
+                }
+        }
+        __syncthreads();
+#pragma unroll 1
+        for (int step = 0; step < STEPS6; ++step) {
+            const int t0 = step * FT6;
+            // pair rows of the next step (its gather runs behind B1; the previous gather finished before B4)
+            if (ht < PROW_N) {
+                const int t = t0 + FT6 - CARRY + ht;
+                prow[ht] = (uint16_t)pair_row(token_state(bases, t), token_state(bases, t + 1));
+            }
+            {
+                const int sb = max(step - 1, 0);                                 // step 0: empty head-B range
+                const PairJob jb = {bufY, a.weff[1], a.pos_sorted[1], mp_w[1], t0 - FT6,
+                                    step > 0 ? a.bucket_ptr[1][sb] : 0, step > 0 ? a.bucket_ptr[1][sb + 1] : 0};
+                const PairJob ja = {bufX, a.weff[0], a.pos_sorted[0], mp_w[0], t0, a.bucket_ptr[0][step], a.bucket_ptr[0][step + 1]};
+                m_partials2(jb, ja, hw, lane);
+            }
+            uint4 carry = make_uint4(0, 0, 0, 0);
+            const int cr = ht / ROW_U4, cc = ht - cr * ROW_U4;   // 5 rows x 29 chunks of 16 B
+            if (ht < CARRY * ROW_U4) carry = *reinterpret_cast<const uint4*>(bufX + (FT6 + cr) * ROW6 + cc * 16);
+            __syncthreads();                                                     // ---- B1
+            if (ht < CARRY * ROW_U4) *reinterpret_cast<uint4*>(bufX + cr * ROW6 + cc * 16) = carry;
+            GatherUnit g;
+            gather_issue(g, prow, a.conv1_k, gu, gp);                            // in flight across the short B1..B2 span
+            __syncthreads();                                                     // ---- B2
+            gather_finish(g, bufX, gu, gp);
+#pragma unroll
+            for (int k = 1; k < GROUNDS; ++k)
+                if (gu + 64 * k < FT6) {
+                    gather_issue(g, prow, a.conv1_k, gu + 64 * k, gp);
+                    gather_finish(g, bufX, gu + 64 * k, gp);
+                }
+            if (ht < CARRY * ROW_U4) carry = *reinterpret_cast<const uint4*>(bufY + (FT6 + cr) * ROW6 + cc * 16);
+            __syncthreads();                                                     // ---- B3
+            if (ht < CARRY * ROW_U4) *reinterpret_cast<uint4*>(bufY + cr * ROW6 + cc * 16) = carry;
+            __syncthreads();                                                     // ---- B4
+        }
+        const PairJob jb = {bufY, a.weff[1], a.pos_sorted[1], mp_w[1], (STEPS6 - 1) * FT6, a.bucket_ptr[1][STEPS6 - 1],
+                            a.bucket_ptr[1][STEPS6]};
+        const PairJob none = {bufX, a.weff[0], a.pos_sorted[0], mp_w[0], 0, 0, 0};
+        m_partials2(jb, none, hw, lane);
+    }
+}
+
+// ---------------------------------------------------------------------------------- host side
+static double e2m3_value(uint32_t c) {
+    const int e = (c >> 3) & 3, m = c & 7;
+    return e == 0 ? m / 8.0 : (1 + m / 8.0) * std::ldexp(1.0, e - 1);
+}
+// e2m3 encode, round to nearest (ties to the even code), saturating at 7.5
+static uint32_t e2m3_encode(double x) {
+    const uint32_t s = std::signbit(x) ? 32u : 0u;
+    const double a = std::fabs(x);
+    uint32_t best = 0;
+    double bd = 1e300;
+    for (uint32_t c = 0; c < 32; ++c) {
+        const double d = std::fabs(e2m3_value(c) - a);
+        if (d < bd || (d == bd && !(c & 1))) bd = d, best = c;
+    }
+    return s | best;
+}
+// OCP MX block exponent for e2m3 elements: floor(log2(amax)) - 2 (oracle/precision_study.py rnd_mx)
+static int mx6_exponent(double amax) {
+    if (!(amax > 0)) return -127 + 1;
+    int e;
+    std::frexp(amax, &e);           // amax = f * 2^e, f in [0.5, 1)  ->  floor(log2 amax) = e - 1
+    return std::min(std::max(e - 1 - 2, -126), 127);
+}
+static void put6(uint32_t* w, int i, uint32_t c) {
+    const int bit = i * 6, k = bit >> 5, o = bit & 31;
+    w[k] |= c << o;
+    if (o > 26) w[k + 1] |= c >> (32 - o);
+}
+
+// Wmat (K x N row major; K, N multiples of 32) -> the Args weight stream and scale words.
+static void pack_c6(const float* wmat, int K, int N, std::vector<uint32_t>& frags, std::vector<uint32_t>& scales) {
+    const int nk32 = K / 32, nblks = N / 32, ntaps = (nk32 + 3) / 4;
+    frags.assign((size_t)nk32 * nblks * (WNBLK_B / 4), 0);
+    scales.assign((size_t)ntaps * nblks * 64, 0x7F7F7F7Fu);
+    for (int ks = 0; ks < nk32; ++ks)
+        for (int nb = 0; nb < nblks; ++nb) {
+            unsigned char* bytes = reinterpret_cast<unsigned char*>(&frags[((size_t)ks * nblks + nb) * (WNBLK_B / 4)]);
+            for (int l = 0; l < 64; ++l) {
+                const int n = nb * 32 + (l & 31), half = l >> 5;
+                for (int s = 0; s < 2; ++s)             // f16 fragments: k = ks*32 + s*16 + half*8 + e
+                    for (int e = 0; e < 8; ++e) {
+                        const _Float16 h = (_Float16)wmat[(size_t)(ks * 32 + s * 16 + half * 8 + e) * N + n];
+                        std::memcpy(bytes + (size_t)s * 1024 + l * 16 + e * 2, &h, 2);
+                    }
+                // fp6 fragment of this lane: K block `half` = (w - f16 w) for lanes 0-31, w for lanes 32-63, over
+                // the 32 k of the step in natural order
+                double v[32], amax = 0;
+                for (int i = 0; i < 32; ++i) {
+                    const float wv = wmat[(size_t)(ks * 32 + i) * N + n];
+                    v[i] = half == 0 ? (double)wv - (double)(float)(_Float16)wv : (double)wv;
+                    amax = std::max(amax, std::fabs(v[i]));
+                }
+                const int e = mx6_exponent(amax);
+                uint32_t f[6] = {0, 0, 0, 0, 0, 0};
+                for (int i = 0; i < 32; ++i) put6(f, i, e2m3_encode(v[i] / std::ldexp(1.0, e)));
+                std::memcpy(bytes + 2048 + l * 16, f, 16);
+                std::memcpy(bytes + 3072 + l * 8, f + 4, 8);
+                unsigned char* sc = reinterpret_cast<unsigned char*>(&scales[((size_t)(ks >> 2) * nblks + nb) * 64 + l]);
+                sc[ks & 3] = (unsigned char)(e + 127);
+            }
+        }
+}
+
+template <typename Tp>
+static int upload_vec(gnn_ctx* ctx, const std::vector<Tp>& v, Tp** dev) {
+    void* p = nullptr;
+    GNN_HIP(hipMalloc(&p, v.size() * sizeof(Tp)));
+    ctx->owned.push_back(p);
+    GNN_HIP(hipMemcpy(p, v.data(), v.size() * sizeof(Tp), hipMemcpyHostToDevice));
+    *dev = static_cast<Tp*>(p);
+    return GNN_OK;
+}
+
+}  // namespace c6
+
+int pack_fused_c6_weights(gnn_ctx* ctx, const gnn_weights* w) {
+    using namespace c6;
+    DeviceWeights& d = ctx->w;
+    const float* ck[2] = {w->conv2_kernel, w->conv3_kernel};
+    const gnn_igloo_weights* ig[2] = {&w->igloo_a, &w->igloo_b};
+    std::vector<uint32_t> f, s;
+    int rc;
+    for (int i = 0; i < 2; ++i) {
+        pack_c6(ck[i], KS * C, C, f, s);
+        if ((rc = upload_vec(ctx, f, &d.conv_c6[i]))) return rc;
+        if ((rc = upload_vec(ctx, s, &d.conv_c6s[i]))) return rc;
+        pack_c6(ig[i]->w_v, C, C, f, s);
+        if ((rc = upload_vec(ctx, f, &d.wv_c6[i]))) return rc;
+        if ((rc = upload_vec(ctx, s, &d.wv_c6s[i]))) return rc;
+        // entry ranges of the position-sorted IGLOO pairs per step of FT6 rows
+        std::vector<int32_t> ptr(STEPS6 + 1, 0);
+        for (int e = 0; e < NPAIR; ++e) ptr[ig[i]->patches[e] / FT6 + 1] += 1;
+        for (int st = 0; st < STEPS6; ++st) ptr[st + 1] += ptr[st];
+        if ((rc = upload_vec(ctx, ptr, &d.bucket_ptr6[i]))) return rc;
+    }
+    // conv1 pair tables in the lane order of this kernel's gather, conv1 bias folded into table 0 (every position adds
+    // exactly one row of each table)
+    std::vector<float> pt;
+    build_conv1_pair_tables(w->conv1_kernel, pt);
+    std::vector<float> pq(pt.size());
+    for (int j = 0; j < 3; ++j)
+        for (int r = 0; r < PAIR_ROWS; ++r) {
+            const float* src = &pt[((size_t)j * PAIR_ROWS + r) * C];
+            float* dst = &pq[((size_t)j * PAIR_ROWS + r) * C];
+            for (int c = 0; c < C; ++c) {
+                const int p = c >> 5, i = (c >> 2) & 7, e = c & 3;
+                dst[i * 16 + p * 4 + e] = src[c] + (j == 0 ? w->conv1_bias[c] : 0.f);
+            }
+        }
+    if ((rc = upload_vec(ctx, pq, &d.conv1_pairs6))) return rc;
+    return GNN_OK;
+}
+
+int launch_front_c6(gnn_ctx* ctx, const uint8_t* bases, int64_t n) {
+    using namespace c6;
+    const DeviceWeights& d = ctx->w;
+    Args a;
+    a.bases = bases;
+    a.conv1_k = d.conv1_pairs6;
+    for (int i = 0; i < 2; ++i) {
+        a.conv_w[i] = reinterpret_cast<const unsigned char*>(d.conv_c6[i]);
+        a.conv_s[i] = d.conv_c6s[i];
+        a.conv_b[i] = d.conv_b[i];
+        a.wv_w[i] = reinterpret_cast<const unsigned char*>(d.wv_c6[i]);
+        a.wv_s[i] = d.wv_c6s[i];
+        a.weff[i] = d.weff_sorted[i];
+        a.pos_sorted[i] = d.pos_sorted[i];
+        a.bucket_ptr[i] = d.bucket_ptr6[i];
+    }
+    a.mp = ctx->ws.mp;
+    a.yp = ctx->ws.yp;
+    hipLaunchKernelGGL(fused_front_c6_kernel, dim3((unsigned)n), dim3(512), 0, ctx->stream, a);
+    GNN_HIP(hipGetLastError());
+    return GNN_OK;
+}
+
+}  // namespace gnn

@@ -219,7 +219,7 @@ def _engine():
     return _ENGINE
 
 
-F16_MODES = ("f16c8", "f16x3")     # their operands are f16: activations beyond 65504 overflow to inf -> NaN scores
+F16_MODES = ("f16c8", "f16c6", "f16x3")     # their operands are f16: activations beyond 65504 overflow to inf -> NaN scores
 _WARNED = set()
 
 
