@@ -47,8 +47,9 @@ MFMA_PEAK_TFLOPS = 2500.0              # MI355X_MICROARCH.md: dense bf16 / f16 M
 ENCODER_BYTES = {"u8": 6000 + 5997 * 257, "bf16": 6000 + 5997 * 257 * 2, "f32": 6000 + 5997 * 257 * 4}
 HBM_PEAK_GBS = 8000.0
 # matrix-pipe cost of one product in units of one bf16/f16 pass (f16c8: 1 f16 pass + 2 fp8 corrections at 2x rate)
-MFMA_PASSES = {"f16c8": 2.0, "f16x3": 3.0, "bf16x3": 3.0, "bf16": 1.0}
-DTYPE_TEXT = {"f16c8": "f16 MFMA + MX-fp8 (e4m3) correction MFMAs, f32 accumulate (2.0 bf16-pass equivalents)",
+MFMA_PASSES = {"f16c6": 1.5, "f16c8": 2.0, "f16x3": 3.0, "bf16x3": 3.0, "bf16": 1.0}
+DTYPE_TEXT = {"f16c6": "f16 MFMA + MX-fp6 (e2m3, both operands block scaled) correction MFMAs, f32 accumulate (1.5 f16-pass equivalents)",
+              "f16c8": "f16 MFMA + MX-fp8 (e4m3) correction MFMAs, f32 accumulate (2.0 bf16-pass equivalents)",
               "f16x3": "f16x3 (split-f16 MFMA, 3 passes, f32 accumulate, exact-f32 logits GEMM)",
               "bf16x3": "bf16x3 (split-bf16 MFMA, 3 passes, f32 accumulate)", "bf16": "bf16", "f32": "f32"}
 
@@ -97,7 +98,7 @@ def main():
                     "or of every rank (weak)")
     ap.add_argument("--scaling", default="strong", choices=["strong", "weak"])
     ap.add_argument("--chunk", type=int, default=4096, help="windows per launch of the fused kernel")
-    ap.add_argument("--precision", default="f16c8", choices=["f16c8", "f16x3", "bf16x3", "bf16", "f32"])
+    ap.add_argument("--precision", default="f16c8", choices=["f16c6", "f16c8", "f16x3", "bf16x3", "bf16", "f32"])
     ap.add_argument("--cpu-sample", type=int, default=1024, help="windows for the CPU baseline (0 = skip)")
     ap.add_argument("--kernel", default="classify", choices=["classify", "encoder"],
                     help="'encoder' benches the stand-alone byte->one-hot HBM kernel instead")
@@ -308,7 +309,7 @@ def main():
             "bound": "mfma", "achieved": round(tflops, 2), "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
             "frac": round(tflops / MFMA_PEAK_TFLOPS, 4), "traffic": traffic, "traffic_source": traffic_source,
             "algorithmic_bytes_per_launch": int(6012 * win_per_launch),
-            "kernel": {"f16c8": "fused_front_c8_kernel", "f32": "f32 front end (5 kernels)"}.get(args.precision, "fused_front_kernel"),
+            "kernel": {"f16c6": "fused_front_c6_kernel", "f16c8": "fused_front_c8_kernel", "f32": "f32 front end (5 kernels)"}.get(args.precision, "fused_front_kernel"),
             "flop_per_launch": int(FLOP_PER_WINDOW * win_per_launch), "avg_launch_ms": round(avg_ms, 4),
             "launches": int(front_launches), "mfma_passes": passes,
             "note": "achieved counts ALGORITHMIC flops (2.763 GFLOP/window) against the dense 16-bit MFMA peak; the "

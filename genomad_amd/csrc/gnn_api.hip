@@ -219,7 +219,16 @@ extern "C" {
 
 const char* gnn_last_error(void) { return g_last_error.c_str(); }
 
-int gnn_version(void) { return 200; }
+int gnn_version(void) { return 210; }
+
+int gnn_fused_rows_per_step(int precision) {
+    switch (precision) {
+        case GNN_PREC_F32: return 0;
+        case GNN_PREC_F16C6: return c6_rows_per_step();
+        case GNN_PREC_BF16X3: case GNN_PREC_BF16: case GNN_PREC_F16C8: case GNN_PREC_F16X3: return FT;
+        default: return GNN_ERR_ARG;
+    }
+}
 
 // CRC-32C (Castagnoli, reflected polynomial 0x82F63B78) of a host buffer — the checksum of the
 // TFRecord framing the reference writes its encoded windows with (nn_classification.py:43-52).

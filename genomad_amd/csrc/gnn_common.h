@@ -83,10 +83,9 @@ struct DeviceWeights {
     // f16 + MX-fp6-correction packs (gnn_fused_c6.hip): [k32 step][nblk 4][f16 even 1 KiB | f16 odd 1 KiB | fp6 dwords 0-3 1 KiB |
     // fp6 dwords 4-5 512 B], scale words as above, pair tables in the gather's lane order (bias folded), entry ranges per step
     uint32_t* conv_c6[2] = {nullptr, nullptr};
-    uint32_t* conv_c6s[2] = {nullptr, nullptr};
     uint32_t* wv_c6[2] = {nullptr, nullptr};
-    uint32_t* wv_c6s[2] = {nullptr, nullptr};
     float* conv1_pairs6 = nullptr;
+    float* weff6[2] = {nullptr, nullptr};      // folded IGLOO weights, entry pairs x [i 8][entry parity][block 4][4 ch]
     int32_t* bucket_ptr6[2] = {nullptr, nullptr};
 };
 
@@ -159,6 +158,7 @@ int launch_front_c6(gnn_ctx* ctx, const uint8_t* bases, int64_t n);             
 int pack_fused_weights(gnn_ctx* ctx, const gnn_weights* w);
 int pack_fused_c8_weights(gnn_ctx* ctx, const gnn_weights* w);
 int pack_fused_c6_weights(gnn_ctx* ctx, const gnn_weights* w);
+int c6_rows_per_step();
 // conv1 pair tables (3, PAIR_ROWS, 128): W1[2j][a] + W1[2j+1][b] for every token pair of adjacent positions (gnn_api.hip)
 void build_conv1_pair_tables(const float* conv1_kernel, std::vector<float>& pt);
 

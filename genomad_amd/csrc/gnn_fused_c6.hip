@@ -47,13 +47,24 @@ constexpr int BUF6_ROWS = CARRY + FT6;
 constexpr int BUF6_BYTES = BUF6_ROWS * ROW6;
 constexpr int PROW_OFF = 2 * BUF6_BYTES;
 constexpr int PROW_N = FT6 + 4;              // pair rows a step's conv1 gather reads
-constexpr int SMEM6 = PROW_OFF + ((PROW_N * 2 + 15) / 16) * 16;
+constexpr int BIAS_OFF = PROW_OFF + ((PROW_N * 2 + 15) / 16) * 16;   // conv2 | conv3 bias, 2 x 128 f32
+constexpr int SMEM6 = BIAS_OFF + 2 * C * 4;
 constexpr int XL_SHIFT = 11;                 // the residual is converted from f16((x - f16 x) * 2^11)
 constexpr int WNBLK_B = 3584;                // weight bytes per (k32 step, n-block): f16 k16 even | f16 k16 odd | fp6 16-B parts | fp6 8-B parts
 constexpr int WSTEP_B = 4 * WNBLK_B;         // per k32 step
 constexpr int ROW_U4 = ROW6 / 16;            // 29
+// 8-B parts: slot (block ^ bit 4 of the buffer row) — with the 464-B stride rows R and R+16 start on the same bank, and a
+// ds_read_b64 serves 32 consecutive rows per LDS cycle; swapping neighbouring slots in every other group of 16 rows makes
+// those reads conflict free.  GNN_C6_NOSWZ: measurement variant.
+#ifdef GNN_C6_NOSWZ
+__device__ __forceinline__ int swz(int) { return 0; }
+#else
+__device__ __forceinline__ int swz(int buf_row) { return (buf_row >> 4) & 1; }
+#endif
 static_assert(SMEM6 <= 160 * 1024, "LDS budget");
+static_assert(FT6 % 32 == 0, "carry-row copies keep bit 4 of the row index");
 static_assert(PROW_N <= 256, "one helper thread per pair row");
+static_assert(FT6 % 2 == 0, "the conv1 gather works on row pairs");
 
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
@@ -64,17 +75,17 @@ typedef int i32x6 __attribute__((ext_vector_type(6)));
 
 struct Args {
     const uint8_t* bases;
-    const float* conv1_k;             // (3, PAIR_ROWS, 128) f32 pair tables, channel 32p + 4i + e at i*16 + p*4 + e, bias folded into table 0
-    const unsigned char* conv_w[2];   // [k32 step 24][nblk 4][3584 B]
-    const uint32_t* conv_s[2];        // [tap 6][nblk 4][lane 64] u32: byte j = E8M0 scale of k32 step 4*tap + j
+    const float* conv1_k;             // (3, PAIR_ROWS, 128) f32 pair tables in the gather's lane order (GatherUnit), bias folded into table 0
+    const unsigned char* conv_w[2];   // [k32 step 24][nblk 4][3584 B], then [tap 6][nblk 4][lane 64] u32: byte j = E8M0 scale of k32 step 4*tap + j
     const float* conv_b[2];
     const unsigned char* wv_w[2];     // same layouts, 4 k32 steps / 1 tap
-    const uint32_t* wv_s[2];
     const float* weff[2];
     const int32_t* pos_sorted[2];
     const int32_t* bucket_ptr[2];     // (STEPS6 + 1,) entry ranges per step of FT6 rows
     float* mp;
     float* yp;
+    unsigned long long* cycles;       // PROF builds: 16 phase counters (GNN_TICK in gnn_fused_common.h), summed over workgroups:
+                                      // matrix wave 0 -> 0..7, helper wave 4 -> 8..15 (names in scripts/c6_check.py)
 };
 
 struct WStep {
@@ -110,7 +121,14 @@ __device__ __forceinline__ void load_w_h(WStep& w, wrsrc_t r, uint32_t l16, int 
 }
 __device__ __forceinline__ void load_w_c(WStep& w, wrsrc_t r, uint32_t l16, int soff) {
     const u32x4 a = __builtin_amdgcn_raw_buffer_load_b128(r, l16 + 2048, soff, 0);
+#if defined(GNN_ABL_NOC1)      // measurement variants: is the cost of a weight load its bytes or its instruction?
+    const u32x2 b = {a[0], a[1]};
+#elif defined(GNN_ABL_C1X4)
+    const u32x4 b4 = __builtin_amdgcn_raw_buffer_load_b128(r, l16 + 2560, soff, 0);
+    const u32x2 b = {b4[0], b4[1]};
+#else
     const u32x2 b = __builtin_amdgcn_raw_buffer_load_b64(r, (l16 >> 1) + 3072, soff, 0);
+#endif
     w.c0 = make_uint4(a[0], a[1], a[2], a[3]);
     w.c1 = make_uint2(b[0], b[1]);
 }
@@ -123,12 +141,13 @@ __device__ __forceinline__ void load_xf(XF& f, const unsigned char* __restrict__
         for (int mb = 0; mb < NMB; ++mb) f.v[s][mb] = *reinterpret_cast<const uint4*>(xh + mb * 32 * ROW6 + (J * 2 + s) * 32);
 }
 // xq = lane base of the tap row's fp6 planes (x image for lanes 0-31, residual image for lanes 32-63)
+// x8 = the same + 64 +- 8 * swz(row): its slot J is the row's swizzled slot for even J (+) / odd J (-)
 template <int J>
-__device__ __forceinline__ void load_xc(XC& f, const unsigned char* __restrict__ xq) {
+__device__ __forceinline__ void load_xc(XC& f, const unsigned char* __restrict__ xq, const unsigned char* __restrict__ x8) {
 #pragma unroll
     for (int mb = 0; mb < NMB; ++mb) {
         const uint4 a = *reinterpret_cast<const uint4*>(xq + mb * 32 * ROW6 + J * 16);
-        const uint2 b = *reinterpret_cast<const uint2*>(xq + mb * 32 * ROW6 + (X6B - X6A) + J * 8);
+        const uint2 b = *reinterpret_cast<const uint2*>(x8 + mb * 32 * ROW6 + J * 8);
         f.v[mb] = i32x8{(int)a.x, (int)a.y, (int)a.z, (int)a.w, (int)b.x, (int)b.y, 0, 0};
     }
 }
@@ -175,12 +194,20 @@ __device__ __forceinline__ void mfma_c6_phase(const WStep& w, const XC& x, int w
 template <bool SWAP, int J, int JN, bool LW, bool LX>
 __device__ __forceinline__ void k32_step(const WStep& wcur, WStep& wload, XF& xf, XC& xc, int (&sx)[NMB],
                                          const unsigned char* __restrict__ xh_next, const unsigned char* __restrict__ xq,
-                                         const unsigned char* __restrict__ xs, wrsrc_t wr, int wnext,
+                                         const unsigned char* __restrict__ x8, const unsigned char* __restrict__ xs, wrsrc_t wr, int wnext,
                                          uint32_t l16, int ws, f32x16 (&acc)[NMB]) {
-    load_xc<J>(xc, xq);
+    // GNN_ABL_*: measurement-only ablations (scripts/mkvariant.sh) that compile parts of the work out — wrong results
+    // by construction, used to see what the launch time is made of (profiles/README.md)
+#ifndef GNN_ABL_NOX
+    load_xc<J>(xc, xq, x8);
     if constexpr (J == 0) load_sx(sx, xs);
+#endif
+#ifndef GNN_ABL_NOW
     if constexpr (LW) load_w_h(wload, wr, l16, wnext);
+#endif
+#ifndef GNN_ABL_NOF16
     mfma_f16_phase<SWAP>(wcur, xf, acc);
+#endif
 #pragma unroll
     for (int i = 0; i < 2 * NMB; ++i) {
         __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                           // 1 MFMA
@@ -189,9 +216,15 @@ __device__ __forceinline__ void k32_step(const WStep& wcur, WStep& wload, XF& xf
         if (LW && (i == 1 || i == 5)) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);   // 1 VMEM read
     }
     GNN_REGION_END();
+#ifndef GNN_ABL_NOX
     if constexpr (LX) load_xf<JN>(xf, xh_next);
+#endif
+#ifndef GNN_ABL_NOW
     if constexpr (LW) load_w_c(wload, wr, l16, wnext);
+#endif
+#ifndef GNN_ABL_NOC6
     mfma_c6_phase<SWAP, J>(wcur, xc, ws, sx, acc);
+#endif
 #pragma unroll
     for (int i = 0; i < NMB; ++i) {
         __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
@@ -207,7 +240,8 @@ struct WRing {
     WStep w0, w1, w2;
     int ws;
 };
-__device__ __forceinline__ void prefetch_w(WRing& r, wrsrc_t wr, int woff, const uint32_t* __restrict__ sbase, int lane) {
+template <int NTAPS>
+__device__ __forceinline__ void prefetch_w(WRing& r, wrsrc_t wr, int woff, int hw, int lane) {
     const uint32_t l16 = (uint32_t)lane * 16u;
     load_w_h(r.w0, wr, l16, woff);
     load_w_c(r.w0, wr, l16, woff);
@@ -215,16 +249,16 @@ __device__ __forceinline__ void prefetch_w(WRing& r, wrsrc_t wr, int woff, const
     load_w_c(r.w1, wr, l16, woff + WSTEP_B);
     load_w_h(r.w2, wr, l16, woff + 2 * WSTEP_B);
     load_w_c(r.w2, wr, l16, woff + 2 * WSTEP_B);
-    r.ws = *reinterpret_cast<const int*>(reinterpret_cast<const unsigned char*>(sbase) + (uint32_t)lane * 4u);
+    r.ws = (int)__builtin_amdgcn_raw_buffer_load_b32(wr, (uint32_t)lane * 4u, NTAPS * 4 * WSTEP_B + hw * 256, 0);   // scale word of tap 0
     asm volatile("" ::: "memory");
 }
 
 // FT6 rows x 32 columns, K = NTAPS * 128, as NTAPS * 4 k32 steps; weight ring of four k32 steps, the first three
 // already in flight (prefetch_w).  SWAP: D = W^T X^T for the convs (a lane ends up with 16 channels of one row),
 // D = X W for y @ w_v (a lane ends up with 16 rows of one channel: the max-pool is register local).
-template <bool SWAP, int NTAPS>
+template <bool SWAP, int NTAPS, int ROW0>   // ROW0 = buffer row of xbuf's first row (the swizzle needs absolute rows)
 __device__ __forceinline__ void gemm_tile(const unsigned char* __restrict__ xbuf, wrsrc_t wr, int woff,
-                                          const uint32_t* __restrict__ sbase, WRing& ring, f32x16 (&acc)[NMB], int lane) {
+                                          int hw, WRing& ring, f32x16 (&acc)[NMB], int lane) {
     constexpr int NK = NTAPS * 4;
     const unsigned char* xrow = xbuf + (lane & 31) * ROW6;
     const unsigned char* xh = xrow + (lane >> 5) * 16;
@@ -242,19 +276,23 @@ __device__ __forceinline__ void gemm_tile(const unsigned char* __restrict__ xbuf
     for (int t = 0; t < NTAPS - 1; ++t) {
         const int k = t * 4;
         const unsigned char *th = xh + t * ROW6, *tq = xq + t * ROW6, *ts = xs + t * ROW6;
-        const int ws_next = *reinterpret_cast<const int*>(reinterpret_cast<const unsigned char*>(sbase + (t + 1) * 256) + lane_s);
-        k32_step<SWAP, 0, 1, true, true>(ring.w0, w3, xf, xc, sx, th, tq, ts, wr, woff + (k + 3) * WSTEP_B, l16, ws, acc);
-        k32_step<SWAP, 1, 2, true, true>(ring.w1, ring.w0, xf, xc, sx, th, tq, ts, wr, woff + (k + 4) * WSTEP_B, l16, ws, acc);
-        k32_step<SWAP, 2, 3, true, true>(ring.w2, ring.w1, xf, xc, sx, th, tq, ts, wr, woff + (k + 5) * WSTEP_B, l16, ws, acc);
-        k32_step<SWAP, 3, 0, true, true>(w3, ring.w2, xf, xc, sx, th + ROW6, tq, ts, wr, woff + (k + 6) * WSTEP_B, l16, ws, acc);
+        const int sw8 = swz((lane & 31) + t + ROW0) * 8;
+        const unsigned char *te = tq + (X6B - X6A) + sw8, *to = tq + (X6B - X6A) - sw8;
+        const int ws_next = (int)__builtin_amdgcn_raw_buffer_load_b32(wr, lane_s, NK * WSTEP_B + (t + 1) * 1024 + hw * 256, 0);
+        k32_step<SWAP, 0, 1, true, true>(ring.w0, w3, xf, xc, sx, th, tq, te, ts, wr, woff + (k + 3) * WSTEP_B, l16, ws, acc);
+        k32_step<SWAP, 1, 2, true, true>(ring.w1, ring.w0, xf, xc, sx, th, tq, to, ts, wr, woff + (k + 4) * WSTEP_B, l16, ws, acc);
+        k32_step<SWAP, 2, 3, true, true>(ring.w2, ring.w1, xf, xc, sx, th, tq, te, ts, wr, woff + (k + 5) * WSTEP_B, l16, ws, acc);
+        k32_step<SWAP, 3, 0, true, true>(w3, ring.w2, xf, xc, sx, th + ROW6, tq, to, ts, wr, woff + (k + 6) * WSTEP_B, l16, ws, acc);
         ws = ws_next;
     }
     {
         const unsigned char *th = xh + (NTAPS - 1) * ROW6, *tq = xq + (NTAPS - 1) * ROW6, *ts = xs + (NTAPS - 1) * ROW6;
-        k32_step<SWAP, 0, 1, true, true>(ring.w0, w3, xf, xc, sx, th, tq, ts, wr, woff + (NK - 1) * WSTEP_B, l16, ws, acc);
-        k32_step<SWAP, 1, 2, false, true>(ring.w1, ring.w0, xf, xc, sx, th, tq, ts, wr, woff, l16, ws, acc);
-        k32_step<SWAP, 2, 3, false, true>(ring.w2, ring.w1, xf, xc, sx, th, tq, ts, wr, woff, l16, ws, acc);
-        k32_step<SWAP, 3, 0, false, false>(w3, ring.w2, xf, xc, sx, th, tq, ts, wr, woff, l16, ws, acc);
+        const int sw8 = swz((lane & 31) + (NTAPS - 1) + ROW0) * 8;
+        const unsigned char *te = tq + (X6B - X6A) + sw8, *to = tq + (X6B - X6A) - sw8;
+        k32_step<SWAP, 0, 1, true, true>(ring.w0, w3, xf, xc, sx, th, tq, te, ts, wr, woff + (NK - 1) * WSTEP_B, l16, ws, acc);
+        k32_step<SWAP, 1, 2, false, true>(ring.w1, ring.w0, xf, xc, sx, th, tq, to, ts, wr, woff, l16, ws, acc);
+        k32_step<SWAP, 2, 3, false, true>(ring.w2, ring.w1, xf, xc, sx, th, tq, te, ts, wr, woff, l16, ws, acc);
+        k32_step<SWAP, 3, 0, false, false>(w3, ring.w2, xf, xc, sx, th, tq, to, ts, wr, woff, l16, ws, acc);
     }
 }
 
@@ -271,7 +309,9 @@ __device__ __forceinline__ uint32_t f16_exp(float amax) {
 // xl6 = e2m3 of the f16 rounding residual, block scaled the same way (converted from f16((x - h) * 2^11), exact
 // up to f16's 11 bits; the 2^11 goes into the scale byte).  The scale bytes are what the MFMA multiplies the
 // fragments with (2^(byte - 127)).
-__device__ __forceinline__ void store_block32(unsigned char* __restrict__ row, int blk, const float (&x)[32]) {
+__device__ __forceinline__ void store_block32(unsigned char* __restrict__ buf, int buf_row, int blk, const float (&x)[32]) {
+    unsigned char* row = buf + buf_row * ROW6;
+    const int b8 = (blk ^ swz(buf_row)) * 8;
     f16x32 hv, rv;
     float ax = 0.f, ar = 0.f;
 #pragma unroll
@@ -296,9 +336,9 @@ __device__ __forceinline__ void store_block32(unsigned char* __restrict__ row, i
 #pragma unroll
     for (int i = 0; i < 4; ++i) hp[i] = hs[i];
     *reinterpret_cast<uint4*>(row + X6A + blk * 16) = make_uint4((uint32_t)x6[0], (uint32_t)x6[1], (uint32_t)x6[2], (uint32_t)x6[3]);
-    *reinterpret_cast<uint2*>(row + X6B + blk * 8) = make_uint2((uint32_t)x6[4], (uint32_t)x6[5]);
+    *reinterpret_cast<uint2*>(row + X6B + b8) = make_uint2((uint32_t)x6[4], (uint32_t)x6[5]);
     *reinterpret_cast<uint4*>(row + L6A + blk * 16) = make_uint4((uint32_t)l6[0], (uint32_t)l6[1], (uint32_t)l6[2], (uint32_t)l6[3]);
-    *reinterpret_cast<uint2*>(row + L6B + blk * 8) = make_uint2((uint32_t)l6[4], (uint32_t)l6[5]);
+    *reinterpret_cast<uint2*>(row + L6B + b8) = make_uint2((uint32_t)l6[4], (uint32_t)l6[5]);
     row[SXO + blk] = (unsigned char)bx;
     row[SLO + blk] = (unsigned char)(br - XL_SHIFT);
 }
@@ -331,20 +371,20 @@ __device__ __forceinline__ void conv_epilogue(unsigned char* __restrict__ obuf, 
             v[8 * (r >> 2) + (r & 3)] = lrelu_f(__uint_as_float(sw[0]));
             v[8 * (r >> 2) + 4 + (r & 3)] = lrelu_f(__uint_as_float(sw[1]));
         }
-        if (pair || lane < 32) store_block32(obuf + (CARRY + (p + (lane >> 5)) * 32 + (lane & 31)) * ROW6, wave, v);
+        if (pair || lane < 32) store_block32(obuf, CARRY + (p + (lane >> 5)) * 32 + (lane & 31), wave, v);
     }
 }
 
 __device__ __forceinline__ void wv_mfma(const unsigned char* __restrict__ xbuf, wrsrc_t wr, int woff,
-                                        const uint32_t* __restrict__ sbase, WRing& ring, f32x16 (&acc)[NMB], int lane) {
+                                        int hw, WRing& ring, f32x16 (&acc)[NMB], int lane) {
 #pragma unroll
     for (int mb = 0; mb < NMB; ++mb)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[mb][r] = 0.f;
-    gemm_tile<false, 1>(xbuf + CARRY * ROW6, wr, woff, sbase, ring, acc, lane);
+    gemm_tile<false, 1, CARRY>(xbuf + CARRY * ROW6, wr, woff, hw, ring, acc, lane);
 }
 // MaxPool1D(8) -> yp rows (igloo.py:209-210), as in gnn_fused_c8.hip
-__device__ __forceinline__ void wv_pool_store(const f32x16 (&acc)[NMB], float* __restrict__ yp_w, int t0, int wave, int lane) {
+__device__ __forceinline__ void wv_pool_store(const f32x16 (&acc)[NMB], wrsrc_t yp_w, int t0, int wave, int lane) {
     float m[4 * NMB];
 #pragma unroll
     for (int i = 0; i < 4 * NMB; ++i) {
@@ -357,37 +397,79 @@ __device__ __forceinline__ void wv_pool_store(const f32x16 (&acc)[NMB], float* _
     const int q0 = t0 / GNN_POOL;
     const int nq = min(4 * NMB, POOLED - q0);
     if (lane < 32) {
-        float* dst = yp_w + (size_t)q0 * C + wave * 32 + lane;
+        const uint32_t voff = (uint32_t)(wave * 32 + lane) * 4u;      // buffer stores: no 64-bit per-lane address lives across the tiles
 #pragma unroll
         for (int i = 0; i < 4 * NMB; ++i)
-            if (i < nq) dst[(size_t)i * C] = m[i];
+            if (i < nq) __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(m[i]), yp_w, voff, (q0 + i) * (C * 4), 0);
     }
+}
+
+// Pair row of the adjacent positions (t, t + 1) from the aligned 8 bytes that hold bases[t .. t+4] (sequence.py:170-193 in
+// closed form, gnn_fused_common.h).  The bytes of the step after next are requested one step early (prow_fetch) and
+// turned into the pair row at the top of the next step (prow_make): no memory round trip sits in front of the step.
+__device__ __forceinline__ int prow_base(int t) { return min(max(t, 0) & ~3, W - 8); }
+__device__ __forceinline__ void prow_fetch(const uint8_t* __restrict__ bases, int t, uint32_t& lo, uint32_t& hi) {
+    const uint32_t* src = reinterpret_cast<const uint32_t*>(bases + prow_base(t));   // windows start 4-byte aligned (checked at launch)
+    lo = src[0];
+    hi = src[1];
+}
+__device__ __forceinline__ int token_from(uint32_t lo, uint32_t hi, int a, int q) {
+    if (q < 0) return -1;
+    if (q >= T) return 0;
+    const uint32_t w4 = (uint32_t)((((unsigned long long)hi << 32) | lo) >> (8 * (q - a)));
+    const int c0 = base_code_f(w4 & 255u), c1 = base_code_f((w4 >> 8) & 255u), c2 = base_code_f((w4 >> 16) & 255u),
+              c3 = base_code_f(w4 >> 24);
+    return (c0 | c1 | c2 | c3) < 0 ? 0 : 1 + c0 * 64 + c1 * 16 + c2 * 4 + c3;
+}
+__device__ __forceinline__ uint16_t prow_make(uint32_t lo, uint32_t hi, int t) {
+    const int a = prow_base(t);
+    return (uint16_t)pair_row(token_from(lo, hi, a, t), token_from(lo, hi, a, t + 1));
 }
 
 // conv1 + LeakyReLU of one (row, block) unit: conv1 on a one-hot input is a row gather-sum of its kernel (model.py:11 +
 // igloo.py:45-48), 3 rows with the pair tables (gnn_fused_common.h).  The tables of this kernel are stored so that a
 // lane's 32 channels come as 8 loads of 16 B of which the 4 lanes of a row read 64 contiguous bytes each time.
+// The tables of this kernel (pack_fused_c6_weights) keep a row as [i 0..3][block 4][half 2][4 ch]: channel 32 p + 16 q + 4 i + k
+// at float i * 32 + (2 p + q) * 4 + k.  A lane PAIR (q = 0, 1) owns block p of two neighbouring rows; each lane fetches ITS
+// 16 channels of BOTH rows (4 loads per table row: the 8 lanes of a row cover one whole 128-B line per load, a wave 8 lines —
+// with 4 lanes per row it was 16 half lines, and the vector memory path is paid per line touched), sums the three table rows,
+// and the two lanes then swap halves (16 DPP moves) so that each holds all 32 channels of ONE row for the conversion.
 struct GatherUnit {
-    f32x4 v[3][8];
+    f32x4 v[2][3][4];      // [row A / B][table][i]
 };
-__device__ __forceinline__ void gather_issue(GatherUnit& g, const uint16_t* __restrict__ prow, const float* __restrict__ pt, int u, int p) {
-#pragma unroll
-    for (int j = 0; j < 3; ++j) {
-        const uint32_t r = prow[u + 2 * j];
-        const float* src = pt + ((size_t)j * PAIR_ROWS + r) * C + p * 4;
-#pragma unroll
-        for (int i = 0; i < 8; ++i) g.v[j][i] = *reinterpret_cast<const f32x4*>(src + i * 16);
-    }
+__device__ __forceinline__ float dpp_xor1(float v) {     // value of lane ^ 1 (quad_perm [1,0,3,2])
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, false));
 }
-__device__ __forceinline__ void gather_finish(const GatherUnit& g, unsigned char* __restrict__ xbuf, int u, int p) {
+__device__ __forceinline__ float dpp_xor2(float v) {     // value of lane ^ 2 (quad_perm [2,3,0,1])
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, false));
+}
+// ua = first row of the lane pair (even), pq = 2 p + q
+__device__ __forceinline__ void gather_issue(GatherUnit& g, const uint16_t* __restrict__ prow, const float* __restrict__ pt, int ua, int pq) {
+#pragma unroll
+    for (int r = 0; r < 2; ++r)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            const uint32_t row = prow[ua + r + 2 * j];
+            const float* src = pt + ((size_t)j * PAIR_ROWS + row) * C + pq * 4;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) g.v[r][j][i] = *reinterpret_cast<const f32x4*>(src + i * 32);
+        }
+}
+__device__ __forceinline__ void gather_finish(const GatherUnit& g, unsigned char* __restrict__ xbuf, int ua, int pq) {
+    const bool odd = pq & 1;
     float x[32];
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
-        const f32x4 s = g.v[0][i] + g.v[1][i] + g.v[2][i];
+    for (int i = 0; i < 4; ++i) {
+        const f32x4 sa = g.v[0][0][i] + g.v[0][1][i] + g.v[0][2][i];     // row A, channels 16 q + 4 i ..
+        const f32x4 sb = g.v[1][0][i] + g.v[1][1][i] + g.v[1][2][i];     // row B
 #pragma unroll
-        for (int e = 0; e < 4; ++e) x[4 * i + e] = lrelu_f(s[e]);
+        for (int k = 0; k < 4; ++k) {
+            const float got = dpp_xor1(odd ? sa[k] : sb[k]);             // even lane keeps row A and gets the partner's row A half
+            x[4 * i + k] = lrelu_f(odd ? got : sa[k]);                   // channels 0..15 of the block
+            x[16 + 4 * i + k] = lrelu_f(odd ? sb[k] : got);              // channels 16..31
+        }
     }
-    store_block32(xbuf + (CARRY + u) * ROW6, p, x);
+    store_block32(xbuf, CARRY + ua + (odd ? 1 : 0), pq >> 1, x);
 }
 
 // IGLOO pair dot products (igloo.py:192-204 with w_mult * w_summer folded) of head B for the previous step's x3 rows
@@ -400,68 +482,91 @@ struct PairJob {
     float* mp;
     int t0, e, e_end;
 };
+// folded weights of one (entry, block) unit: 32 f32.  Layout of this kernel's copy (pack_fused_c6_weights): entries in pairs,
+// [e >> 1][i 0..7][e & 1][block 4][4 ch] -> the 8 lanes of two neighbouring entries read one 128-B line per load
+struct PairW {
+    float4 w[8];
+};
+__device__ __forceinline__ void pair_load_w(PairW& o, const PairJob& jb, int e, int p) {
+    const float* wr = jb.weff + (size_t)(e >> 1) * (2 * C) + (e & 1) * 16 + p * 4;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) o.w[i] = *reinterpret_cast<const float4*>(wr + i * 32);
+}
+// dot product of the unit's 32 weights with row u of the job's buffer (f16 + residual image), summed over the entry's 4 lanes
+__device__ __forceinline__ void pair_compute(const PairW& w, const PairJob& jb, int e, int u, int p) {
+    const int br = CARRY + u - jb.t0;
+    const unsigned char* xr = jb.xbuf + br * ROW6;
+    uint4 hx[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) hx[i] = *reinterpret_cast<const uint4*>(xr + p * 64 + i * 16);
+    const uint4 la = *reinterpret_cast<const uint4*>(xr + L6A + p * 16);
+    const uint2 lb = *reinterpret_cast<const uint2*>(xr + L6B + (p ^ swz(br)) * 8);
+    const uint32_t sb = xr[SLO + p];
+    const i32x6 l6 = {(int)la.x, (int)la.y, (int)la.z, (int)la.w, (int)lb.x, (int)lb.y};
+    const f32x32 q = __builtin_amdgcn_cvt_scalef32_pk32_f32_fp6(l6, 1.0f);
+    float s = 0.f, r = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const f16x8 hh = __builtin_bit_cast(f16x8, hx[i]);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const int c = i * 8 + k;
+            const float4 wq = w.w[c >> 2];
+            const float wc = (c & 3) == 0 ? wq.x : ((c & 3) == 1 ? wq.y : ((c & 3) == 2 ? wq.z : wq.w));
+            s = fmaf((float)hh[k], wc, s);
+            r = fmaf(q[c], wc, r);
+        }
+    }
+    s = fmaf(r, __uint_as_float(sb << 23), s);
+    s += dpp_xor1(s);
+    s += dpp_xor2(s);
+    if (p == 0) jb.mp[e] = s;
+}
+// Both heads in one loop, 64 entries of each per pass (4 lanes per entry, 16 entries per wave).  The weights of pass
+// k+1 are requested before pass k is computed (two register sets, the loop is unrolled by two), and the positions one
+// pass further ahead still: the loads of a step, whose round trip is several thousand cycles beside the matrix waves'
+// weight stream, overlap instead of queueing one round trip per pass.
 __device__ __forceinline__ void m_partials2(PairJob jb, PairJob ja, int wave, int lane) {
     const int p = lane & 3;
     PairJob job[2] = {jb, ja};
-    int u[2];
+    int e[2], u[2], un[2] = {0, 0};
+    PairW wa[2], wb[2];
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
-        job[h].e += wave * 16 + (lane >> 2);
-        u[h] = job[h].e < job[h].e_end ? job[h].pos[job[h].e] : job[h].t0;
+        e[h] = job[h].e + wave * 16 + (lane >> 2);
+        u[h] = job[h].t0;
+        if (e[h] < job[h].e_end) {
+            u[h] = job[h].pos[e[h]];
+            pair_load_w(wa[h], job[h], e[h], p);
+        }
     }
     // the 4 lanes of an entry share e: a lane group enters / leaves together and the width-4 shuffles only read active lanes
-    while (job[0].e < job[0].e_end || job[1].e < job[1].e_end) {
-        float4 w[2][8];
-        uint4 hx[2][4], la[2];
-        uint2 lb[2];
-        uint32_t sb[2];
-        int un[2];
+    while (e[0] < job[0].e_end || e[1] < job[1].e_end) {
 #pragma unroll
-        for (int h = 0; h < 2; ++h) {
-            const int ei = max(min(job[h].e, job[h].e_end - 1), 0);   // clamped duplicates are computed, not stored
-            const float* wr = job[h].weff + (size_t)ei * C + p * 32;
-#pragma unroll
-            for (int i = 0; i < 8; ++i) w[h][i] = *reinterpret_cast<const float4*>(wr + i * 4);
-        }
-#pragma unroll
-        for (int h = 0; h < 2; ++h) {
-            const unsigned char* xr = job[h].xbuf + (CARRY + u[h] - job[h].t0) * ROW6;
-#pragma unroll
-            for (int i = 0; i < 4; ++i) hx[h][i] = *reinterpret_cast<const uint4*>(xr + p * 64 + i * 16);
-            la[h] = *reinterpret_cast<const uint4*>(xr + L6A + p * 16);
-            lb[h] = *reinterpret_cast<const uint2*>(xr + L6B + p * 8);
-            sb[h] = xr[SLO + p];
-        }
-#pragma unroll
-        for (int h = 0; h < 2; ++h) {
-            const int en = job[h].e + 64;
-            un[h] = en < job[h].e_end ? job[h].pos[en] : job[h].t0;
-        }
-#pragma unroll
-        for (int h = 0; h < 2; ++h) {
-            const i32x6 l6 = {(int)la[h].x, (int)la[h].y, (int)la[h].z, (int)la[h].w, (int)lb[h].x, (int)lb[h].y};
-            const f32x32 q = __builtin_amdgcn_cvt_scalef32_pk32_f32_fp6(l6, 1.0f);
-            float s = 0.f, r = 0.f;
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const f16x8 hh = __builtin_bit_cast(f16x8, hx[h][i]);
-#pragma unroll
-                for (int k = 0; k < 8; ++k) {
-                    const int c = i * 8 + k;
-                    const float4 wq = w[h][c >> 2];
-                    const float wc = (c & 3) == 0 ? wq.x : ((c & 3) == 1 ? wq.y : ((c & 3) == 2 ? wq.z : wq.w));
-                    s = fmaf((float)hh[k], wc, s);
-                    r = fmaf(q[c], wc, r);
-                }
+        for (int h = 0; h < 2; ++h)
+            if (e[h] + 64 < job[h].e_end) {
+                pair_load_w(wb[h], job[h], e[h] + 64, p);
+                un[h] = job[h].pos[e[h] + 64];
             }
-            s = fmaf(r, __uint_as_float(sb[h] << 23), s);
-            s += __shfl_xor(s, 1, 4);
-            s += __shfl_xor(s, 2, 4);
-            if (p == 0 && job[h].e < job[h].e_end) job[h].mp[job[h].e] = s;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            if (e[h] < job[h].e_end) pair_compute(wa[h], job[h], e[h], u[h], p);
+            e[h] += 64;
             u[h] = un[h];
         }
-        job[0].e += 64;
-        job[1].e += 64;
+        if (!(e[0] < job[0].e_end || e[1] < job[1].e_end)) break;
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+            if (e[h] + 64 < job[h].e_end) {
+                pair_load_w(wa[h], job[h], e[h] + 64, p);
+                un[h] = job[h].pos[e[h] + 64];
+            }
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            if (e[h] < job[h].e_end) pair_compute(wb[h], job[h], e[h], u[h], p);
+            e[h] += 64;
+            u[h] = un[h];
+        }
     }
 }
 
@@ -470,11 +575,13 @@ __device__ __forceinline__ void m_partials2(PairJob jb, PairJob ja, int wave, in
 //            epilogue -> bufY (x3) | B4 | w_v B(s) [bufY]   -> straight into step s+1
 //   helpers: pair rows of step s+1, pair products B(s-1) [bufY] and A(s) [bufX] | B1 | x1 carry rows, gather(s+1) loads
 //            of the first unit | B2 | gather(s+1) -> bufX, read x2 carry | B3 | x2 carry rows -> bufY | B4
+template <bool PROF>
 __global__ __launch_bounds__(512, 2) void fused_front_c6_kernel(Args a) {
     __shared__ __attribute__((aligned(16))) unsigned char smem[SMEM6];
     unsigned char* bufX = smem;
     unsigned char* bufY = smem + BUF6_BYTES;
     uint16_t* prow = reinterpret_cast<uint16_t*>(smem + PROW_OFF);
+    float* bias_s = reinterpret_cast<float*>(smem + BIAS_OFF);   // read at the head of every conv tile: LDS, not an L2 round trip
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -484,50 +591,65 @@ __global__ __launch_bounds__(512, 2) void fused_front_c6_kernel(Args a) {
     const int64_t wi = blockIdx.x;
     const uint8_t* bases = a.bases + wi * W;
     float* mp_w[2] = {a.mp + (wi * 2 + 0) * NPAIR, a.mp + (wi * 2 + 1) * NPAIR};
-    float* yp_w[2] = {a.yp + (wi * 2 + 0) * (size_t)POOLED * C, a.yp + (wi * 2 + 1) * (size_t)POOLED * C};
     const int woff = hw * WNBLK_B;                       // this wave's n-block inside every k32 step
-    const uint32_t* cs[2] = {a.conv_s[0] + hw * 64, a.conv_s[1] + hw * 64};
-    const uint32_t* vs[2] = {a.wv_s[0] + hw * 64, a.wv_s[1] + hw * 64};
 
     // carry rows of the first step = the causal zero padding (zero fragments, scale bytes irrelevant but finite)
     for (int i = tid; i < CARRY * ROW_U4; i += 512) {
         reinterpret_cast<uint4*>(bufX)[i] = make_uint4(0, 0, 0, 0);
         reinterpret_cast<uint4*>(bufY)[i] = make_uint4(0, 0, 0, 0);
     }
+    if (tid >= 256) bias_s[tid - 256] = a.conv_b[(tid - 256) >> 7][tid & 127];
     // pair rows of step 0: prow[i] = pair row of positions (t0 - 5 + i, t0 - 4 + i)
-    if (tid < PROW_N) prow[tid] = (uint16_t)pair_row(token_state(bases, tid - CARRY), token_state(bases, tid - CARRY + 1));
+    if (tid < PROW_N) {
+        uint32_t lo, hi;
+        prow_fetch(bases, tid - CARRY, lo, hi);
+        prow[tid] = prow_make(lo, hi, tid - CARRY);
+    }
     __syncthreads();
-    const int gp = ht & 3, gu = ht >> 2;                 // conv1 gather unit of this helper thread: block, row (+ 64 per round)
+    unsigned long long cyc[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long tick_ = 0;
+    const int gpq = ht & 7, gua = (ht >> 3) * 2;         // conv1 gather: 2 * block + channel half, first row of the lane pair (+ 64 per round)
     constexpr int GROUNDS = (FT6 + 63) / 64;
 
     if (!helper) {
         __builtin_amdgcn_s_setprio(2);
-        const wrsrc_t cw[2] = {make_wrsrc(a.conv_w[0], KS * 4 * WSTEP_B), make_wrsrc(a.conv_w[1], KS * 4 * WSTEP_B)};
-        const wrsrc_t vw[2] = {make_wrsrc(a.wv_w[0], 4 * WSTEP_B), make_wrsrc(a.wv_w[1], 4 * WSTEP_B)};
+        const wrsrc_t cw[2] = {make_wrsrc(a.conv_w[0], KS * 4 * WSTEP_B + KS * 1024), make_wrsrc(a.conv_w[1], KS * 4 * WSTEP_B + KS * 1024)};
+        const wrsrc_t vw[2] = {make_wrsrc(a.wv_w[0], 4 * WSTEP_B + 1024), make_wrsrc(a.wv_w[1], 4 * WSTEP_B + 1024)};
+        const wrsrc_t yp_w[2] = {make_wrsrc(reinterpret_cast<const unsigned char*>(a.yp + (wi * 2 + 0) * (size_t)POOLED * C), POOLED * C * 4),
+                                 make_wrsrc(reinterpret_cast<const unsigned char*>(a.yp + (wi * 2 + 1) * (size_t)POOLED * C), POOLED * C * 4)};
         WRing ring;
-        prefetch_w(ring, vw[0], woff, vs[0], lane);
+        prefetch_w<1>(ring, vw[0], woff, hw, lane);
         __syncthreads();                                                         // x1 of step 0 is in bufX
+        if constexpr (PROF) tick_ = __builtin_readcyclecounter();
 #pragma unroll 1
         for (int step = 0; step < STEPS6; ++step) {
             const int t0 = step * FT6;
+            GNN_TICK(7)
             f32x16 acc[NMB];
-            wv_mfma(bufX, vw[0], woff, vs[0], ring, acc, lane);
-            prefetch_w(ring, cw[0], woff, cs[0], lane);                                // conv2 weights, hidden by the pooling
+            wv_mfma(bufX, vw[0], woff, hw, ring, acc, lane);
+            prefetch_w<KS>(ring, cw[0], woff, hw, lane);                                // conv2 weights, hidden by the pooling
             wv_pool_store(acc, yp_w[0], t0, hw, lane);
-            acc_init_bias(acc, a.conv_b[0], hw, lane);
-            gemm_tile<true, KS>(bufX, cw[0], woff, cs[0], ring, acc, lane);
-            prefetch_w(ring, cw[1], woff, cs[1], lane);                                // conv3 weights, hidden by epilogue + barriers
+            GNN_TICK(0)
+            acc_init_bias(acc, bias_s, hw, lane);
+            gemm_tile<true, KS, 0>(bufX, cw[0], woff, hw, ring, acc, lane);
+            prefetch_w<KS>(ring, cw[1], woff, hw, lane);                                // conv3 weights, hidden by epilogue + barriers
+            GNN_TICK(1)
             __syncthreads();                                                     // ---- B1
+            GNN_TICK(2)
             conv_epilogue(bufY, acc, hw, lane);
             __syncthreads();                                                     // ---- B2
-            acc_init_bias(acc, a.conv_b[1], hw, lane);
-            gemm_tile<true, KS>(bufY, cw[1], woff, cs[1], ring, acc, lane);
-            prefetch_w(ring, vw[1], woff, vs[1], lane);                                // w_v of head B
+            GNN_TICK(3)
+            acc_init_bias(acc, bias_s + C, hw, lane);
+            gemm_tile<true, KS, 0>(bufY, cw[1], woff, hw, ring, acc, lane);
+            prefetch_w<1>(ring, vw[1], woff, hw, lane);                                // w_v of head B
+            GNN_TICK(4)
             __syncthreads();                                                     // ---- B3
+            GNN_TICK(5)
             conv_epilogue(bufY, acc, hw, lane);
             __syncthreads();                                                     // ---- B4
-            wv_mfma(bufY, vw[1], woff, vs[1], ring, acc, lane);
-            prefetch_w(ring, vw[0], woff, vs[0], lane);                                // w_v of head A for the next step
+            GNN_TICK(6)
+            wv_mfma(bufY, vw[1], woff, hw, ring, acc, lane);
+            prefetch_w<1>(ring, vw[0], woff, hw, lane);                                // w_v of head A for the next step
             wv_pool_store(acc, yp_w[1], t0, hw, lane);
         }
     } else {
@@ -535,51 +657,81 @@ __global__ __launch_bounds__(512, 2) void fused_front_c6_kernel(Args a) {
             GatherUnit g;
 #pragma unroll
             for (int k = 0; k < GROUNDS; ++k)
-                if (gu + 64 * k < FT6) {
-                    gather_issue(g, prow, a.conv1_k, gu + 64 * k, gp);
-                    gather_finish(g, bufX, gu + 64 * k, gp);
+                if (gua + 64 * k < FT6) {
+                    gather_issue(g, prow, a.conv1_k, gua + 64 * k, gpq);
+                    gather_finish(g, bufX, gua + 64 * k, gpq);
                 }
         }
+        uint32_t nlo = 0, nhi = 0;                       // bytes of this thread's pair row of the NEXT step
+        if (ht < PROW_N) prow_fetch(bases, FT6 - CARRY + ht, nlo, nhi);
         __syncthreads();
+        if constexpr (PROF) tick_ = __builtin_readcyclecounter();
 #pragma unroll 1
         for (int step = 0; step < STEPS6; ++step) {
             const int t0 = step * FT6;
-            // pair rows of the next step (its gather runs behind B1; the previous gather finished before B4)
+            // pair rows of the next step (its gather runs behind B1; the previous gather finished before B4), from the
+            // bytes requested a step ago; then the request for the step after
             if (ht < PROW_N) {
                 const int t = t0 + FT6 - CARRY + ht;
-                prow[ht] = (uint16_t)pair_row(token_state(bases, t), token_state(bases, t + 1));
+                prow[ht] = prow_make(nlo, nhi, t);
+                prow_fetch(bases, t + FT6, nlo, nhi);
             }
+            GNN_TICK(10)
             {
                 const int sb = max(step - 1, 0);                                 // step 0: empty head-B range
                 const PairJob jb = {bufY, a.weff[1], a.pos_sorted[1], mp_w[1], t0 - FT6,
                                     step > 0 ? a.bucket_ptr[1][sb] : 0, step > 0 ? a.bucket_ptr[1][sb + 1] : 0};
                 const PairJob ja = {bufX, a.weff[0], a.pos_sorted[0], mp_w[0], t0, a.bucket_ptr[0][step], a.bucket_ptr[0][step + 1]};
+#ifndef GNN_ABL_NOHELP
                 m_partials2(jb, ja, hw, lane);
+#endif
             }
             uint4 carry = make_uint4(0, 0, 0, 0);
             const int cr = ht / ROW_U4, cc = ht - cr * ROW_U4;   // 5 rows x 29 chunks of 16 B
             if (ht < CARRY * ROW_U4) carry = *reinterpret_cast<const uint4*>(bufX + (FT6 + cr) * ROW6 + cc * 16);
+            GNN_TICK(8)
             __syncthreads();                                                     // ---- B1
+            GNN_TICK(11)
             if (ht < CARRY * ROW_U4) *reinterpret_cast<uint4*>(bufX + cr * ROW6 + cc * 16) = carry;
+#ifndef GNN_ABL_NOHELP
             GatherUnit g;
-            gather_issue(g, prow, a.conv1_k, gu, gp);                            // in flight across the short B1..B2 span
+            gather_issue(g, prow, a.conv1_k, gua, gpq);                          // in flight across the short B1..B2 span
+#endif
+            GNN_TICK(12)
             __syncthreads();                                                     // ---- B2
-            gather_finish(g, bufX, gu, gp);
+            GNN_TICK(13)
+#ifndef GNN_ABL_NOHELP
+            if constexpr (PROF) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            GNN_TICK(9)                                                          // PROF: rest of the first round's round trip
+            gather_finish(g, bufX, gua, gpq);
+            GNN_TICK(14)                                                         // PROF: sum + conversion + LDS stores of one round
 #pragma unroll
             for (int k = 1; k < GROUNDS; ++k)
-                if (gu + 64 * k < FT6) {
-                    gather_issue(g, prow, a.conv1_k, gu + 64 * k, gp);
-                    gather_finish(g, bufX, gu + 64 * k, gp);
+                if (gua + 64 * k < FT6) {
+                    gather_issue(g, prow, a.conv1_k, gua + 64 * k, gpq);
+                    if constexpr (PROF) {
+                        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                        if (k == 1) { GNN_TICK(15) }                             // PROF: issue + round trip of the second round
+                    }
+                    gather_finish(g, bufX, gua + 64 * k, gpq);
                 }
+#endif
             if (ht < CARRY * ROW_U4) carry = *reinterpret_cast<const uint4*>(bufY + (FT6 + cr) * ROW6 + cc * 16);
             __syncthreads();                                                     // ---- B3
             if (ht < CARRY * ROW_U4) *reinterpret_cast<uint4*>(bufY + cr * ROW6 + cc * 16) = carry;
             __syncthreads();                                                     // ---- B4
+            if constexpr (PROF) tick_ = __builtin_readcyclecounter();
         }
         const PairJob jb = {bufY, a.weff[1], a.pos_sorted[1], mp_w[1], (STEPS6 - 1) * FT6, a.bucket_ptr[1][STEPS6 - 1],
                             a.bucket_ptr[1][STEPS6]};
         const PairJob none = {bufX, a.weff[0], a.pos_sorted[0], mp_w[0], 0, 0, 0};
         m_partials2(jb, none, hw, lane);
+    }
+    if constexpr (PROF) {
+        if (tid == 0)
+            for (int i = 0; i < 8; ++i) atomicAdd(a.cycles + i, cyc[i]);
+        if (tid == 256)
+            for (int i = 8; i < 16; ++i) atomicAdd(a.cycles + i, cyc[i]);
     }
 }
 
@@ -667,17 +819,29 @@ int pack_fused_c6_weights(gnn_ctx* ctx, const gnn_weights* w) {
     std::vector<uint32_t> f, s;
     int rc;
     for (int i = 0; i < 2; ++i) {
-        pack_c6(ck[i], KS * C, C, f, s);
+        pack_c6(ck[i], KS * C, C, f, s);          // one allocation: fragments, then the scale words (one buffer resource in the kernel)
+        f.insert(f.end(), s.begin(), s.end());
         if ((rc = upload_vec(ctx, f, &d.conv_c6[i]))) return rc;
-        if ((rc = upload_vec(ctx, s, &d.conv_c6s[i]))) return rc;
         pack_c6(ig[i]->w_v, C, C, f, s);
+        f.insert(f.end(), s.begin(), s.end());
         if ((rc = upload_vec(ctx, f, &d.wv_c6[i]))) return rc;
-        if ((rc = upload_vec(ctx, s, &d.wv_c6s[i]))) return rc;
         // entry ranges of the position-sorted IGLOO pairs per step of FT6 rows
         std::vector<int32_t> ptr(STEPS6 + 1, 0);
         for (int e = 0; e < NPAIR; ++e) ptr[ig[i]->patches[e] / FT6 + 1] += 1;
         for (int st = 0; st < STEPS6; ++st) ptr[st + 1] += ptr[st];
         if ((rc = upload_vec(ctx, ptr, &d.bucket_ptr6[i]))) return rc;
+        // folded IGLOO weights in entry (position-sorted) order, re-laid for 4 lanes per entry: see PairW
+        std::vector<int32_t> order(NPAIR);
+        for (int e = 0; e < NPAIR; ++e) order[e] = e;
+        std::stable_sort(order.begin(), order.end(), [&](int32_t x, int32_t y) { return ig[i]->patches[x] < ig[i]->patches[y]; });
+        std::vector<float> w6((size_t)(NPAIR + 1) / 2 * 2 * C, 0.f);
+        for (int e = 0; e < NPAIR; ++e) {
+            const int pair = order[e], j = pair % PS;
+            float* dst = &w6[(size_t)(e >> 1) * 2 * C + (e & 1) * 16];
+            for (int c = 0; c < C; ++c)     // channel 32 p + 4 i + k  ->  i * 32 + p * 4 + k  (+ 16 for the odd entry)
+                dst[((c >> 2) & 7) * 32 + (c >> 5) * 4 + (c & 3)] = ig[i]->w_mult[(size_t)pair * C + c] * ig[i]->w_summer[j * C + c];
+        }
+        if ((rc = upload_vec(ctx, w6, &d.weff6[i]))) return rc;
     }
     // conv1 pair tables in the lane order of this kernel's gather, conv1 bias folded into table 0 (every position adds
     // exactly one row of each table)
@@ -689,13 +853,15 @@ int pack_fused_c6_weights(gnn_ctx* ctx, const gnn_weights* w) {
             const float* src = &pt[((size_t)j * PAIR_ROWS + r) * C];
             float* dst = &pq[((size_t)j * PAIR_ROWS + r) * C];
             for (int c = 0; c < C; ++c) {
-                const int p = c >> 5, i = (c >> 2) & 7, e = c & 3;
-                dst[i * 16 + p * 4 + e] = src[c] + (j == 0 ? w->conv1_bias[c] : 0.f);
+                const int pq = c >> 4, i = (c >> 2) & 3, e = c & 3;      // channel 32 p + 16 q + 4 i + e
+                dst[i * 32 + pq * 4 + e] = src[c] + (j == 0 ? w->conv1_bias[c] : 0.f);
             }
         }
     if ((rc = upload_vec(ctx, pq, &d.conv1_pairs6))) return rc;
     return GNN_OK;
 }
+
+int c6_rows_per_step() { return c6::FT6; }
 
 int launch_front_c6(gnn_ctx* ctx, const uint8_t* bases, int64_t n) {
     using namespace c6;
@@ -705,17 +871,21 @@ int launch_front_c6(gnn_ctx* ctx, const uint8_t* bases, int64_t n) {
     a.conv1_k = d.conv1_pairs6;
     for (int i = 0; i < 2; ++i) {
         a.conv_w[i] = reinterpret_cast<const unsigned char*>(d.conv_c6[i]);
-        a.conv_s[i] = d.conv_c6s[i];
         a.conv_b[i] = d.conv_b[i];
         a.wv_w[i] = reinterpret_cast<const unsigned char*>(d.wv_c6[i]);
-        a.wv_s[i] = d.wv_c6s[i];
-        a.weff[i] = d.weff_sorted[i];
+        a.weff[i] = d.weff6[i];
         a.pos_sorted[i] = d.pos_sorted[i];
         a.bucket_ptr[i] = d.bucket_ptr6[i];
     }
     a.mp = ctx->ws.mp;
     a.yp = ctx->ws.yp;
-    hipLaunchKernelGGL(fused_front_c6_kernel, dim3((unsigned)n), dim3(512), 0, ctx->stream, a);
+    if (reinterpret_cast<uintptr_t>(bases) & 3u) {
+        set_error("f16c6: the window buffer must be 4-byte aligned");
+        return GNN_ERR_ARG;
+    }
+    a.cycles = ctx->phase_cycles;
+    if (ctx->phase_cycles) hipLaunchKernelGGL((fused_front_c6_kernel<true>), dim3((unsigned)n), dim3(512), 0, ctx->stream, a);
+    else hipLaunchKernelGGL((fused_front_c6_kernel<false>), dim3((unsigned)n), dim3(512), 0, ctx->stream, a);
     GNN_HIP(hipGetLastError());
     return GNN_OK;
 }

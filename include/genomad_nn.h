@@ -278,6 +278,10 @@ int gnn_phase_cycles(gnn_ctx* ctx, int on, unsigned long long* out16);
  * this (power-managed) chip, reported by bench.py beside the fused kernel's issued-MFMA rate. */
 int gnn_mfma_probe(gnn_ctx* ctx, int ms_target, double* tflops_out);
 
+/* measurement aid: rows (token positions) a workgroup of the fused front end of `precision` streams per step
+ * (128 for the f16c8 / x3 kernels; 32 * GNN_C6_NMB for f16c6), 0 for GNN_PREC_F32, negative on a bad enum. */
+int gnn_fused_rows_per_step(int precision);
+
 /* windows the ctx processes per launch of the fused front end (workspace sizing) */
 int gnn_set_chunk(gnn_ctx* ctx, int64_t windows_per_chunk);
 

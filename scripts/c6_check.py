@@ -14,6 +14,7 @@ args = [a for a in sys.argv[1:] if not a.startswith("--")]
 n = int(args[0]) if args else 8192
 W = synthetic.synth_weights()
 eng = NNEngine(0, W, chunk=4096)
+print('library', _lib.LIB_PATH, 'f16c6 rows per step', eng.lib.gnn_fused_rows_per_step(_lib.PRECISIONS['f16c6']), flush=True)
 b16 = synthetic.synth_windows(0, 16)
 taps = ("m_a", "m_b", "yp_a", "yp_b", "alpha_a", "alpha_b", "feat")
 s32, t32 = eng.debug_forward(b16, "f32", taps=taps)
@@ -59,3 +60,16 @@ for prec in ('f16c8', 'f16c6', 'f16c8', 'f16c6'):
     bms, bl = eng.profile_get(_lib.K_BACKEND)
     print(f"  {prec}: {n / dt:.0f} windows/s; fused {fms / fl:.3f} ms per {n // (fl // 3)} windows, backend {bms / bl:.3f} ms", flush=True)
     eng.profile_enable(False)
+import ctypes as C
+names = ["wvA", "conv2 loop", "wait B1", "conv2 epi+B2", "conv3 loop", "wait B3", "conv3 epi+B4", "wvB",
+         "h pairs", "h round-0 trip rest", "h prow", "h wait B1", "h carry+issue round 0", "h wait B2", "h finish round 0", "h round-1 issue+trip"]
+names8 = names[:8] + ["helper pairs (B4..B1)", "helper B1..B4"]
+for prec in ('f16c8', 'f16c6'):
+    rows = eng.lib.gnn_fused_rows_per_step(_lib.PRECISIONS[prec])
+    steps = (5997 + rows - 1) // rows
+    _lib.check(eng.lib.gnn_phase_cycles(eng.ctx, 1, None))
+    eng.classify_dev(bases.ptr, n, scores.ptr, prec); eng.sync()
+    out = (C.c_uint64 * 16)()
+    _lib.check(eng.lib.gnn_phase_cycles(eng.ctx, 0, out))
+    print(f"  {prec} phase cycles (s_memtime) per window-step of {rows} rows:", {nm: round(v / n / steps) for nm, v in zip(names if prec == 'f16c6' else names8, out)},
+          "matrix-wave total", round(sum(out[:8]) / n / steps), "per 128 rows", round(sum(out[:8]) / n / steps * 128 / rows), flush=True)

@@ -1,6 +1,6 @@
 #!/bin/bash
 # One rocprofv3 PMC pass per argument (a quoted, space-separated counter set) over a short bench run;
-# per-kernel means land in gpurun_out/pmc_<i>.txt.  Run on the GPU box: scripts/pmc_pass.sh "A B" "C D" ...
+# per-kernel means land in gpurun_out/pmc_<i>.txt.  Run on the GPU box: [BENCH_ARGS='--precision f16c6'] [PMC_TAG=x] scripts/pmc_pass.sh "A B" "C D" ...
 set -u
 ROOT=$(pwd)
 mkdir -p gpurun_out
@@ -10,10 +10,10 @@ for set in "$@"; do
   i=$((i+1))
   rm -rf /tmp/pmc_$i
   timeout 300 rocprofv3 --kernel-trace --pmc $set --output-format csv -d /tmp/pmc_$i -- \
-    python $ROOT/bench.py --steps 1 --warmup 1 --windows-per-step 4096 --cpu-sample 0 > /tmp/pmc_$i.log 2>&1
+    python $ROOT/bench.py --steps 1 --warmup 1 --windows-per-step 4096 --cpu-sample 0 ${BENCH_ARGS:-} > /tmp/pmc_$i.log 2>&1
   f=$(find /tmp/pmc_$i -name '*counter_collection.csv' | head -1)
   g=$(find /tmp/pmc_$i -name '*kernel_trace.csv' | head -1)
-  python - "$f" "$g" > $ROOT/gpurun_out/pmc_$i.txt <<'PY'
+  python - "$f" "$g" > $ROOT/gpurun_out/pmc${PMC_TAG:-}_$i.txt <<'PY'
 import csv, sys, collections
 dur = collections.defaultdict(lambda: [0.0, 0])
 for r in csv.DictReader(open(sys.argv[2])):
@@ -30,5 +30,5 @@ for (k, c), (v, n) in sorted(acc.items()):
     if 'fused' in k or 'logits' in k:
         print(f"{k:40s} {c:40s} mean/dispatch {v / n:.6g}  (n={n})")
 PY
-  cat $ROOT/gpurun_out/pmc_$i.txt
+  cat $ROOT/gpurun_out/pmc${PMC_TAG:-}_$i.txt
 done
