@@ -98,7 +98,7 @@ def main():
                     "or of every rank (weak)")
     ap.add_argument("--scaling", default="strong", choices=["strong", "weak"])
     ap.add_argument("--chunk", type=int, default=4096, help="windows per launch of the fused kernel")
-    ap.add_argument("--precision", default="f16c8", choices=["f16c6", "f16c8", "f16x3", "bf16x3", "bf16", "f32"])
+    ap.add_argument("--precision", default="f16c6", choices=["f16c6", "f16c8", "f16x3", "bf16x3", "bf16", "f32"])
     ap.add_argument("--cpu-sample", type=int, default=1024, help="windows for the CPU baseline (0 = skip)")
     ap.add_argument("--kernel", default="classify", choices=["classify", "encoder"],
                     help="'encoder' benches the stand-alone byte->one-hot HBM kernel instead")

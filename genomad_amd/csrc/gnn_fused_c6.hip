@@ -29,6 +29,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstring>
+#include <utility>
 
 #include "gnn_fused_common.h"
 
@@ -49,10 +50,13 @@ constexpr int PROW_OFF = 2 * BUF6_BYTES;
 constexpr int PROW_N = FT6 + 4;              // pair rows a step's conv1 gather reads
 constexpr int BIAS_OFF = PROW_OFF + ((PROW_N * 2 + 15) / 16) * 16;   // conv2 | conv3 bias, 2 x 128 f32
 constexpr int SMEM6 = BIAS_OFF + 2 * C * 4;
-constexpr int XL_SHIFT = 11;                 // the residual is converted from f16((x - f16 x) * 2^11)
 constexpr int WNBLK_B = 3584;                // weight bytes per (k32 step, n-block): f16 k16 even | f16 k16 odd | fp6 16-B parts | fp6 8-B parts
 constexpr int WSTEP_B = 4 * WNBLK_B;         // per k32 step
 constexpr int ROW_U4 = ROW6 / 16;            // 29
+#ifndef GNN_C6_RING
+#define GNN_C6_RING 4
+#endif
+constexpr int RING = GNN_C6_RING;            // weight ring slots: RING - 1 k32 steps of weights are in flight ahead of the MFMAs
 // 8-B parts: slot (block ^ bit 4 of the buffer row) — with the 464-B stride rows R and R+16 start on the same bank, and a
 // ds_read_b64 serves 32 consecutive rows per LDS cycle; swapping neighbouring slots in every other group of 16 rows makes
 // those reads conflict free.  GNN_C6_NOSWZ: measurement variant.
@@ -133,28 +137,29 @@ __device__ __forceinline__ void load_w_c(WStep& w, wrsrc_t r, uint32_t l16, int 
     w.c1 = make_uint2(b[0], b[1]);
 }
 // xh = lane base of the tap row's f16 plane (row l & 31, + 16 B for lanes 32-63); J = k32 step inside the tap
-template <int J>
+template <int J, int TOFF>   // TOFF = tap * ROW6: every offset is an immediate of the DS instruction
 __device__ __forceinline__ void load_xf(XF& f, const unsigned char* __restrict__ xh) {
 #pragma unroll
     for (int s = 0; s < 2; ++s)
 #pragma unroll
-        for (int mb = 0; mb < NMB; ++mb) f.v[s][mb] = *reinterpret_cast<const uint4*>(xh + mb * 32 * ROW6 + (J * 2 + s) * 32);
+        for (int mb = 0; mb < NMB; ++mb) f.v[s][mb] = *reinterpret_cast<const uint4*>(xh + TOFF + mb * 32 * ROW6 + (J * 2 + s) * 32);
 }
 // xq = lane base of the tap row's fp6 planes (x image for lanes 0-31, residual image for lanes 32-63)
 // x8 = the same + 64 +- 8 * swz(row): its slot J is the row's swizzled slot for even J (+) / odd J (-)
-template <int J>
+template <int J, int TOFF>
 __device__ __forceinline__ void load_xc(XC& f, const unsigned char* __restrict__ xq, const unsigned char* __restrict__ x8) {
 #pragma unroll
     for (int mb = 0; mb < NMB; ++mb) {
-        const uint4 a = *reinterpret_cast<const uint4*>(xq + mb * 32 * ROW6 + J * 16);
+        const uint4 a = *reinterpret_cast<const uint4*>(xq + TOFF + mb * 32 * ROW6 + J * 16);
         const uint2 b = *reinterpret_cast<const uint2*>(x8 + mb * 32 * ROW6 + J * 8);
         f.v[mb] = i32x8{(int)a.x, (int)a.y, (int)a.z, (int)a.w, (int)b.x, (int)b.y, 0, 0};
     }
 }
 // activation scale words of the tap row (4 bytes = the row's 4 blocks; OPSEL picks the k32 step's)
+template <int TOFF>
 __device__ __forceinline__ void load_sx(int (&sx)[NMB], const unsigned char* __restrict__ xs) {
 #pragma unroll
-    for (int mb = 0; mb < NMB; ++mb) sx[mb] = *reinterpret_cast<const int*>(xs + mb * 32 * ROW6);
+    for (int mb = 0; mb < NMB; ++mb) sx[mb] = *reinterpret_cast<const int*>(xs + TOFF + mb * 32 * ROW6);
 }
 
 template <bool SWAP>
@@ -191,16 +196,16 @@ __device__ __forceinline__ void mfma_c6_phase(const WStep& w, const XC& x, int w
 // of the SAME step (2*NMB LDS reads, + the tap's NMB scale words when J == 0) and the f16 weight fragments of step
 // j+3 (2 L2 loads) issued between them.  Region C: the NMB fp6 MFMAs (32 cycles each), with the f16 activation
 // fragments of step j+1 and the fp6 weight fragment of step j+3.
-template <bool SWAP, int J, int JN, bool LW, bool LX>
+template <bool SWAP, int J, int JN, bool LW, bool LX, int TOFF, int TOFFN>
 __device__ __forceinline__ void k32_step(const WStep& wcur, WStep& wload, XF& xf, XC& xc, int (&sx)[NMB],
-                                         const unsigned char* __restrict__ xh_next, const unsigned char* __restrict__ xq,
+                                         const unsigned char* __restrict__ xh, const unsigned char* __restrict__ xq,
                                          const unsigned char* __restrict__ x8, const unsigned char* __restrict__ xs, wrsrc_t wr, int wnext,
                                          uint32_t l16, int ws, f32x16 (&acc)[NMB]) {
     // GNN_ABL_*: measurement-only ablations (scripts/mkvariant.sh) that compile parts of the work out — wrong results
     // by construction, used to see what the launch time is made of (profiles/README.md)
 #ifndef GNN_ABL_NOX
-    load_xc<J>(xc, xq, x8);
-    if constexpr (J == 0) load_sx(sx, xs);
+    load_xc<J, TOFF>(xc, xq, x8);
+    if constexpr (J == 0) load_sx<TOFF>(sx, xs);
 #endif
 #ifndef GNN_ABL_NOW
     if constexpr (LW) load_w_h(wload, wr, l16, wnext);
@@ -217,7 +222,7 @@ __device__ __forceinline__ void k32_step(const WStep& wcur, WStep& wload, XF& xf
     }
     GNN_REGION_END();
 #ifndef GNN_ABL_NOX
-    if constexpr (LX) load_xf<JN>(xf, xh_next);
+    if constexpr (LX) load_xf<JN, TOFFN>(xf, xh);
 #endif
 #ifndef GNN_ABL_NOW
     if constexpr (LW) load_w_c(wload, wr, l16, wnext);
@@ -234,66 +239,71 @@ __device__ __forceinline__ void k32_step(const WStep& wcur, WStep& wload, XF& xf
     GNN_REGION_END();
 }
 
-// First three k32 steps of a tile's weights + its first scale word, loaded BEFORE the epilogue and barrier that
-// precede the tile (as in gnn_fused_c8.hip).
+// The first RING - 1 k32 steps of a tile's weights + its first scale word are loaded BEFORE the epilogue and barrier that
+// precede the tile (prefetch_w), and inside the tile every step requests the weights of the step RING - 1 ahead into the
+// slot the previous step just released.  Measured with 2 ... 6 slots (profiles/README.md): the launch time does not depend
+// on the depth — the weight stream is not latency bound — so the default keeps the four slots of gnn_fused_c8.hip.
 struct WRing {
-    WStep w0, w1, w2;
+    WStep w[RING];
     int ws;
 };
+template <int... Ks, class F>
+__device__ __forceinline__ void static_for(std::integer_sequence<int, Ks...>, F&& f) {
+    (f(std::integral_constant<int, Ks>{}), ...);
+}
 template <int NTAPS>
 __device__ __forceinline__ void prefetch_w(WRing& r, wrsrc_t wr, int woff, int hw, int lane) {
     const uint32_t l16 = (uint32_t)lane * 16u;
-    load_w_h(r.w0, wr, l16, woff);
-    load_w_c(r.w0, wr, l16, woff);
-    load_w_h(r.w1, wr, l16, woff + WSTEP_B);
-    load_w_c(r.w1, wr, l16, woff + WSTEP_B);
-    load_w_h(r.w2, wr, l16, woff + 2 * WSTEP_B);
-    load_w_c(r.w2, wr, l16, woff + 2 * WSTEP_B);
+    constexpr int NP = NTAPS * 4 < RING - 1 ? NTAPS * 4 : RING - 1;
+    static_for(std::make_integer_sequence<int, NP>{}, [&](auto sc) {
+        constexpr int st = decltype(sc)::value;
+        load_w_h(r.w[st], wr, l16, woff + st * WSTEP_B);
+        load_w_c(r.w[st], wr, l16, woff + st * WSTEP_B);
+    });
     r.ws = (int)__builtin_amdgcn_raw_buffer_load_b32(wr, (uint32_t)lane * 4u, NTAPS * 4 * WSTEP_B + hw * 256, 0);   // scale word of tap 0
     asm volatile("" ::: "memory");
 }
 
-// FT6 rows x 32 columns, K = NTAPS * 128, as NTAPS * 4 k32 steps; weight ring of four k32 steps, the first three
-// already in flight (prefetch_w).  SWAP: D = W^T X^T for the convs (a lane ends up with 16 channels of one row),
-// D = X W for y @ w_v (a lane ends up with 16 rows of one channel: the max-pool is register local).
-template <bool SWAP, int NTAPS, int ROW0>   // ROW0 = buffer row of xbuf's first row (the swizzle needs absolute rows)
-__device__ __forceinline__ void gemm_tile(const unsigned char* __restrict__ xbuf, wrsrc_t wr, int woff,
+// FT6 rows x 32 columns, K = NTAPS * 128, as NTAPS * 4 fully unrolled k32 steps (static ring slots, static LDS offsets).
+// SWAP: D = W^T X^T for the convs (a lane ends up with 16 channels of one row), D = X W for y @ w_v (a lane ends up with
+// 16 rows of one channel: the max-pool is register local).
+template <bool SWAP, int NTAPS, int ROW0>   // ROW0 = buffer row of the tile's first row (the swizzle needs absolute rows)
+__device__ __forceinline__ void gemm_tile(const unsigned char* __restrict__ smem, int xoff, wrsrc_t wr, int woff,
                                           int hw, WRing& ring, f32x16 (&acc)[NMB], int lane) {
     constexpr int NK = NTAPS * 4;
-    const unsigned char* xrow = xbuf + (lane & 31) * ROW6;
+    // The lane's row offset is made opaque to the compiler: otherwise it keeps ONE base register for both activation
+    // buffers and spends a v_add per LDS read whose folded offset (buffer + m-block + plane) passes the 16-bit DS offset
+    // field - about 20 VALU issues per k32 step in a loop that is bound by issue slots.
+    uint32_t rowoff = (uint32_t)xoff + (uint32_t)(lane & 31) * ROW6;
+    asm volatile("" : "+v"(rowoff));
+    const unsigned char* xrow = smem + rowoff;
     const unsigned char* xh = xrow + (lane >> 5) * 16;
     const unsigned char* xq = xrow + X6A + (lane >> 5) * (L6A - X6A);
     const unsigned char* xs = xrow + SXO + (lane >> 5) * (SLO - SXO);
     const uint32_t l16 = (uint32_t)lane * 16u, lane_s = (uint32_t)lane * 4u;
-    WStep w3;
     XF xf;
     XC xc;
     int sx[NMB];
-    int ws = ring.ws;
-    load_xf<0>(xf, xh);
+    int ws = ring.ws, ws_next = 0;
+    const unsigned char *te = xq, *to = xq;
+    load_xf<0, 0>(xf, xh);
     GNN_REGION_END();
-#pragma unroll 1
-    for (int t = 0; t < NTAPS - 1; ++t) {
-        const int k = t * 4;
-        const unsigned char *th = xh + t * ROW6, *tq = xq + t * ROW6, *ts = xs + t * ROW6;
-        const int sw8 = swz((lane & 31) + t + ROW0) * 8;
-        const unsigned char *te = tq + (X6B - X6A) + sw8, *to = tq + (X6B - X6A) - sw8;
-        const int ws_next = (int)__builtin_amdgcn_raw_buffer_load_b32(wr, lane_s, NK * WSTEP_B + (t + 1) * 1024 + hw * 256, 0);
-        k32_step<SWAP, 0, 1, true, true>(ring.w0, w3, xf, xc, sx, th, tq, te, ts, wr, woff + (k + 3) * WSTEP_B, l16, ws, acc);
-        k32_step<SWAP, 1, 2, true, true>(ring.w1, ring.w0, xf, xc, sx, th, tq, to, ts, wr, woff + (k + 4) * WSTEP_B, l16, ws, acc);
-        k32_step<SWAP, 2, 3, true, true>(ring.w2, ring.w1, xf, xc, sx, th, tq, te, ts, wr, woff + (k + 5) * WSTEP_B, l16, ws, acc);
-        k32_step<SWAP, 3, 0, true, true>(w3, ring.w2, xf, xc, sx, th + ROW6, tq, to, ts, wr, woff + (k + 6) * WSTEP_B, l16, ws, acc);
-        ws = ws_next;
-    }
-    {
-        const unsigned char *th = xh + (NTAPS - 1) * ROW6, *tq = xq + (NTAPS - 1) * ROW6, *ts = xs + (NTAPS - 1) * ROW6;
-        const int sw8 = swz((lane & 31) + (NTAPS - 1) + ROW0) * 8;
-        const unsigned char *te = tq + (X6B - X6A) + sw8, *to = tq + (X6B - X6A) - sw8;
-        k32_step<SWAP, 0, 1, true, true>(ring.w0, w3, xf, xc, sx, th, tq, te, ts, wr, woff + (NK - 1) * WSTEP_B, l16, ws, acc);
-        k32_step<SWAP, 1, 2, false, true>(ring.w1, ring.w0, xf, xc, sx, th, tq, to, ts, wr, woff, l16, ws, acc);
-        k32_step<SWAP, 2, 3, false, true>(ring.w2, ring.w1, xf, xc, sx, th, tq, te, ts, wr, woff, l16, ws, acc);
-        k32_step<SWAP, 3, 0, false, false>(w3, ring.w2, xf, xc, sx, th, tq, to, ts, wr, woff, l16, ws, acc);
-    }
+    static_for(std::make_integer_sequence<int, NK>{}, [&](auto kc) {
+        constexpr int k = decltype(kc)::value, tap = k / 4, J = k % 4, TOFF = tap * ROW6;
+        constexpr int kn = k + 1, TOFFN = (kn / 4) * ROW6, JN = kn % 4;
+        constexpr bool LW = k + RING - 1 < NK, LX = kn < NK;
+        if constexpr (J == 0) {
+            // 8-B parts of this tap's rows: slot J for even J (te) / odd J (to), see swz()
+            const int sw8 = swz((lane & 31) + tap + ROW0) * 8;
+            te = xq + TOFF + (X6B - X6A) + sw8;
+            to = xq + TOFF + (X6B - X6A) - sw8;
+            if constexpr (tap > 0) ws = ws_next;
+            if constexpr (tap + 1 < NTAPS)
+                ws_next = (int)__builtin_amdgcn_raw_buffer_load_b32(wr, lane_s, NK * WSTEP_B + (tap + 1) * 1024 + hw * 256, 0);
+        }
+        k32_step<SWAP, J, JN, LW, LX, TOFF, TOFFN>(ring.w[k % RING], ring.w[(k + RING - 1) % RING], xf, xc, sx, xh, xq, (J & 1) ? to : te, xs,
+                                                  wr, woff + (k + RING - 1) * WSTEP_B, l16, ws, acc);
+    });
 }
 
 // biased f16 exponent (at least 1: the subnormal range shares the exponent of the smallest normals) of a
@@ -306,31 +316,36 @@ __device__ __forceinline__ uint32_t f16_exp(float amax) {
 
 // One (row, 32-channel block) unit, x[] = the block's activations after LeakyReLU in channel order -> the row's
 // operand images: h = f16(x) (RNE), x6 = e2m3(h / 2^(E-2)) with E = exponent of the block's largest |h|, and
-// xl6 = e2m3 of the f16 rounding residual, block scaled the same way (converted from f16((x - h) * 2^11), exact
-// up to f16's 11 bits; the 2^11 goes into the scale byte).  The scale bytes are what the MFMA multiplies the
-// fragments with (2^(byte - 127)).
+// xl6 = e2m3 of the f16 rounding residual x - h, block scaled by the exponent of its own largest element
+// (v_cvt_scalef32_2xpk16_fp6_f32 takes the f32 residuals directly: output slot 2i = first source [i], slot 2i+1 = second
+// source [i], profiles/r02_probe_cvt6.txt).  The scale bytes are what the MFMA multiplies the fragments with
+// (2^(byte - 127)).  Instruction count matters here: the helper waves issue beside the matrix waves' MFMA stream, at a
+// fraction of the nominal VALU rate (profiles/README.md), so the maxima are three-operand and nothing is converted twice.
 __device__ __forceinline__ void store_block32(unsigned char* __restrict__ buf, int buf_row, int blk, const float (&x)[32]) {
     unsigned char* row = buf + buf_row * ROW6;
     const int b8 = (blk ^ swz(buf_row)) * 8;
-    f16x32 hv, rv;
+    f16x32 hv;
+    f32x16 re, ro;         // residuals of the even / odd channels
     float ax = 0.f, ar = 0.f;
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
         const f16x2 h = __builtin_convertvector(f32x2{x[2 * i], x[2 * i + 1]}, f16x2);
-        const float r0 = (x[2 * i] - (float)h[0]) * (float)(1 << XL_SHIFT), r1 = (x[2 * i + 1] - (float)h[1]) * (float)(1 << XL_SHIFT);
-        const f16x2 r = __builtin_convertvector(f32x2{r0, r1}, f16x2);
+        const float r0 = x[2 * i] - (float)h[0], r1 = x[2 * i + 1] - (float)h[1];
         hv[2 * i] = h[0];
         hv[2 * i + 1] = h[1];
-        rv[2 * i] = r[0];
-        rv[2 * i + 1] = r[1];
-        ax = fmaxf(ax, fmaxf(fabsf(x[2 * i]), fabsf(x[2 * i + 1])));
-        ar = fmaxf(ar, fmaxf(fabsf(r0), fabsf(r1)));
+        re[i] = r0;
+        ro[i] = r1;
+        ax = __builtin_fmaxf(__builtin_fmaxf(ax, __builtin_fabsf(x[2 * i])), __builtin_fabsf(x[2 * i + 1]));
+        ar = __builtin_fmaxf(__builtin_fmaxf(ar, __builtin_fabsf(r0)), __builtin_fabsf(r1));
     }
-    // E8M0 byte b <-> scale 2^(b - 127); e2m3 tops out at 7.5 = 1.875 * 2^2, so the block maximum (exponent e =
-    // E - 15) is divided by 2^(e - 2): b = E - 15 - 2 + 127
-    const uint32_t bx = f16_exp(ax) + 110u, br = f16_exp(ar) + 110u;
+    // E8M0 byte b <-> scale 2^(b - 127); e2m3 tops out at 7.5 = 1.875 * 2^2, so a block whose largest element has the
+    // exponent e is divided by 2^(e - 2).  x6 is converted from h: E = biased f16 exponent of the largest |h|, b = E - 15 - 2
+    // + 127; the residual from f32: b = its biased f32 exponent - 2 (at least 1)
+    const uint32_t bx = f16_exp(ax) + 110u;
+    const uint32_t er = (__float_as_uint(ar) >> 23) & 255u;
+    const uint32_t br = (er > 3u ? er : 3u) - 2u;
     const i32x6 x6 = __builtin_amdgcn_cvt_scalef32_pk32_fp6_f16(hv, __uint_as_float(bx << 23));
-    const i32x6 l6 = __builtin_amdgcn_cvt_scalef32_pk32_fp6_f16(rv, __uint_as_float(br << 23));
+    const i32x6 l6 = __builtin_amdgcn_cvt_scalef32_2xpk16_fp6_f32(re, ro, __uint_as_float(br << 23));
     uint4* hp = reinterpret_cast<uint4*>(row + blk * 64);
     const uint4* hs = reinterpret_cast<const uint4*>(&hv);
 #pragma unroll
@@ -340,7 +355,7 @@ __device__ __forceinline__ void store_block32(unsigned char* __restrict__ buf, i
     *reinterpret_cast<uint4*>(row + L6A + blk * 16) = make_uint4((uint32_t)l6[0], (uint32_t)l6[1], (uint32_t)l6[2], (uint32_t)l6[3]);
     *reinterpret_cast<uint2*>(row + L6B + b8) = make_uint2((uint32_t)l6[4], (uint32_t)l6[5]);
     row[SXO + blk] = (unsigned char)bx;
-    row[SLO + blk] = (unsigned char)(br - XL_SHIFT);
+    row[SLO + blk] = (unsigned char)br;
 }
 
 // bias pre-loaded into the accumulators, D = W^T X^T layout: register r of lane l = channel 8 (r >> 2) + 4 (l >> 5) + (r & 3)
@@ -375,13 +390,13 @@ __device__ __forceinline__ void conv_epilogue(unsigned char* __restrict__ obuf, 
     }
 }
 
-__device__ __forceinline__ void wv_mfma(const unsigned char* __restrict__ xbuf, wrsrc_t wr, int woff,
+__device__ __forceinline__ void wv_mfma(const unsigned char* __restrict__ smem, int xoff, wrsrc_t wr, int woff,
                                         int hw, WRing& ring, f32x16 (&acc)[NMB], int lane) {
 #pragma unroll
     for (int mb = 0; mb < NMB; ++mb)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[mb][r] = 0.f;
-    gemm_tile<false, 1, CARRY>(xbuf + CARRY * ROW6, wr, woff, hw, ring, acc, lane);
+    gemm_tile<false, 1, CARRY>(smem, xoff + CARRY * ROW6, wr, woff, hw, ring, acc, lane);
 }
 // MaxPool1D(8) -> yp rows (igloo.py:209-210), as in gnn_fused_c8.hip
 __device__ __forceinline__ void wv_pool_store(const f32x16 (&acc)[NMB], wrsrc_t yp_w, int t0, int wave, int lane) {
@@ -612,7 +627,9 @@ __global__ __launch_bounds__(512, 2) void fused_front_c6_kernel(Args a) {
     constexpr int GROUNDS = (FT6 + 63) / 64;
 
     if (!helper) {
+#ifndef GNN_C6_NOPRIO
         __builtin_amdgcn_s_setprio(2);
+#endif
         const wrsrc_t cw[2] = {make_wrsrc(a.conv_w[0], KS * 4 * WSTEP_B + KS * 1024), make_wrsrc(a.conv_w[1], KS * 4 * WSTEP_B + KS * 1024)};
         const wrsrc_t vw[2] = {make_wrsrc(a.wv_w[0], 4 * WSTEP_B + 1024), make_wrsrc(a.wv_w[1], 4 * WSTEP_B + 1024)};
         const wrsrc_t yp_w[2] = {make_wrsrc(reinterpret_cast<const unsigned char*>(a.yp + (wi * 2 + 0) * (size_t)POOLED * C), POOLED * C * 4),
@@ -626,12 +643,12 @@ __global__ __launch_bounds__(512, 2) void fused_front_c6_kernel(Args a) {
             const int t0 = step * FT6;
             GNN_TICK(7)
             f32x16 acc[NMB];
-            wv_mfma(bufX, vw[0], woff, hw, ring, acc, lane);
+            wv_mfma(smem, 0, vw[0], woff, hw, ring, acc, lane);
             prefetch_w<KS>(ring, cw[0], woff, hw, lane);                                // conv2 weights, hidden by the pooling
             wv_pool_store(acc, yp_w[0], t0, hw, lane);
             GNN_TICK(0)
             acc_init_bias(acc, bias_s, hw, lane);
-            gemm_tile<true, KS, 0>(bufX, cw[0], woff, hw, ring, acc, lane);
+            gemm_tile<true, KS, 0>(smem, 0, cw[0], woff, hw, ring, acc, lane);
             prefetch_w<KS>(ring, cw[1], woff, hw, lane);                                // conv3 weights, hidden by epilogue + barriers
             GNN_TICK(1)
             __syncthreads();                                                     // ---- B1
@@ -640,7 +657,7 @@ __global__ __launch_bounds__(512, 2) void fused_front_c6_kernel(Args a) {
             __syncthreads();                                                     // ---- B2
             GNN_TICK(3)
             acc_init_bias(acc, bias_s + C, hw, lane);
-            gemm_tile<true, KS, 0>(bufY, cw[1], woff, hw, ring, acc, lane);
+            gemm_tile<true, KS, 0>(smem, BUF6_BYTES, cw[1], woff, hw, ring, acc, lane);
             prefetch_w<1>(ring, vw[1], woff, hw, lane);                                // w_v of head B
             GNN_TICK(4)
             __syncthreads();                                                     // ---- B3
@@ -648,7 +665,7 @@ __global__ __launch_bounds__(512, 2) void fused_front_c6_kernel(Args a) {
             conv_epilogue(bufY, acc, hw, lane);
             __syncthreads();                                                     // ---- B4
             GNN_TICK(6)
-            wv_mfma(bufY, vw[1], woff, hw, ring, acc, lane);
+            wv_mfma(smem, BUF6_BYTES, vw[1], woff, hw, ring, acc, lane);
             prefetch_w<1>(ring, vw[0], woff, hw, lane);                                // w_v of head A for the next step
             wv_pool_store(acc, yp_w[1], t0, hw, lane);
         }

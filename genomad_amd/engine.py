@@ -120,7 +120,7 @@ class NNEngine:
             db.free()
             do.free()
 
-    def classify(self, bases, precision="f16c8") -> np.ndarray:
+    def classify(self, bases, precision="f16c6") -> np.ndarray:
         """(n,6000) uint8 windows -> (n,3) float32 class scores (chromosome, plasmid, virus)."""
         b = self._check_bases(bases)
         out = np.empty((len(b), _lib.CLASSES), dtype=np.float32)
@@ -128,7 +128,7 @@ class NNEngine:
                                     out.ctypes.data))
         return out
 
-    def classify_dev(self, bases_ptr: int, n: int, scores_ptr: int, precision="f16c8"):
+    def classify_dev(self, bases_ptr: int, n: int, scores_ptr: int, precision="f16c6"):
         """Asynchronous: device pointers in and out, enqueued on the engine's stream."""
         check(self.lib.gnn_classify_dev(self.ctx, bases_ptr, int(n), _lib.PRECISIONS[precision],
                                         scores_ptr))
@@ -150,7 +150,7 @@ class NNEngine:
         return scores, arrays
 
     def classify_contigs(self, seq: np.ndarray, offsets: np.ndarray, single_window: bool = False,
-                         precision="f16c8"):
+                         precision="f16c6"):
         """Contig front end: packed raw contig bytes -> per-contig scores.
 
         Does what generate_data + the predict loop + segment_mean do (nn_classification.py:54-82,
@@ -164,7 +164,7 @@ class NNEngine:
         return self._classify_contigs(seq.ctypes.data, 1, seq.nbytes, offsets, single_window, precision)
 
     def classify_contigs_dev(self, seq_ptr: int, offsets: np.ndarray, single_window: bool = False,
-                             precision="f16c8"):
+                             precision="f16c6"):
         """Same as :meth:`classify_contigs` for a packed contig buffer that is already resident in
         HBM (``seq_ptr`` = device address of byte 0, ``offsets`` = (n_contigs+1,) byte offsets)."""
         offsets = np.ascontiguousarray(offsets, dtype=np.int64)
@@ -185,7 +185,7 @@ class NNEngine:
         return scores, ids[:n.value].copy()
 
     def classify_contigs_spans(self, seq_ptr: int, offsets: np.ndarray, single_window: bool = False,
-                               precision="f16c8"):
+                               precision="f16c6"):
         """The same result assembled on the host from the span-level entry points (gnn_span_byte_count,
         gnn_classify_spans, gnn_segment_mean) — kept as an independently coded cross-check for the tests."""
         from . import sequence as S

@@ -34,9 +34,10 @@ import numpy as np
 
 from . import sequence
 
-# arithmetic of the fused front end: "f16c8" = f16 MFMA + MX-fp8 corrections (fastest inside the 1e-4 tolerance),
-# "bf16x3" = split-bf16 three passes, "f32" = exact f32 reference kernels
-DEFAULT_PRECISION = "f16c8"
+# arithmetic of the fused front end: "f16c6" = f16 MFMA + MX-fp6 corrections (fastest inside the 1e-4 tolerance on BASELINE
+# config 2, no head-room: DESIGN.md section 2), "f16c8" = the same with fp8 corrections, "f16x3" = split-f16 three passes
+# (f32-class accuracy), "bf16x3" = split-bf16 three passes (f32 range), "f32" = exact f32 reference kernels
+DEFAULT_PRECISION = "f16c6"
 MODULE_NAME = "nn_classification"   # utils.write_execution_info("nn_classification", ...) :207-212
 TSV_HEADER = "seq_name\tchromosome_score\tplasmid_score\tvirus_score\n"   # :345
 

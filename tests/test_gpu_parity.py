@@ -165,9 +165,10 @@ def test_errors_are_reported_not_swallowed(engine):
 
 
 # ------------------------------------------------------------------ fused MFMA paths
-# f16c8 = f16 MFMA + MX-fp8 correction MFMAs (gnn_fused_c8.hip, the default), f16x3 / bf16x3 = split-f16 /
-# split-bf16, three passes (gnn_fused.hip).  Per-stage tolerances are absolute, against the fp64 oracle.
-FUSED = ["f16c8", "f16x3", "bf16x3"]
+# f16c6 = f16 MFMA + MX-fp6 correction MFMAs, both operands block scaled (gnn_fused_c6.hip), f16c8 = f16 MFMA + MX-fp8
+# correction MFMAs (gnn_fused_c8.hip), f16x3 / bf16x3 = split-f16 / split-bf16, three passes (gnn_fused.hip).
+# Per-stage tolerances are absolute, against the fp64 oracle.
+FUSED = ["f16c6", "f16c8", "f16x3", "bf16x3"]
 
 
 @pytest.mark.parametrize("prec", FUSED)
@@ -175,7 +176,7 @@ def test_fused_intermediates(engine, oracle16, prec):
     """Fused kernels (activations in LDS, low-precision MFMA operands) against the fp64 oracle, per stage."""
     bases, scores64, t64 = oracle16
     scores, taps = engine.debug_forward(bases, prec)
-    loose = {"f16c8": 2.5, "f16x3": 0.25}.get(prec, 1.0)   # 4-bit correction terms / 11+11-bit limbs vs bf16's 8+8
+    loose = {"f16c6": 2.5, "f16c8": 2.5, "f16x3": 0.25}.get(prec, 1.0)   # 4-bit correction terms / 11+11-bit limbs vs bf16's 8+8
     checks = [("m_a", "mA", 1e-4), ("m_b", "mB", 1e-3), ("yp_a", "ypA", 1e-4), ("yp_b", "ypB", 1e-3),
               ("alpha_a", "alphaA", 1e-5), ("alpha_b", "alphaB", 2e-4), ("feat", "f", 5e-4)]
     for mine, ref, tol in checks:
@@ -233,8 +234,11 @@ def test_f16c8_large_activations_saturate_instead_of_nan(synth_weights):
         _, taps = e2.debug_forward(bases, "f32", taps=("x1",))
         assert np.abs(taps["x1"]).max() > 500.0        # beyond the 464 where the conversion turns to NaN
         got, exact = e2.classify(bases, "f16c8"), e2.classify(bases, "f32")
+        got6 = e2.classify(bases, "f16c6")
     assert np.isfinite(got).all() and exact.std(axis=0).min() > 0.01
     assert np.abs(got - exact).max() <= 1e-3
+    # the block-scaled fp6 images of f16c6 follow the activations' magnitude: no clamp, full accuracy
+    assert np.isfinite(got6).all() and np.abs(got6 - exact).max() <= SCORE_TOL
 
 
 def test_f16_modes_overflow_is_detected_and_main_falls_back_to_bf16x3(synth_weights, tmp_path, monkeypatch):
@@ -254,7 +258,7 @@ def test_f16_modes_overflow_is_detected_and_main_falls_back_to_bf16x3(synth_weig
     with NNEngine(0, w) as e2:
         exact, wide = e2.classify(bases, "f32"), e2.classify(bases, "bf16x3")
         assert np.isfinite(wide).all() and np.abs(wide - exact).max() <= 1e-3
-        for prec in ("f16c8", "f16x3"):
+        for prec in ("f16c8", "f16c6", "f16x3"):
             assert not np.isfinite(e2.classify(bases, prec)).all()
         wpath = tmp_path / "w.npz"
         W.save_npz(wpath, w)
@@ -465,7 +469,7 @@ def test_config2_10k_windows_vs_reference_graph_golden(engine, golden_dir):
     n = len(ref32)
     assert n == 10_000
     worst = {}
-    for prec, tol64 in (("f32", 2e-5), ("f16x3", 2e-5), ("bf16x3", SCORE_TOL), ("f16c8", SCORE_TOL)):
+    for prec, tol64 in (("f32", 2e-5), ("f16x3", 2e-5), ("bf16x3", SCORE_TOL), ("f16c8", SCORE_TOL), ("f16c6", SCORE_TOL)):
         got = _classify_resident(engine, 0, n, prec)
         assert np.isfinite(got).all() and np.allclose(got.sum(1), 1.0, atol=1e-5)
         e32, e64 = np.abs(got - ref32).max(), np.abs(got - truth).max()
