@@ -68,7 +68,7 @@ __device__ __forceinline__ int swz(int buf_row) { return (buf_row >> 4) & 1; }
 static_assert(SMEM6 <= 160 * 1024, "LDS budget");
 static_assert(FT6 % 32 == 0, "carry-row copies keep bit 4 of the row index");
 static_assert(PROW_N <= 256, "one helper thread per pair row");
-static_assert(FT6 % 2 == 0, "the conv1 gather works on row pairs");
+static_assert(FT6 % 2 == 0 && FT6 >= 128, "the conv1 gather works on row pairs, two rounds of 64 rows per step at least");
 
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
@@ -470,13 +470,23 @@ __device__ __forceinline__ void gather_issue(GatherUnit& g, const uint16_t* __re
             for (int i = 0; i < 4; ++i) g.v[r][j][i] = *reinterpret_cast<const f32x4*>(src + i * 32);
         }
 }
-__device__ __forceinline__ void gather_finish(const GatherUnit& g, unsigned char* __restrict__ xbuf, int ua, int pq) {
+// the three table rows summed (bias is folded into table 0): 32 registers instead of 96 while a round waits for its slot
+struct GatherSum {
+    f32x4 sa[4], sb[4];    // row A / row B, channels 16 q + 4 i ..
+};
+__device__ __forceinline__ void gather_sum(GatherSum& o, const GatherUnit& g) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        o.sa[i] = g.v[0][0][i] + g.v[0][1][i] + g.v[0][2][i];
+        o.sb[i] = g.v[1][0][i] + g.v[1][1][i] + g.v[1][2][i];
+    }
+}
+__device__ __forceinline__ void gather_store(const GatherSum& g, unsigned char* __restrict__ xbuf, int ua, int pq) {
     const bool odd = pq & 1;
     float x[32];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-        const f32x4 sa = g.v[0][0][i] + g.v[0][1][i] + g.v[0][2][i];     // row A, channels 16 q + 4 i ..
-        const f32x4 sb = g.v[1][0][i] + g.v[1][1][i] + g.v[1][2][i];     // row B
+        const f32x4 sa = g.sa[i], sb = g.sb[i];
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             const float got = dpp_xor1(odd ? sa[k] : sb[k]);             // even lane keeps row A and gets the partner's row A half
@@ -485,6 +495,11 @@ __device__ __forceinline__ void gather_finish(const GatherUnit& g, unsigned char
         }
     }
     store_block32(xbuf, CARRY + ua + (odd ? 1 : 0), pq >> 1, x);
+}
+__device__ __forceinline__ void gather_finish(const GatherUnit& g, unsigned char* __restrict__ xbuf, int ua, int pq) {
+    GatherSum t;
+    gather_sum(t, g);
+    gather_store(t, xbuf, ua, pq);
 }
 
 // IGLOO pair dot products (igloo.py:192-204 with w_mult * w_summer folded) of head B for the previous step's x3 rows
@@ -588,8 +603,8 @@ __device__ __forceinline__ void m_partials2(PairJob jb, PairJob ja, int wave, in
 // Barriers B1..B4 per step exactly as in gnn_fused_c8.hip:
 //   matrix : w_v A(s), conv2 loop [bufX] | B1 | epilogue -> bufY (x2) | B2 | conv3 loop [bufY] | B3 |
 //            epilogue -> bufY (x3) | B4 | w_v B(s) [bufY]   -> straight into step s+1
-//   helpers: pair rows of step s+1, pair products B(s-1) [bufY] and A(s) [bufX] | B1 | x1 carry rows, gather(s+1) loads
-//            of the first unit | B2 | gather(s+1) -> bufX, read x2 carry | B3 | x2 carry rows -> bufY | B4
+//   helpers: pair rows of step s+1, pair products B(s-1) [bufY] and A(s) [bufX], gather(s+1) table loads | B1 | x1 carry rows,
+//            first half of x1(s+1) -> bufX | B2 | read x2 carry | B3 | x2 carry rows -> bufY, second half of x1(s+1) -> bufX | B4
 template <bool PROF>
 __global__ __launch_bounds__(512, 2) void fused_front_c6_kernel(Args a) {
     __shared__ __attribute__((aligned(16))) unsigned char smem[SMEM6];
@@ -706,36 +721,49 @@ __global__ __launch_bounds__(512, 2) void fused_front_c6_kernel(Args a) {
             uint4 carry = make_uint4(0, 0, 0, 0);
             const int cr = ht / ROW_U4, cc = ht - cr * ROW_U4;   // 5 rows x 29 chunks of 16 B
             if (ht < CARRY * ROW_U4) carry = *reinterpret_cast<const uint4*>(bufX + (FT6 + cr) * ROW6 + cc * 16);
+            // conv1 gather of the next step.  Beside the matrix waves' MFMA stream a helper wave gets VALU issue slots at
+            // about a quarter of the nominal rate (one row conversion: 2.9 k cycles alone, 10 k beside the conv3 loop), so
+            // the table loads are requested here, before B1; the first conversion runs in the window in which the matrix waves
+            // are in their conv2 epilogue and no MFMA is in flight on the CU (B1..B2), the second beside the conv3 loop, where
+            // the helpers have nothing else to do (both in the B3..B4 window as well made the matrix waves wait at B2 AND B4).
+#ifndef GNN_ABL_NOHELP
+            GatherUnit g0, g1;
+            gather_issue(g0, prow, a.conv1_k, gua, gpq);
+            gather_issue(g1, prow, a.conv1_k, gua + 64, gpq);
+#endif
             GNN_TICK(8)
             __syncthreads();                                                     // ---- B1
             GNN_TICK(11)
             if (ht < CARRY * ROW_U4) *reinterpret_cast<uint4*>(bufX + cr * ROW6 + cc * 16) = carry;
 #ifndef GNN_ABL_NOHELP
-            GatherUnit g;
-            gather_issue(g, prow, a.conv1_k, gua, gpq);                          // in flight across the short B1..B2 span
+            gather_finish(g0, bufX, gua, gpq);
+            GatherSum s1;
+            gather_sum(s1, g1);
 #endif
             GNN_TICK(12)
             __syncthreads();                                                     // ---- B2
             GNN_TICK(13)
 #ifndef GNN_ABL_NOHELP
-            if constexpr (PROF) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            GNN_TICK(9)                                                          // PROF: rest of the first round's round trip
-            gather_finish(g, bufX, gua, gpq);
-            GNN_TICK(14)                                                         // PROF: sum + conversion + LDS stores of one round
+#ifndef GNN_C6_X1B_LATE
+            gather_store(s1, bufX, gua + 64, gpq);                              // beside the conv3 loop, where the helpers have nothing else to do
+#endif
 #pragma unroll
-            for (int k = 1; k < GROUNDS; ++k)
+            for (int k = 2; k < GROUNDS; ++k)
                 if (gua + 64 * k < FT6) {
+                    GatherUnit g;
                     gather_issue(g, prow, a.conv1_k, gua + 64 * k, gpq);
-                    if constexpr (PROF) {
-                        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                        if (k == 1) { GNN_TICK(15) }                             // PROF: issue + round trip of the second round
-                    }
                     gather_finish(g, bufX, gua + 64 * k, gpq);
                 }
 #endif
             if (ht < CARRY * ROW_U4) carry = *reinterpret_cast<const uint4*>(bufY + (FT6 + cr) * ROW6 + cc * 16);
+            GNN_TICK(9)
             __syncthreads();                                                     // ---- B3
+            GNN_TICK(14)
             if (ht < CARRY * ROW_U4) *reinterpret_cast<uint4*>(bufY + cr * ROW6 + cc * 16) = carry;
+#if defined(GNN_C6_X1B_LATE) && !defined(GNN_ABL_NOHELP)
+            gather_store(s1, bufX, gua + 64, gpq);                              // measurement variant: in the conv3 epilogue window
+#endif
+            GNN_TICK(15)
             __syncthreads();                                                     // ---- B4
             if constexpr (PROF) tick_ = __builtin_readcyclecounter();
         }

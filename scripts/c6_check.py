@@ -62,7 +62,7 @@ for prec in ('f16c8', 'f16c6', 'f16c8', 'f16c6'):
     eng.profile_enable(False)
 import ctypes as C
 names = ["wvA", "conv2 loop", "wait B1", "conv2 epi+B2", "conv3 loop", "wait B3", "conv3 epi+B4", "wvB",
-         "h pairs", "h round-0 trip rest", "h prow", "h wait B1", "h carry+issue round 0", "h wait B2", "h finish round 0", "h round-1 issue+trip"]
+         "h pairs + table loads", "h x1 second half (B2..B3)", "h prow", "h wait B1", "h x1 first half", "h wait B2", "h wait B3", "h B3..B4"]
 names8 = names[:8] + ["helper pairs (B4..B1)", "helper B1..B4"]
 for prec in ('f16c8', 'f16c6'):
     rows = eng.lib.gnn_fused_rows_per_step(_lib.PRECISIONS[prec])

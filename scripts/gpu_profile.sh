@@ -9,6 +9,7 @@ mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 # 1. un-profiled bench lines
 timeout 600 python $ROOT/bench.py > $OUT/bench_default.json 2> $OUT/bench_default.err
+timeout 300 python $ROOT/bench.py --precision f16c8 --steps 16 --cpu-sample 0 > $OUT/bench_f16c8.json 2>> $OUT/bench_default.err
 timeout 300 python $ROOT/bench.py --precision bf16x3 --steps 16 --cpu-sample 0 > $OUT/bench_bf16x3.json 2>> $OUT/bench_default.err
 timeout 300 python $ROOT/bench.py --precision f16x3 --steps 16 --cpu-sample 0 > $OUT/bench_f16x3.json 2>> $OUT/bench_default.err
 timeout 300 python $ROOT/bench.py --steps 8 --force-dist --cpu-sample 0 > $OUT/bench_force_dist.json 2> $OUT/bench_force_dist.err
@@ -17,7 +18,11 @@ timeout 300 env WORLD_SIZE=1 RANK=0 LOCAL_RANK=0 MASTER_ADDR=127.0.0.1 MASTER_PO
 timeout 600 python $ROOT/bench.py --workload metagenome --gbp-total 3 --cpu-sample 0 > $OUT/bench_metagenome_3gbp.json 2> $OUT/bench_metagenome.err
 timeout 900 python $ROOT/bench.py --workload metagenome --gbp-total 60 --cpu-sample 0 > $OUT/bench_metagenome_60gbp.json 2>> $OUT/bench_metagenome.err
 # 1b. accuracy tails of the fused arithmetic options against the exact f32 device path
-(cd $ROOT && timeout 200 python scripts/seed_check.py 10000 42 43; timeout 300 python scripts/seed_check.py 100000 42 43) > $OUT/tails.txt 2>&1
+(cd $ROOT && timeout 200 python scripts/seed_check.py 10000 42 43; timeout 300 python scripts/seed_check.py 100000 42 43; timeout 400 python scripts/seed_check.py 1048576 42) > $OUT/tails.txt 2>&1
+# 1c. what the launch time is made of: ablation builds of the default kernel (scripts/mkvariant.sh c6<name> gnn_fused_c6 -DGNN_ABL_...)
+(cd $ROOT && python scripts/ablate_c6.py; for v in $(ls build_variants/lib_c6*.so 2>/dev/null); do GENOMAD_AMD_LIB=$v timeout 120 python scripts/ablate_c6.py; done; python scripts/ablate_c6.py) > $OUT/ablation_c6.txt 2>&1
+(cd $ROOT && timeout 300 python scripts/c6_check.py 8192) > $OUT/c6_check.txt 2>&1
+(cd $ROOT && timeout 300 python scripts/real_input_bench.py 600) > $OUT/real_input.txt 2>&1
 # 2. kernel trace + stats of the default command (shorter)
 rm -rf /tmp/kt
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/kt -- \
