@@ -267,10 +267,14 @@ __device__ __forceinline__ void prefetch_w(WRing& r, wrsrc_t wr, int woff, int h
 // FT6 rows x 32 columns, K = NTAPS * 128, as NTAPS * 4 fully unrolled k32 steps (static ring slots, static LDS offsets).
 // SWAP: D = W^T X^T for the convs (a lane ends up with 16 channels of one row), D = X W for y @ w_v (a lane ends up with
 // 16 rows of one channel: the max-pool is register local).
-template <bool SWAP, int NTAPS, int ROW0>   // ROW0 = buffer row of the tile's first row (the swizzle needs absolute rows)
-__device__ __forceinline__ void gemm_tile(const unsigned char* __restrict__ smem, int xoff, wrsrc_t wr, int woff,
+// The weight stream runs THROUGH the tile boundaries: the last RING - 1 steps of a tile request the first RING - 1 steps (and
+// the first scale word) of the NEXT tile (wr_next, NTAPS_NEXT), so a tile never starts behind the L2 round trip of its own
+// first weights (GNN_C6_NOCHAIN: measurement variant that requests them after the tile instead, as gnn_fused_c8.hip does).
+template <bool SWAP, int NTAPS, int ROW0, int NTAPS_NEXT>   // ROW0 = buffer row of the tile's first row (the swizzle needs absolute rows)
+__device__ __forceinline__ void gemm_tile(const unsigned char* __restrict__ smem, int xoff, wrsrc_t wr, wrsrc_t wr_next, int woff,
                                           int hw, WRing& ring, f32x16 (&acc)[NMB], int lane) {
     constexpr int NK = NTAPS * 4;
+    static_assert(NK % RING == 0 && NTAPS_NEXT * 4 >= RING - 1, "the next tile's first steps land in the slots it expects them in");
     // The lane's row offset is made opaque to the compiler: otherwise it keeps ONE base register for both activation
     // buffers and spends a v_add per LDS read whose folded offset (buffer + m-block + plane) passes the 16-bit DS offset
     // field - about 20 VALU issues per k32 step in a loop that is bound by issue slots.
@@ -291,7 +295,11 @@ __device__ __forceinline__ void gemm_tile(const unsigned char* __restrict__ smem
     static_for(std::make_integer_sequence<int, NK>{}, [&](auto kc) {
         constexpr int k = decltype(kc)::value, tap = k / 4, J = k % 4, TOFF = tap * ROW6;
         constexpr int kn = k + 1, TOFFN = (kn / 4) * ROW6, JN = kn % 4;
-        constexpr bool LW = k + RING - 1 < NK, LX = kn < NK;
+#ifdef GNN_C6_NOCHAIN
+        constexpr bool LW = k + RING - 1 < NK, LX = kn < NK, NEXT = false;
+#else
+        constexpr bool LW = true, LX = kn < NK, NEXT = k + RING - 1 >= NK;   // NEXT: this step's request belongs to the next tile
+#endif
         if constexpr (J == 0) {
             // 8-B parts of this tap's rows: slot J for even J (te) / odd J (to), see swz()
             const int sw8 = swz((lane & 31) + tap + ROW0) * 8;
@@ -301,9 +309,14 @@ __device__ __forceinline__ void gemm_tile(const unsigned char* __restrict__ smem
             if constexpr (tap + 1 < NTAPS)
                 ws_next = (int)__builtin_amdgcn_raw_buffer_load_b32(wr, lane_s, NK * WSTEP_B + (tap + 1) * 1024 + hw * 256, 0);
         }
+        if constexpr (NEXT && k == NK - 1)
+            ws_next = (int)__builtin_amdgcn_raw_buffer_load_b32(wr_next, lane_s, NTAPS_NEXT * 4 * WSTEP_B + hw * 256, 0);
         k32_step<SWAP, J, JN, LW, LX, TOFF, TOFFN>(ring.w[k % RING], ring.w[(k + RING - 1) % RING], xf, xc, sx, xh, xq, (J & 1) ? to : te, xs,
-                                                  wr, woff + (k + RING - 1) * WSTEP_B, l16, ws, acc);
+                                                  NEXT ? wr_next : wr, woff + (NEXT ? k + RING - 1 - NK : k + RING - 1) * WSTEP_B, l16, ws, acc);
     });
+#ifndef GNN_C6_NOCHAIN
+    ring.ws = ws_next;      // scale word of the next tile's tap 0
+#endif
 }
 
 // biased f16 exponent (at least 1: the subnormal range shares the exponent of the smallest normals) of a
@@ -390,13 +403,14 @@ __device__ __forceinline__ void conv_epilogue(unsigned char* __restrict__ obuf, 
     }
 }
 
-__device__ __forceinline__ void wv_mfma(const unsigned char* __restrict__ smem, int xoff, wrsrc_t wr, int woff,
+template <int NTAPS_NEXT>
+__device__ __forceinline__ void wv_mfma(const unsigned char* __restrict__ smem, int xoff, wrsrc_t wr, wrsrc_t wr_next, int woff,
                                         int hw, WRing& ring, f32x16 (&acc)[NMB], int lane) {
 #pragma unroll
     for (int mb = 0; mb < NMB; ++mb)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[mb][r] = 0.f;
-    gemm_tile<false, 1, CARRY>(smem, xoff + CARRY * ROW6, wr, woff, hw, ring, acc, lane);
+    gemm_tile<false, 1, CARRY, NTAPS_NEXT>(smem, xoff + CARRY * ROW6, wr, wr_next, woff, hw, ring, acc, lane);
 }
 // MaxPool1D(8) -> yp rows (igloo.py:209-210), as in gnn_fused_c8.hip
 __device__ __forceinline__ void wv_pool_store(const f32x16 (&acc)[NMB], wrsrc_t yp_w, int t0, int wave, int lane) {
@@ -658,13 +672,17 @@ __global__ __launch_bounds__(512, 2) void fused_front_c6_kernel(Args a) {
             const int t0 = step * FT6;
             GNN_TICK(7)
             f32x16 acc[NMB];
-            wv_mfma(smem, 0, vw[0], woff, hw, ring, acc, lane);
+            wv_mfma<KS>(smem, 0, vw[0], cw[0], woff, hw, ring, acc, lane);
+#ifdef GNN_C6_NOCHAIN
             prefetch_w<KS>(ring, cw[0], woff, hw, lane);                                // conv2 weights, hidden by the pooling
+#endif
             wv_pool_store(acc, yp_w[0], t0, hw, lane);
             GNN_TICK(0)
             acc_init_bias(acc, bias_s, hw, lane);
-            gemm_tile<true, KS, 0>(smem, 0, cw[0], woff, hw, ring, acc, lane);
+            gemm_tile<true, KS, 0, KS>(smem, 0, cw[0], cw[1], woff, hw, ring, acc, lane);
+#ifdef GNN_C6_NOCHAIN
             prefetch_w<KS>(ring, cw[1], woff, hw, lane);                                // conv3 weights, hidden by epilogue + barriers
+#endif
             GNN_TICK(1)
             __syncthreads();                                                     // ---- B1
             GNN_TICK(2)
@@ -672,16 +690,20 @@ __global__ __launch_bounds__(512, 2) void fused_front_c6_kernel(Args a) {
             __syncthreads();                                                     // ---- B2
             GNN_TICK(3)
             acc_init_bias(acc, bias_s + C, hw, lane);
-            gemm_tile<true, KS, 0>(smem, BUF6_BYTES, cw[1], woff, hw, ring, acc, lane);
+            gemm_tile<true, KS, 0, 1>(smem, BUF6_BYTES, cw[1], vw[1], woff, hw, ring, acc, lane);
+#ifdef GNN_C6_NOCHAIN
             prefetch_w<1>(ring, vw[1], woff, hw, lane);                                // w_v of head B
+#endif
             GNN_TICK(4)
             __syncthreads();                                                     // ---- B3
             GNN_TICK(5)
             conv_epilogue(bufY, acc, hw, lane);
             __syncthreads();                                                     // ---- B4
             GNN_TICK(6)
-            wv_mfma(smem, BUF6_BYTES, vw[1], woff, hw, ring, acc, lane);
+            wv_mfma<1>(smem, BUF6_BYTES, vw[1], vw[0], woff, hw, ring, acc, lane);
+#ifdef GNN_C6_NOCHAIN
             prefetch_w<1>(ring, vw[0], woff, hw, lane);                                // w_v of head A for the next step
+#endif
             wv_pool_store(acc, yp_w[1], t0, hw, lane);
         }
     } else {

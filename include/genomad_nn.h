@@ -56,11 +56,12 @@ typedef enum gnn_precision {
     GNN_PREC_F16C8 = 3,      /* fused path: one f16 MFMA pass + MX-scaled fp8 (e4m3) MFMA corrections of
                                 both operands' f16 rounding residuals = 2.0 pass equivalents; inside the
                                 1e-4 tolerance on BASELINE config 2 with little head-room (DESIGN.md §2,
-                                profiles/r02_precision_study.json); the fastest mode and the default of
-                                bench.py / main(); needs |activation| < 65504 (f16 range)                */
+                                profiles/r02_precision_study.json); needs |activation| < 65504 (f16 range) */
     GNN_PREC_F16C6 = 5,      /* fused path: one f16 MFMA pass + MX-scaled fp6 (e2m3) MFMA corrections, both operands block
                                 scaled (activations per row and 32 channels at run time) = 1.5 pass equivalents; the
-                                accuracy class of F16C8; needs |activation| < 65504 (f16 range)   */
+                                accuracy class of F16C8 (config 2: 8.2e-5); the fastest mode and the
+                                default of bench.py / main(); needs |activation| < 65504 (f16 range) and a 4-byte
+                                aligned window buffer (any gnn_dev_alloc / host staging buffer is)                      */
     GNN_PREC_F16X3 = 4       /* fused path: split-f16 (hi+lo, 11+11 significant bits), 3 MFMA passes, exact-f32 logits
                                 GEMM: f32-class accuracy (25x below bf16x3) at bf16x3's speed; needs
                                 |activation| < 65504 (f16 range)                                   */
