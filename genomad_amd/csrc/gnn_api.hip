@@ -221,6 +221,24 @@ const char* gnn_last_error(void) { return g_last_error.c_str(); }
 
 int gnn_version(void) { return 210; }
 
+int gnn_debug_pack_c6(const float* w, int k, int n, uint32_t* out, size_t out_words, size_t* need_words) {
+    std::vector<uint32_t> v;
+    const int rc = c6_pack_matrix(w, k, n, v);
+    if (rc) {
+        set_error("gnn_debug_pack_c6: w is NULL or K is not a multiple of 128 or N not a multiple of 32");
+        return rc;
+    }
+    if (need_words) *need_words = v.size();
+    if (out) {
+        if (out_words < v.size()) {
+            set_error("gnn_debug_pack_c6: output buffer too small");
+            return GNN_ERR_ARG;
+        }
+        std::memcpy(out, v.data(), v.size() * sizeof(uint32_t));
+    }
+    return GNN_OK;
+}
+
 int gnn_fused_rows_per_step(int precision) {
     switch (precision) {
         case GNN_PREC_F32: return 0;

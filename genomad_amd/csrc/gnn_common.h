@@ -159,6 +159,7 @@ int pack_fused_weights(gnn_ctx* ctx, const gnn_weights* w);
 int pack_fused_c8_weights(gnn_ctx* ctx, const gnn_weights* w);
 int pack_fused_c6_weights(gnn_ctx* ctx, const gnn_weights* w);
 int c6_rows_per_step();
+int c6_pack_matrix(const float* wmat, int K, int N, std::vector<uint32_t>& out);   // host only (tests)
 // conv1 pair tables (3, PAIR_ROWS, 128): W1[2j][a] + W1[2j+1][b] for every token pair of adjacent positions (gnn_api.hip)
 void build_conv1_pair_tables(const float* conv1_kernel, std::vector<float>& pt);
 

@@ -930,6 +930,15 @@ int pack_fused_c6_weights(gnn_ctx* ctx, const gnn_weights* w) {
 
 int c6_rows_per_step() { return c6::FT6; }
 
+// host-only: the f16c6 weight stream of one K x N matrix (fragments, then scale words) for the CPU test-suite
+int c6_pack_matrix(const float* wmat, int K, int N, std::vector<uint32_t>& out) {
+    if (!wmat || K <= 0 || N <= 0 || K % 128 || N % 32) return GNN_ERR_ARG;
+    std::vector<uint32_t> sc;
+    c6::pack_c6(wmat, K, N, out, sc);
+    out.insert(out.end(), sc.begin(), sc.end());
+    return GNN_OK;
+}
+
 int launch_front_c6(gnn_ctx* ctx, const uint8_t* bases, int64_t n) {
     using namespace c6;
     const DeviceWeights& d = ctx->w;

@@ -283,6 +283,13 @@ int gnn_mfma_probe(gnn_ctx* ctx, int ms_target, double* tflops_out);
  * (128 for the f16c8 / x3 kernels; 32 * GNN_C6_NMB for f16c6), 0 for GNN_PREC_F32, negative on a bad enum. */
 int gnn_fused_rows_per_step(int precision);
 
+/* test aid, host only (no GPU, no ctx): the f16c6 weight stream of a row-major K x N matrix (K multiple of 128, N of 32) as
+ * gnn_load_weights builds it — per (k32 step, 32-column block) 3584 B: the f16 fragments of the two k16 halves (2 x 1 KiB:
+ * lane l holds column l & 31, k = 16 s + 8 (l >> 5) + 0..7), the fp6 (e2m3) fragment dwords 0-3 (1 KiB) and 4-5 (512 B) of
+ * MX block l >> 5 (0: w - f16(w), 1: w; element i of the step's 32 k in bits 6i..6i+5) — followed by the E8M0 scale words
+ * [k / 128][block][lane], byte (k / 32) % 4.  need_words receives the size in 32-bit words; out may be NULL to query it. */
+int gnn_debug_pack_c6(const float* w, int k, int n, uint32_t* out, size_t out_words, size_t* need_words);
+
 /* windows the ctx processes per launch of the fused front end (workspace sizing) */
 int gnn_set_chunk(gnn_ctx* ctx, int64_t windows_per_chunk);
 

@@ -84,3 +84,58 @@ def test_precision_enum_matches_the_binding_and_rows_per_step():
     assert lib.gnn_fused_rows_per_step(77) < 0
     from genomad_amd import nn_classification
     assert nn_classification.DEFAULT_PRECISION in _lib.PRECISIONS
+
+
+def _e2m3_value(code):
+    import numpy as np
+    code = np.asarray(code)
+    e, m = (code >> 3) & 3, code & 7
+    mag = np.where(e == 0, m / 8.0, (1 + m / 8.0) * np.exp2(e - 1.0))
+    return np.where(code & 32, -mag, mag)
+
+
+def test_f16c6_weight_stream_decodes_to_the_mx_rounding_of_the_oracle_study():
+    """gnn_debug_pack_c6 (the host packer gnn_load_weights uses for GNN_PREC_F16C6) against an independent numpy
+    decoding: the f16 fragments are f16(w) (RNE) in MFMA fragment order, the fp6 fragments times 2^(scale byte - 127)
+    are the OCP-MX e2m3 images of w and of w - f16(w) (block = the 32 k of a step, exponent floor(log2 amax) - 2) that
+    oracle/precision_study.py's rnd_mx emulates — the arithmetic DESIGN.md section 2 prices."""
+    import numpy as np
+    from genomad_amd import _lib
+    from oracle import precision_study as PS
+    lib = _lib.load()
+    rng = np.random.default_rng(5)
+    K, N = 256, 64
+    w = (rng.standard_normal((K, N)) * np.exp2(rng.integers(-6, 3, size=(K, 1)))).astype(np.float32)
+    w[7, 3] = 0.0
+    w[32:64, 5] = 0.0                                         # an all-zero MX block
+    need = ctypes.c_size_t()
+    fp = w.ctypes.data_as(ctypes.POINTER(ctypes.c_float))
+    _lib.check(lib.gnn_debug_pack_c6(fp, K, N, None, 0, ctypes.byref(need)))
+    nk32, nblk = K // 32, N // 32
+    assert need.value == nk32 * nblk * 3584 // 4 + (K // 128) * nblk * 64
+    out = np.zeros(need.value, np.uint32)
+    _lib.check(lib.gnn_debug_pack_c6(fp, K, N, out.ctypes.data_as(ctypes.POINTER(ctypes.c_uint32)), out.size, None))
+    frag = out[:nk32 * nblk * 896].view(np.uint8).reshape(nk32, nblk, 3584)
+    scales = out[nk32 * nblk * 896:].view(np.uint8).reshape(K // 128, nblk, 64, 4)
+    h16 = w.astype(np.float16)
+    want_w = PS.rnd_mx(w.astype(np.float64), "e2m3", axis=0)
+    want_lo = PS.rnd_mx(w.astype(np.float64) - h16.astype(np.float64), "e2m3", axis=0)
+    for ks in range(nk32):
+        for nb in range(nblk):
+            rec = frag[ks, nb]
+            for s in range(2):                                 # f16 fragments
+                got = rec[s * 1024:(s + 1) * 1024].view(np.float16).reshape(64, 8)
+                for lane in (0, 13, 31, 32, 47, 63):
+                    k0 = ks * 32 + s * 16 + (lane >> 5) * 8
+                    assert np.array_equal(got[lane], h16[k0:k0 + 8, nb * 32 + (lane & 31)])
+            a = rec[2048:3072].reshape(64, 16)
+            b = rec[3072:3584].reshape(64, 8)
+            bits = np.unpackbits(np.concatenate([a, b], axis=1), axis=1, bitorder="little").reshape(64, 32, 6)
+            codes = (bits * (1 << np.arange(6))).sum(axis=2)
+            val = _e2m3_value(codes) * np.exp2(scales[ks // 4, nb, :, ks % 4].astype(np.float64) - 127)[:, None]
+            cols = nb * 32 + (np.arange(64) & 31)
+            want = np.where((np.arange(64) >> 5)[:, None] == 0, want_lo[ks * 32:(ks + 1) * 32, cols].T,
+                            want_w[ks * 32:(ks + 1) * 32, cols].T)
+            assert np.array_equal(val, want), (ks, nb)
+    with pytest.raises(_lib.GnnError):
+        _lib.check(lib.gnn_debug_pack_c6(fp, 100, N, None, 0, ctypes.byref(need)))
