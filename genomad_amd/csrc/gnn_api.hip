@@ -448,7 +448,7 @@ int gnn_load_weights(gnn_ctx* ctx, const gnn_weights* w) {
     }
     // Fold BatchNormalization (inference statistics) into the preceding Dense (model.py:28-30, 40-42):
     // y = gamma * (x@K + b - mean) / sqrt(var + eps) + beta = x@(K*s) + ((b - mean)*s + beta)
-    auto fold = [&](const gnn_dense_bn& l, int in, float** dk, float** db) -> int {
+    auto fold = [&](const gnn_dense_bn& l, int in, float** dk, float** db, uint16_t** dfrag) -> int {
         std::vector<float> k((size_t)in * HID), b(HID);
         for (int o = 0; o < HID; ++o) {
             const float s = l.gamma[o] / std::sqrt(l.var[o] + BN_EPS);
@@ -457,10 +457,17 @@ int gnn_load_weights(gnn_ctx* ctx, const gnn_weights* w) {
         }
         int r = upload(ctx, k.data(), k.size(), dk);
         if (r) return r;
-        return upload(ctx, b.data(), b.size(), db);
+        if ((r = upload(ctx, b.data(), b.size(), db))) return r;
+        const std::vector<uint16_t> fr = pack_frags(k.data(), in, HID, true);   // the same folded kernel, f16 hi / lo limbs, for dense_mfma_kernel
+        void* p = nullptr;
+        GNN_HIP(hipMalloc(&p, fr.size() * sizeof(uint16_t)));
+        ctx->owned.push_back(p);
+        GNN_HIP(hipMemcpy(p, fr.data(), fr.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
+        *dfrag = static_cast<uint16_t*>(p);
+        return GNN_OK;
     };
-    if ((rc = fold(w->enc, FEAT, &d.d1_k, &d.d1_b))) return rc;
-    if ((rc = fold(w->head, HID, &d.d2_k, &d.d2_b))) return rc;
+    if ((rc = fold(w->enc, FEAT, &d.d1_k, &d.d1_b, &d.d1_frag))) return rc;
+    if ((rc = fold(w->head, HID, &d.d2_k, &d.d2_b, &d.d2_frag))) return rc;
     if ((rc = upload(ctx, w->out_kernel, (size_t)HID * GNN_CLASSES, &d.d3_k))) return rc;
     if ((rc = upload(ctx, w->out_bias, (size_t)GNN_CLASSES, &d.d3_b))) return rc;
     if ((rc = pack_fused_weights(ctx, w))) return rc;

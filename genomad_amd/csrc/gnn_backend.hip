@@ -345,6 +345,113 @@ __global__ __launch_bounds__(512) void dense_kernel(const float* __restrict__ fe
     }
 }
 
+// The same dense stack on the matrix pipe (model.py:28-30, 40-44 with BN folded) for the f16-operand fast modes (f16c6,
+// f16c8): 64 windows per block, D = X W with X split to f16 hi/lo in registers (11 + 11 significant bits) and W pre-split
+// in MFMA fragment order (pack_frags), three products per k16 step -> f32-class accuracy (a split-bf16 version cost
+// 1.3e-5 of the 1e-4 score tolerance, which these modes do not have to spare).  Inputs beyond the f16 range give
+// non-finite scores, which is what these modes do everywhere else too (main() then falls back to bf16x3, whose dense
+// stack is the exact f32 kernel above).  Wave w owns columns
+// 128 w .. 128 w + 127 of the 512 hidden units for all 64 windows (2 x 4 accumulator blocks); the first layer's output
+// (bias + ReLU) goes through LDS (64 x 516 f32, rows padded so that the row groups of a C/D register land on
+// different banks) because every wave needs all of it as the second layer's A operand.  Dense3 + softmax as above.
+constexpr int DM_ROWS = 64;
+constexpr int DM_STRIDE = HID + 4;
+
+template <int KSTEPS, bool FROM_LDS>
+__device__ __forceinline__ void dense_mfma_layer(const float* __restrict__ a0, const float* __restrict__ a1, const uint4* __restrict__ frag,
+                                                 int wave, int lane, f32x16 (&acc)[2][4]) {
+    typedef float f32x8 __attribute__((ext_vector_type(8)));
+    typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    const float* rows[2] = {a0, a1};
+#pragma unroll 2
+    for (int ks = 0; ks < KSTEPS; ++ks) {
+        const int k = ks * 16 + (lane >> 5) * 8;
+        f16x8 ah[2], al[2];
+#pragma unroll
+        for (int mb = 0; mb < 2; ++mb) {
+            const float4 lo4 = *reinterpret_cast<const float4*>(rows[mb] + k), hi4 = *reinterpret_cast<const float4*>(rows[mb] + k + 4);
+            const f32x8 x = {lo4.x, lo4.y, lo4.z, lo4.w, hi4.x, hi4.y, hi4.z, hi4.w};
+            ah[mb] = __builtin_convertvector(x, f16x8);
+            al[mb] = __builtin_convertvector(x - __builtin_convertvector(ah[mb], f32x8), f16x8);
+        }
+        const uint4* bp = frag + ((size_t)ks * (HID / 32) + wave * 4) * 2 * 64 + lane;
+#pragma unroll
+        for (int nb = 0; nb < 4; ++nb) {
+            const f16x8 bh = __builtin_bit_cast(f16x8, bp[nb * 2 * 64]), bl = __builtin_bit_cast(f16x8, bp[nb * 2 * 64 + 64]);
+#pragma unroll
+            for (int mb = 0; mb < 2; ++mb) {
+                acc[mb][nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[mb], bl, acc[mb][nb], 0, 0, 0);
+                acc[mb][nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[mb], bh, acc[mb][nb], 0, 0, 0);
+                acc[mb][nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[mb], bh, acc[mb][nb], 0, 0, 0);
+            }
+        }
+    }
+}
+
+// bias + ReLU (NaN stays NaN, see dense_kernel) of a wave's 64 x 128 tile into the LDS rows
+__device__ __forceinline__ void dense_mfma_store(float* __restrict__ hs, const float* __restrict__ bias, int wave, int lane,
+                                                 const f32x16 (&acc)[2][4]) {
+#pragma unroll
+    for (int nb = 0; nb < 4; ++nb) {
+        const int col = (wave * 4 + nb) * 32 + (lane & 31);
+        const float b = bias[col];
+#pragma unroll
+        for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = mb * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);   // C/D layout of 32x32
+                const float v = acc[mb][nb][r] + b;
+                hs[row * DM_STRIDE + col] = v < 0.f ? 0.f : v;
+            }
+    }
+}
+
+__global__ __launch_bounds__(256) void dense_mfma_kernel(const float* __restrict__ feat, const uint4* __restrict__ f1,
+                                                         const float* __restrict__ d1b, const uint4* __restrict__ f2,
+                                                         const float* __restrict__ d2b, const float* __restrict__ d3k,
+                                                         const float* __restrict__ d3b, int n, float* __restrict__ scores) {
+    __shared__ __attribute__((aligned(16))) float hs[DM_ROWS * DM_STRIDE];
+    __shared__ float lg[DM_ROWS][4];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int w0 = blockIdx.x * DM_ROWS;
+    f32x16 acc[2][4];
+    // rows past the end are clamped (computed, never stored)
+    dense_mfma_layer<FEAT / 16, false>(feat + (size_t)min(w0 + (lane & 31), n - 1) * FEAT,
+                                       feat + (size_t)min(w0 + 32 + (lane & 31), n - 1) * FEAT, f1, wave, lane, acc);
+    dense_mfma_store(hs, d1b, wave, lane, acc);
+    __syncthreads();
+    dense_mfma_layer<HID / 16, true>(hs + (lane & 31) * DM_STRIDE, hs + (32 + (lane & 31)) * DM_STRIDE, f2, wave, lane, acc);
+    __syncthreads();                                   // every wave has read h1: the rows are reused for h2
+    dense_mfma_store(hs, d2b, wave, lane, acc);
+    __syncthreads();
+    for (int o = wave; o < DM_ROWS * GNN_CLASSES; o += 4) {
+        const int w = o / GNN_CLASSES, cl = o % GNN_CLASSES;
+        float s = 0.f;
+        for (int k = lane; k < HID; k += 64) s = fmaf(hs[w * DM_STRIDE + k], d3k[(size_t)k * GNN_CLASSES + cl], s);
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) s += __shfl_xor(s, off, 64);
+        if (lane == 0) lg[w][cl] = s + d3b[cl];
+    }
+    __syncthreads();
+    const int j = threadIdx.x;
+    if (j < DM_ROWS && w0 + j < n) {
+        const float a = lg[j][0], b = lg[j][1], c = lg[j][2];
+        const float mx = fmaxf(a, fmaxf(b, c));
+        const float ea = expf(a - mx), eb = expf(b - mx), ec = expf(c - mx);
+        const float inv = 1.f / (ea + eb + ec);
+        float* o = scores + (size_t)(w0 + j) * GNN_CLASSES;
+        o[0] = ea * inv;
+        o[1] = eb * inv;
+        o[2] = ec * inv;
+    }
+}
+
 int launch_backend(gnn_ctx* ctx, int64_t n, int precision, float* scores_dev) {
     const DeviceWeights& d = ctx->w;
     Workspace& ws = ctx->ws;
@@ -363,8 +470,13 @@ int launch_backend(gnn_ctx* ctx, int64_t n, int precision, float* scores_dev) {
                            ctx->stream, ws.m, d.w_qk[0], d.w_qk[1], (int)n, ws.logits);
     hipLaunchKernelGGL(attn_kernel, dim3((unsigned)n, 2), dim3(256), 0, ctx->stream, ws.logits, ws.yp, ws.alpha,
                        ws.feat);
-    hipLaunchKernelGGL(dense_kernel, dim3((unsigned)((n + DW - 1) / DW)), dim3(512), 0, ctx->stream, ws.feat,
-                       d.d1_k, d.d1_b, d.d2_k, d.d2_b, d.d3_k, d.d3_b, (int)n, scores_dev);
+    if (precision != GNN_PREC_F16C6 && precision != GNN_PREC_F16C8)    // exact f32 FMAs (f32 range and accuracy)
+        hipLaunchKernelGGL(dense_kernel, dim3((unsigned)((n + DW - 1) / DW)), dim3(512), 0, ctx->stream, ws.feat,
+                           d.d1_k, d.d1_b, d.d2_k, d.d2_b, d.d3_k, d.d3_b, (int)n, scores_dev);
+    else                                                                // split-f16 x 3 on the matrix pipe
+        hipLaunchKernelGGL(dense_mfma_kernel, dim3((unsigned)((n + DM_ROWS - 1) / DM_ROWS)), dim3(256), 0, ctx->stream, ws.feat,
+                           reinterpret_cast<const uint4*>(d.d1_frag), d.d1_b, reinterpret_cast<const uint4*>(d.d2_frag), d.d2_b,
+                           d.d3_k, d.d3_b, (int)n, scores_dev);
     GNN_HIP(hipGetLastError());
     return GNN_OK;
 }

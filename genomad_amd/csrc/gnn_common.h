@@ -68,6 +68,8 @@ struct DeviceWeights {
     float* d2_b = nullptr;
     float* d3_k = nullptr;  // (512,3)
     float* d3_b = nullptr;
+    uint16_t* d1_frag = nullptr;   // BN-folded Dense512 kernels in MFMA fragment order, f16 hi / lo (dense_mfma_kernel):
+    uint16_t* d2_frag = nullptr;   // [kstep][nblk 16][plane 2][lane 64][8]
     // fused path packs (gnn_fused.hip): MFMA fragment order, bf16 hi / lo planes
     uint16_t* conv_frag[2] = {nullptr, nullptr};  // conv2, conv3: [kstep 48][nblk 4][plane 2][lane 64][8]
     uint16_t* wv_frag[2] = {nullptr, nullptr};    // head A, B:   [kstep 8][nblk 4][plane 2][lane 64][8]
@@ -156,6 +158,8 @@ int launch_front_c6(gnn_ctx* ctx, const uint8_t* bases, int64_t n);             
 
 // host-side packing for the fused paths (gnn_fused.hip, gnn_fused_c8.hip)
 int pack_fused_weights(gnn_ctx* ctx, const gnn_weights* w);
+// K x N row-major f32 -> [kstep][nblk][plane hi, lo][lane 64][8 x 16 bit] (bf16 or f16 limbs), zero padded (gnn_fused.hip)
+std::vector<uint16_t> pack_frags(const float* wmat, int K, int N, bool f16 = false);
 int pack_fused_c8_weights(gnn_ctx* ctx, const gnn_weights* w);
 int pack_fused_c6_weights(gnn_ctx* ctx, const gnn_weights* w);
 int c6_rows_per_step();

@@ -450,7 +450,7 @@ static float f16_value(uint16_t u) {
     return (float)h;
 }
 
-static std::vector<uint16_t> pack_frags(const float* wmat, int K, int N, bool f16 = false) {
+std::vector<uint16_t> pack_frags(const float* wmat, int K, int N, bool f16) {
     const int ksteps = (K + 15) / 16, nblks = (N + 31) / 32;
     std::vector<uint16_t> out((size_t)ksteps * nblks * 2 * 64 * 8, 0);
     for (int ks = 0; ks < ksteps; ++ks)
