@@ -354,28 +354,28 @@ __global__ __launch_bounds__(512) void dense_kernel(const float* __restrict__ fe
 // 128 w .. 128 w + 127 of the 512 hidden units for all 64 windows (2 x 4 accumulator blocks); the first layer's output
 // (bias + ReLU) goes through LDS (64 x 516 f32, rows padded so that the row groups of a C/D register land on
 // different banks) because every wave needs all of it as the second layer's A operand.  Dense3 + softmax as above.
-constexpr int DM_ROWS = 64;
+constexpr int DM_MB = 1;                 // 32-window blocks per workgroup: 4096 windows = 128 workgroups (with 2: 64, half the chip idle and 0.13 ms)
+constexpr int DM_ROWS = 32 * DM_MB;
 constexpr int DM_STRIDE = HID + 4;
 
 template <int KSTEPS, bool FROM_LDS>
-__device__ __forceinline__ void dense_mfma_layer(const float* __restrict__ a0, const float* __restrict__ a1, const uint4* __restrict__ frag,
-                                                 int wave, int lane, f32x16 (&acc)[2][4]) {
+__device__ __forceinline__ void dense_mfma_layer(const float* __restrict__ a0, int row_stride, const uint4* __restrict__ frag,
+                                                 int wave, int lane, f32x16 (&acc)[DM_MB][4]) {
     typedef float f32x8 __attribute__((ext_vector_type(8)));
     typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < DM_MB; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-    const float* rows[2] = {a0, a1};
 #pragma unroll 2
     for (int ks = 0; ks < KSTEPS; ++ks) {
         const int k = ks * 16 + (lane >> 5) * 8;
-        f16x8 ah[2], al[2];
+        f16x8 ah[DM_MB], al[DM_MB];
 #pragma unroll
-        for (int mb = 0; mb < 2; ++mb) {
-            const float4 lo4 = *reinterpret_cast<const float4*>(rows[mb] + k), hi4 = *reinterpret_cast<const float4*>(rows[mb] + k + 4);
+        for (int mb = 0; mb < DM_MB; ++mb) {
+            const float4 lo4 = *reinterpret_cast<const float4*>(a0 + mb * row_stride + k), hi4 = *reinterpret_cast<const float4*>(a0 + mb * row_stride + k + 4);
             const f32x8 x = {lo4.x, lo4.y, lo4.z, lo4.w, hi4.x, hi4.y, hi4.z, hi4.w};
             ah[mb] = __builtin_convertvector(x, f16x8);
             al[mb] = __builtin_convertvector(x - __builtin_convertvector(ah[mb], f32x8), f16x8);
@@ -385,7 +385,7 @@ __device__ __forceinline__ void dense_mfma_layer(const float* __restrict__ a0, c
         for (int nb = 0; nb < 4; ++nb) {
             const f16x8 bh = __builtin_bit_cast(f16x8, bp[nb * 2 * 64]), bl = __builtin_bit_cast(f16x8, bp[nb * 2 * 64 + 64]);
 #pragma unroll
-            for (int mb = 0; mb < 2; ++mb) {
+            for (int mb = 0; mb < DM_MB; ++mb) {
                 acc[mb][nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[mb], bl, acc[mb][nb], 0, 0, 0);
                 acc[mb][nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[mb], bh, acc[mb][nb], 0, 0, 0);
                 acc[mb][nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[mb], bh, acc[mb][nb], 0, 0, 0);
@@ -396,13 +396,13 @@ __device__ __forceinline__ void dense_mfma_layer(const float* __restrict__ a0, c
 
 // bias + ReLU (NaN stays NaN, see dense_kernel) of a wave's 64 x 128 tile into the LDS rows
 __device__ __forceinline__ void dense_mfma_store(float* __restrict__ hs, const float* __restrict__ bias, int wave, int lane,
-                                                 const f32x16 (&acc)[2][4]) {
+                                                 const f32x16 (&acc)[DM_MB][4]) {
 #pragma unroll
     for (int nb = 0; nb < 4; ++nb) {
         const int col = (wave * 4 + nb) * 32 + (lane & 31);
         const float b = bias[col];
 #pragma unroll
-        for (int mb = 0; mb < 2; ++mb)
+        for (int mb = 0; mb < DM_MB; ++mb)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int row = mb * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);   // C/D layout of 32x32
@@ -420,13 +420,13 @@ __global__ __launch_bounds__(256) void dense_mfma_kernel(const float* __restrict
     __shared__ float lg[DM_ROWS][4];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int w0 = blockIdx.x * DM_ROWS;
-    f32x16 acc[2][4];
-    // rows past the end are clamped (computed, never stored)
-    dense_mfma_layer<FEAT / 16, false>(feat + (size_t)min(w0 + (lane & 31), n - 1) * FEAT,
-                                       feat + (size_t)min(w0 + 32 + (lane & 31), n - 1) * FEAT, f1, wave, lane, acc);
+    f32x16 acc[DM_MB][4];
+    // rows past the end are clamped (computed, never stored); the launch guarantees whole 32-row blocks exist for mb > 0 or clamps too
+    static_assert(DM_MB == 1, "the first layer's row clamp is written for one 32-window block per workgroup");
+    dense_mfma_layer<FEAT / 16, false>(feat + (size_t)min(w0 + (lane & 31), n - 1) * FEAT, 32 * FEAT, f1, wave, lane, acc);
     dense_mfma_store(hs, d1b, wave, lane, acc);
     __syncthreads();
-    dense_mfma_layer<HID / 16, true>(hs + (lane & 31) * DM_STRIDE, hs + (32 + (lane & 31)) * DM_STRIDE, f2, wave, lane, acc);
+    dense_mfma_layer<HID / 16, true>(hs + (lane & 31) * DM_STRIDE, 32 * DM_STRIDE, f2, wave, lane, acc);
     __syncthreads();                                   // every wave has read h1: the rows are reused for h2
     dense_mfma_store(hs, d2b, wave, lane, acc);
     __syncthreads();
