@@ -242,7 +242,8 @@ __device__ __forceinline__ void k32_step(const WStep& wcur, WStep& wload, XF& xf
 // The first RING - 1 k32 steps of a tile's weights + its first scale word are loaded BEFORE the epilogue and barrier that
 // precede the tile (prefetch_w), and inside the tile every step requests the weights of the step RING - 1 ahead into the
 // slot the previous step just released.  Measured with 2 ... 6 slots (profiles/README.md): the launch time does not depend
-// on the depth — the weight stream is not latency bound — so the default keeps the four slots of gnn_fused_c8.hip.
+// on the depth — the weight stream is not latency bound — so the default keeps the four slots of gnn_fused_c8.hip (with
+// the stream chained through the tile boundaries the depth has to divide the 4 steps of a tap: 2 or 4).
 struct WRing {
     WStep w[RING];
     int ws;
