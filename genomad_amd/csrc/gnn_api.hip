@@ -1,6 +1,7 @@
 // Host side of the C ABI declared in include/genomad_nn.h.
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 
 #include "gnn_common.h"
@@ -78,8 +79,7 @@ static void free_ws(Workspace& ws) {
 }
 
 // Make sure the workspace holds `chunk` windows (and the f32 activation buffers `x_chunk`).
-static int ensure_ws(gnn_ctx* ctx, int64_t chunk, int64_t x_chunk) {
-    Workspace& ws = ctx->ws;
+static int ensure_ws(gnn_ctx* ctx, Workspace& ws, int64_t chunk, int64_t x_chunk) {
     if (ws.chunk < chunk) {
         GNN_HIP(hipStreamSynchronize(ctx->stream));
         auto re = [&](auto*& p, size_t bytes) -> int {
@@ -188,11 +188,38 @@ int classify_chunks(gnn_ctx* ctx, const uint8_t* bases_dev, int64_t n, int preci
     }
     const bool f32 = precision == GNN_PREC_F32;
     const int64_t chunk = std::min<int64_t>(f32 ? ctx->chunk_f32 : ctx->chunk_fused, std::max<int64_t>(n, 1));
-    int rc = ensure_ws(ctx, chunk, f32 ? chunk : 0);
+    int rc = ensure_ws(ctx, ctx->ws, chunk, f32 ? chunk : 0);
     if (rc) return rc;
-    for (int64_t a = 0; a < n; a += chunk) {
+    // More than one chunk of a fused precision: the back end of chunk i (five small, mostly HBM-bound kernels, 5 % of
+    // the time) is enqueued on a second stream and runs beside the front end of chunk i+1, on whatever the power-bound
+    // fused kernel leaves idle between its workgroups; two workspaces alternate.  GNN_NO_BACKEND_OVERLAP=1 disables it.
+    static const bool allow_overlap = std::getenv("GNN_NO_BACKEND_OVERLAP") == nullptr;
+    const bool overlap = allow_overlap && !f32 && n > chunk;
+    if (overlap) {
+        if ((rc = ensure_ws(ctx, ctx->ws_alt, chunk, 0))) return rc;
+        if (!ctx->stream2) {
+            GNN_HIP(hipStreamCreateWithFlags(&ctx->stream2, hipStreamNonBlocking));
+            for (int i = 0; i < 2; ++i) {
+                GNN_HIP(hipEventCreateWithFlags(&ctx->ev_front[i], hipEventDisableTiming));
+                GNN_HIP(hipEventCreateWithFlags(&ctx->ev_back[i], hipEventDisableTiming));
+            }
+        }
+    }
+    struct StreamGuard {           // launchers read ctx->stream / ctx->ws: both are switched per phase and restored on every path
+        gnn_ctx* c;
+        hipStream_t main;
+        ~StreamGuard() { c->stream = main; }
+    } guard{ctx, ctx->stream};
+    int64_t idx = 0;
+    bool back_pending[2] = {false, false};
+    for (int64_t a = 0; a < n; a += chunk, ++idx) {
         const int64_t m = std::min(chunk, n - a);
         const uint8_t* b = bases_dev + a * W;
+        const int buf = (int)(idx & 1);
+        if (overlap) {
+            if (idx > 0) std::swap(ctx->ws, ctx->ws_alt);
+            if (back_pending[buf]) GNN_HIP(hipStreamWaitEvent(guard.main, ctx->ev_back[buf], 0));   // back end of chunk i-2 is done with it
+        }
         if (f32) {
             ProfScope ps(ctx, GNN_K_F32_FRONT);
             if ((rc = launch_front_f32(ctx, b, m))) return rc;
@@ -203,11 +230,26 @@ int classify_chunks(gnn_ctx* ctx, const uint8_t* bases_dev, int64_t n, int preci
                                                : launch_front_fused(ctx, b, m, precision);
             if (rc) return rc;
         }
+        if (overlap) {
+            GNN_HIP(hipEventRecord(ctx->ev_front[buf], guard.main));
+            ctx->stream = ctx->stream2;
+            GNN_HIP(hipStreamWaitEvent(ctx->stream2, ctx->ev_front[buf], 0));
+        }
         {
             ProfScope ps(ctx, GNN_K_BACKEND);
-            if ((rc = launch_backend(ctx, m, precision, scores_dev + a * GNN_CLASSES))) return rc;
+            rc = launch_backend(ctx, m, precision, scores_dev + a * GNN_CLASSES);
         }
+        if (overlap) {
+            if (!rc) {
+                GNN_HIP(hipEventRecord(ctx->ev_back[buf], ctx->stream2));
+                back_pending[buf] = true;
+            }
+            ctx->stream = guard.main;
+        }
+        if (rc) return rc;
     }
+    for (int i = 0; i < 2; ++i)         // the caller synchronises ctx->stream only
+        if (back_pending[i]) GNN_HIP(hipStreamWaitEvent(guard.main, ctx->ev_back[i], 0));
     return GNN_OK;
 }
 
@@ -330,6 +372,15 @@ int gnn_destroy(gnn_ctx* ctx) {
     if (ctx->comm || ctx->comm_scratch) (void)gnn_comm_destroy(ctx);
     free_contig_ws(ctx);
     free_ws(ctx->ws);
+    free_ws(ctx->ws_alt);
+    if (ctx->stream2) {
+        (void)hipStreamSynchronize(ctx->stream2);
+        for (int i = 0; i < 2; ++i) {
+            if (ctx->ev_front[i]) (void)hipEventDestroy(ctx->ev_front[i]);
+            if (ctx->ev_back[i]) (void)hipEventDestroy(ctx->ev_back[i]);
+        }
+        (void)hipStreamDestroy(ctx->stream2);
+    }
     for (void* p : ctx->owned) (void)hipFree(p);
     for (auto& s : ctx->prof)
         for (auto& pr : s.pending) {

@@ -120,6 +120,10 @@ struct gnn_ctx {
     bool has_weights = false;
     gnn::DeviceWeights w;
     gnn::Workspace ws;
+    // second workspace + stream: the back end of chunk i runs beside the front end of chunk i+1 (classify_chunks)
+    gnn::Workspace ws_alt;
+    hipStream_t stream2 = nullptr;
+    hipEvent_t ev_front[2] = {nullptr, nullptr}, ev_back[2] = {nullptr, nullptr};
     int64_t chunk_fused = 2048;
     int64_t chunk_f32 = 64;
     bool profile = false;
