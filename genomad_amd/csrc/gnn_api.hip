@@ -281,6 +281,13 @@ int gnn_debug_pack_c6(const float* w, int k, int n, uint32_t* out, size_t out_wo
     return GNN_OK;
 }
 
+int gnn_debug_set_pad_skip(gnn_ctx* ctx, int on) {
+    int rc = check_ctx(ctx);
+    if (rc) return rc;
+    ctx->c6_pad_skip = on != 0;
+    return GNN_OK;
+}
+
 int gnn_fused_rows_per_step(int precision) {
     switch (precision) {
         case GNN_PREC_F32: return 0;
@@ -354,6 +361,7 @@ int gnn_create(int device, gnn_ctx** out) {
     }
     gnn_ctx* ctx = new gnn_ctx();
     ctx->device = device;
+    ctx->c6_pad_skip = std::getenv("GNN_NO_PAD_SKIP") == nullptr;
     ctx->cu_count = prop.multiProcessorCount;
     hipError_t e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking);
     if (e != hipSuccess) {

@@ -89,6 +89,8 @@ struct DeviceWeights {
     float* conv1_pairs6 = nullptr;
     float* weff6[2] = {nullptr, nullptr};      // folded IGLOO weights, entry pairs x [i 8][entry parity][block 4][4 ch]
     int32_t* bucket_ptr6[2] = {nullptr, nullptr};
+    float* c6_yp_const = nullptr;   // (2, 749, 128) / (2, 8400): the f16c6 kernel's yp and mp of an all-N window (padding skip)
+    float* c6_mp_const = nullptr;
 };
 
 struct Workspace {
@@ -131,6 +133,7 @@ struct gnn_ctx {
     std::vector<hipEvent_t> event_pool;
     std::vector<void*> owned;   // device allocations to free at destroy
     int cu_count = 0;
+    bool c6_pad_skip = true;                      // f16c6: copy the all-N tail of a window instead of computing it (gnn_debug_set_pad_skip)
     unsigned long long* phase_cycles = nullptr;   // non-null: fused kernel runs its instrumented build
     gnn::ContigWorkspace* contig_ws = nullptr;    // gnn_contigs.hip: persistent buffers of gnn_classify_contigs
     // RCCL communicator of this ctx (gnn_comm.hip); ncclComm_t kept opaque here

@@ -28,6 +28,7 @@
 // The narrower row (464 instead of 528 B) is what lets a step hold FT6 = 160 rows (GNN_C6_NMB = 5) in 160 KB.
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <utility>
 
@@ -49,7 +50,8 @@ constexpr int BUF6_BYTES = BUF6_ROWS * ROW6;
 constexpr int PROW_OFF = 2 * BUF6_BYTES;
 constexpr int PROW_N = FT6 + 4;              // pair rows a step's conv1 gather reads
 constexpr int BIAS_OFF = PROW_OFF + ((PROW_N * 2 + 15) / 16) * 16;   // conv2 | conv3 bias, 2 x 128 f32
-constexpr int SMEM6 = BIAS_OFF + 2 * C * 4;
+constexpr int LAST_OFF = BIAS_OFF + 2 * C * 4;                        // index of the window's last ACGT base
+constexpr int SMEM6 = LAST_OFF + 16;
 constexpr int WNBLK_B = 3584;                // weight bytes per (k32 step, n-block): f16 k16 even | f16 k16 odd | fp6 16-B parts | fp6 8-B parts
 constexpr int WSTEP_B = 4 * WNBLK_B;         // per k32 step
 constexpr int ROW_U4 = ROW6 / 16;            // 29
@@ -88,6 +90,10 @@ struct Args {
     const int32_t* bucket_ptr[2];     // (STEPS6 + 1,) entry ranges per step of FT6 rows
     float* mp;
     float* yp;
+    // outputs of an all-N window (pack_fused_c6_weights runs the kernel on one at load time): the yp rows and pair products of
+    // a window's all-N tail are copied from here instead of being recomputed; nullptr = compute everything
+    const float* yp_c;
+    const float* mp_c;
     unsigned long long* cycles;       // PROF builds: 16 phase counters (GNN_TICK in gnn_fused_common.h), summed over workgroups:
                                       // matrix wave 0 -> 0..7, helper wave 4 -> 8..15 (names in scripts/c6_check.py)
 };
@@ -627,6 +633,7 @@ __global__ __launch_bounds__(512, 2) void fused_front_c6_kernel(Args a) {
     unsigned char* bufY = smem + BUF6_BYTES;
     uint16_t* prow = reinterpret_cast<uint16_t*>(smem + PROW_OFF);
     float* bias_s = reinterpret_cast<float*>(smem + BIAS_OFF);   // read at the head of every conv tile: LDS, not an L2 round trip
+    int* s_last = reinterpret_cast<int*>(smem + LAST_OFF);
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -644,6 +651,19 @@ __global__ __launch_bounds__(512, 2) void fused_front_c6_kernel(Args a) {
         reinterpret_cast<uint4*>(bufY)[i] = make_uint4(0, 0, 0, 0);
     }
     if (tid >= 256) bias_s[tid - 256] = a.conv_b[(tid - 256) >> 7][tid & 127];
+    // Padding skip.  From the first position p behind which every base is non-ACGT (the N padding of a contig's last window,
+    // nn_classification.py:72) every token is 0; x3[t] sees bases t-15 .. t+3, so all rows t >= p + 15 of all three layers
+    // carry the values they carry in an all-N window, whatever lies before p: the steps made of such rows only are not
+    // computed — their yp rows and pair products are copied from the all-N window's (same arithmetic, same rows: bit
+    // identical, tests/test_gpu_parity.py).  A contig's last window is half padding on average.
+    if (tid == 0) *s_last = -1;
+    __syncthreads();
+    if (a.yp_c) {
+        int last = -1;
+        for (int i = tid * 12; i < tid * 12 + 12 && i < W; ++i)
+            if (base_code_f(bases[i]) >= 0) last = i;
+        if (last >= 0) atomicMax(s_last, last);
+    }
     // pair rows of step 0: prow[i] = pair row of positions (t0 - 5 + i, t0 - 4 + i)
     if (tid < PROW_N) {
         uint32_t lo, hi;
@@ -651,6 +671,8 @@ __global__ __launch_bounds__(512, 2) void fused_front_c6_kernel(Args a) {
         prow[tid] = prow_make(lo, hi, tid - CARRY);
     }
     __syncthreads();
+    // steps [0, nsteps) contain a row t < p + 15 and are computed (at least one: an all-N window computes its first step)
+    const int nsteps = a.yp_c ? max(1, min(STEPS6, (*s_last + 1 + 15 + FT6 - 1) / FT6)) : STEPS6;
     unsigned long long cyc[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     unsigned long long tick_ = 0;
     const int gpq = ht & 7, gua = (ht >> 3) * 2;         // conv1 gather: 2 * block + channel half, first row of the lane pair (+ 64 per round)
@@ -669,7 +691,7 @@ __global__ __launch_bounds__(512, 2) void fused_front_c6_kernel(Args a) {
         __syncthreads();                                                         // x1 of step 0 is in bufX
         if constexpr (PROF) tick_ = __builtin_readcyclecounter();
 #pragma unroll 1
-        for (int step = 0; step < STEPS6; ++step) {
+        for (int step = 0; step < nsteps; ++step) {
             const int t0 = step * FT6;
             GNN_TICK(7)
             f32x16 acc[NMB];
@@ -722,7 +744,7 @@ __global__ __launch_bounds__(512, 2) void fused_front_c6_kernel(Args a) {
         __syncthreads();
         if constexpr (PROF) tick_ = __builtin_readcyclecounter();
 #pragma unroll 1
-        for (int step = 0; step < STEPS6; ++step) {
+        for (int step = 0; step < nsteps; ++step) {
             const int t0 = step * FT6;
             // pair rows of the next step (its gather runs behind B1; the previous gather finished before B4), from the
             // bytes requested a step ago; then the request for the step after
@@ -790,10 +812,22 @@ __global__ __launch_bounds__(512, 2) void fused_front_c6_kernel(Args a) {
             __syncthreads();                                                     // ---- B4
             if constexpr (PROF) tick_ = __builtin_readcyclecounter();
         }
-        const PairJob jb = {bufY, a.weff[1], a.pos_sorted[1], mp_w[1], (STEPS6 - 1) * FT6, a.bucket_ptr[1][STEPS6 - 1],
-                            a.bucket_ptr[1][STEPS6]};
+        const PairJob jb = {bufY, a.weff[1], a.pos_sorted[1], mp_w[1], (nsteps - 1) * FT6, a.bucket_ptr[1][nsteps - 1],
+                            a.bucket_ptr[1][nsteps]};
         const PairJob none = {bufX, a.weff[0], a.pos_sorted[0], mp_w[0], 0, 0, 0};
         m_partials2(jb, none, hw, lane);
+    }
+    if (nsteps < STEPS6) {            // the all-N tail: copy instead of compute (disjoint from what the steps above wrote)
+        const int q0 = nsteps * (FT6 / GNN_POOL);
+        const int nrow4 = (POOLED - q0) * (C / 4);
+        for (int i = tid; i < 2 * nrow4; i += 512) {
+            const int h = i >= nrow4, j = i - h * nrow4;
+            const size_t off = (size_t)h * POOLED * C + (size_t)q0 * C + (size_t)j * 4;
+            *reinterpret_cast<float4*>(a.yp + wi * 2 * (size_t)POOLED * C + off) = *reinterpret_cast<const float4*>(a.yp_c + off);
+        }
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+            for (int e = a.bucket_ptr[h][nsteps] + tid; e < NPAIR; e += 512) mp_w[h][e] = a.mp_c[h * NPAIR + e];
     }
     if constexpr (PROF) {
         if (tid == 0)
@@ -879,6 +913,22 @@ static int upload_vec(gnn_ctx* ctx, const std::vector<Tp>& v, Tp** dev) {
 
 }  // namespace c6
 
+namespace c6 {
+static void fill_args(const gnn_ctx* ctx, Args& a, const uint8_t* bases) {
+    const DeviceWeights& d = ctx->w;
+    a.bases = bases;
+    a.conv1_k = d.conv1_pairs6;
+    for (int i = 0; i < 2; ++i) {
+        a.conv_w[i] = reinterpret_cast<const unsigned char*>(d.conv_c6[i]);
+        a.conv_b[i] = d.conv_b[i];
+        a.wv_w[i] = reinterpret_cast<const unsigned char*>(d.wv_c6[i]);
+        a.weff[i] = d.weff6[i];
+        a.pos_sorted[i] = d.pos_sorted[i];
+        a.bucket_ptr[i] = d.bucket_ptr6[i];
+    }
+}
+}  // namespace c6
+
 int pack_fused_c6_weights(gnn_ctx* ctx, const gnn_weights* w) {
     using namespace c6;
     DeviceWeights& d = ctx->w;
@@ -926,6 +976,29 @@ int pack_fused_c6_weights(gnn_ctx* ctx, const gnn_weights* w) {
             }
         }
     if ((rc = upload_vec(ctx, pq, &d.conv1_pairs6))) return rc;
+    // the all-N window's outputs, computed once by the kernel itself (padding skip: see the kernel's prologue)
+    {
+        void *bn = nullptr, *yc = nullptr, *mc = nullptr;
+        GNN_HIP(hipMalloc(&bn, W));
+        GNN_HIP(hipMalloc(&yc, (size_t)2 * POOLED * C * sizeof(float)));
+        GNN_HIP(hipMalloc(&mc, (size_t)2 * NPAIR * sizeof(float)));
+        ctx->owned.push_back(bn);
+        ctx->owned.push_back(yc);
+        ctx->owned.push_back(mc);
+        GNN_HIP(hipMemsetAsync(bn, 'N', W, ctx->stream));
+        Args a;
+        fill_args(ctx, a, static_cast<const uint8_t*>(bn));
+        a.mp = static_cast<float*>(mc);
+        a.yp = static_cast<float*>(yc);
+        a.yp_c = nullptr;
+        a.mp_c = nullptr;
+        a.cycles = nullptr;
+        hipLaunchKernelGGL((fused_front_c6_kernel<false>), dim3(1), dim3(512), 0, ctx->stream, a);
+        GNN_HIP(hipGetLastError());
+        GNN_HIP(hipStreamSynchronize(ctx->stream));
+        d.c6_yp_const = static_cast<float*>(yc);
+        d.c6_mp_const = static_cast<float*>(mc);
+    }
     return GNN_OK;
 }
 
@@ -942,24 +1015,17 @@ int c6_pack_matrix(const float* wmat, int K, int N, std::vector<uint32_t>& out) 
 
 int launch_front_c6(gnn_ctx* ctx, const uint8_t* bases, int64_t n) {
     using namespace c6;
-    const DeviceWeights& d = ctx->w;
-    Args a;
-    a.bases = bases;
-    a.conv1_k = d.conv1_pairs6;
-    for (int i = 0; i < 2; ++i) {
-        a.conv_w[i] = reinterpret_cast<const unsigned char*>(d.conv_c6[i]);
-        a.conv_b[i] = d.conv_b[i];
-        a.wv_w[i] = reinterpret_cast<const unsigned char*>(d.wv_c6[i]);
-        a.weff[i] = d.weff6[i];
-        a.pos_sorted[i] = d.pos_sorted[i];
-        a.bucket_ptr[i] = d.bucket_ptr6[i];
-    }
-    a.mp = ctx->ws.mp;
-    a.yp = ctx->ws.yp;
     if (reinterpret_cast<uintptr_t>(bases) & 3u) {
         set_error("f16c6: the window buffer must be 4-byte aligned");
         return GNN_ERR_ARG;
     }
+    const bool pad_skip = ctx->c6_pad_skip;
+    Args a;
+    fill_args(ctx, a, bases);
+    a.mp = ctx->ws.mp;
+    a.yp = ctx->ws.yp;
+    a.yp_c = pad_skip ? ctx->w.c6_yp_const : nullptr;
+    a.mp_c = pad_skip ? ctx->w.c6_mp_const : nullptr;
     a.cycles = ctx->phase_cycles;
     if (ctx->phase_cycles) hipLaunchKernelGGL((fused_front_c6_kernel<true>), dim3((unsigned)n), dim3(512), 0, ctx->stream, a);
     else hipLaunchKernelGGL((fused_front_c6_kernel<false>), dim3((unsigned)n), dim3(512), 0, ctx->stream, a);

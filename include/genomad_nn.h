@@ -283,6 +283,12 @@ int gnn_mfma_probe(gnn_ctx* ctx, int ms_target, double* tflops_out);
  * (128 for the f16c8 / x3 kernels; 32 * GNN_C6_NMB for f16c6), 0 for GNN_PREC_F32, negative on a bad enum. */
 int gnn_fused_rows_per_step(int precision);
 
+/* test aid: the f16c6 kernel does not compute the steps of a window that lie entirely in its all-N tail (the padding of a
+ * contig's last window, nn_classification.py:72) — it copies the rows an all-N window produces, which the library computed
+ * with the same kernel at gnn_load_weights time (bit-identical by construction).  on = 0 makes it compute everything; the
+ * default is on (environment GNN_NO_PAD_SKIP=1 turns it off at gnn_create). */
+int gnn_debug_set_pad_skip(gnn_ctx* ctx, int on);
+
 /* test aid, host only (no GPU, no ctx): the f16c6 weight stream of a row-major K x N matrix (K multiple of 128, N of 32) as
  * gnn_load_weights builds it — per (k32 step, 32-column block) 3584 B: the f16 fragments of the two k16 halves (2 x 1 KiB:
  * lane l holds column l & 31, k = 16 s + 8 (l >> 5) + 0..7), the fp6 (e2m3) fragment dwords 0-3 (1 KiB) and 4-5 (512 B) of

@@ -721,3 +721,36 @@ def test_second_weight_set_and_engine(synth_weights):
     assert np.abs(got - want).max() <= SCORE_TOL
     assert np.abs(got8 - want).max() <= SCORE_TOL
     assert not np.array_equal(got, np.zeros_like(got))
+
+
+def test_f16c6_padding_skip_is_bit_identical(engine):
+    """The f16c6 kernel copies the yp rows and pair products of a window's all-N tail from an all-N window instead of
+    computing them (the padding of a contig's last window, nn_classification.py:72).  With the skip switched off the
+    scores AND the intermediates must be the same bits: windows of every length class (empty, shorter than a step,
+    ending exactly on / one base around a step boundary, N runs inside, IUPAC codes and lower case in the tail, full)."""
+    from genomad_amd import _lib
+    rng = np.random.default_rng(11)
+    def win(n, tail=b"N"):
+        body = bytes(rng.choice(list(b"ACGT"), n).tolist())
+        return (body + tail * 6000)[:6000]
+    lens = [0, 1, 3, 100, 112, 113, 114, 127, 128, 129, 2500, 2559, 2560, 2561, 4000, 5984, 5996, 5997, 6000]
+    wins = [win(n) for n in lens]
+    wins.append(win(3000, b"n"))                      # lower-case n: not ACGT either
+    wins.append(win(3000, b"R"))                      # IUPAC code
+    w = bytearray(win(6000)); w[1000:5200] = b"N" * 4200; wins.append(bytes(w))       # N run inside, bases after it
+    w = bytearray(win(2000)); w[500:700] = b"N" * 200; wins.append(bytes(w))
+    bases = np.frombuffer(b"".join(wins), np.uint8).reshape(len(wins), 6000).copy()
+    taps = ("m_a", "m_b", "yp_a", "yp_b", "feat")
+    try:
+        _lib.check(engine.lib.gnn_debug_set_pad_skip(engine.ctx, 0))
+        full, tfull = engine.debug_forward(bases, "f16c6", taps=taps)
+        _lib.check(engine.lib.gnn_debug_set_pad_skip(engine.ctx, 1))
+        skip, tskip = engine.debug_forward(bases, "f16c6", taps=taps)
+    finally:
+        _lib.check(engine.lib.gnn_debug_set_pad_skip(engine.ctx, 1))
+    assert np.isfinite(full).all()
+    for k in taps:
+        assert np.array_equal(tfull[k], tskip[k]), k
+    assert np.array_equal(full, skip)
+    exact = engine.classify(bases, "f32")
+    assert np.abs(skip - exact).max() <= SCORE_TOL
