@@ -15,7 +15,8 @@
 // Everything that touches an activation row works on (row, 32-channel block) units held by ONE lane, because that is
 // the granularity of the hardware's fp6 conversions (v_cvt_scalef32_pk32_fp6_f16: 32 values -> 24 bytes, natural
 // order: scripts/probe_mx.hip) and of the MX scale: the conv epilogues bring a row's 32 channels together with 16
-// v_permlane32_swap, the conv1 gather and the IGLOO pair products are mapped 4 lanes per row.
+// v_permlane32_swap, the conv1 gather works on lane pairs (each lane fetches half a block of two neighbouring rows, the
+// halves are swapped with DPP moves) and the IGLOO pair products are mapped 4 lanes per row.
 //
 // Operand layout facts (scripts/probe_mx.hip -> profiles/r02_probe_mx.txt): an fp6 operand of 32x32x64 is 6 dwords
 // per lane: lane l = row (or column) l & 31, K block l >> 5, element i of the block in bits [6i, 6i+6); the scale of
