@@ -103,8 +103,9 @@ def int_limbs(x, n, axis_scale):
 # A scheme turns (x rows, w matrix) into a list of (x_limb, w_limb) products to be summed, and says
 # how the activations are stored (what the pair-product path reads back).
 class Scheme:
-    def __init__(self, name, cost, xsplit, wsplit, terms, note="", stored=None):
+    def __init__(self, name, cost, xsplit, wsplit, terms, note="", stored=None, weff_fmt=None):
         self.name, self.cost, self.xsplit, self.wsplit, self.terms, self.note = name, cost, xsplit, wsplit, terms, note
+        self.weff_fmt = weff_fmt     # format the folded IGLOO weights (w_mult * w_summer) are rounded to for the pair products (None = f32)
         # what the pair-product path reads back from LDS: by default the sum of all activation limbs; the
         # correction schemes keep [hi, coarse image of x, image of the residual] and read hi + residual image
         self.stored = stored or (lambda limbs: sum(l for l in limbs if l is not None))
@@ -123,6 +124,21 @@ def _corr_x(lo_fmt, mx):
         # e4m3 with uniform hardware scales: x as is (range 2^-9 .. 448), residual scaled by 2^11
         return [hi, rnd(x, lo_fmt), rnd((x - hi) * 2048.0, lo_fmt) / 2048.0]
     return f
+
+
+def _corr_x_fp6_derived(x):
+    """f16c6 variant that was NOT built: the residual's block scale derived from the block maximum of x (2^-11 below the x
+    image's) instead of from the residuals' own maximum — one amax less per (row, block) in the kernel"""
+    x = np.asarray(x, dtype=np.float64)
+    hi = rnd(x, "fp16")
+    shp = x.shape
+    xb = x.reshape(shp[:-1] + (shp[-1] // 32, 32))
+    amax = np.abs(xb).max(axis=-1, keepdims=True)
+    e = np.floor(np.log2(np.where(amax > 0, amax, 1.0)))
+    s, sl = np.exp2(e - 2), np.exp2(e - 13)
+    x6 = (rnd(xb / s, "e2m3") * s).reshape(shp)
+    xl6 = (rnd((x - hi).reshape(xb.shape) / sl, "e2m3") * sl).reshape(shp)
+    return [hi, x6, xl6]
 
 
 _HI_PLUS_RESIDUAL = lambda l: l[0] + l[2]   # noqa: E731
@@ -175,6 +191,12 @@ SCHEMES = [
     Scheme("fp16 + e5m2 corrections", 2.0, _corr_x("e5m2", False), _corr_w("e5m2"), [(0, 0), (1, 2), (2, 1)], "", _HI_PLUS_RESIDUAL),
     Scheme("fp16 + e2m3 (fp6, MX both sides) corrections", 1.5, _corr_x("e2m3", True), _corr_w("e2m3"),
            [(0, 0), (1, 2), (2, 1)], "", _HI_PLUS_RESIDUAL),
+    Scheme("fp16 + e2m3 corrections, residual scale derived from the x scale", 1.5, _corr_x_fp6_derived, _corr_w("e2m3"),
+           [(0, 0), (1, 2), (2, 1)], "f16c6 variant, not built", _HI_PLUS_RESIDUAL),
+    Scheme("fp16 + e2m3 corrections, pair products read f16(x) only", 1.5, _corr_x("e2m3", True), _corr_w("e2m3"),
+           [(0, 0), (1, 2), (2, 1)], "f16c6 variant, not built", lambda l: l[0]),
+    Scheme("fp16 + e2m3 corrections, folded IGLOO weights in f16", 1.5, _corr_x("e2m3", True), _corr_w("e2m3"),
+           [(0, 0), (1, 2), (2, 1)], "f16c6 variant, not built", _HI_PLUS_RESIDUAL, weff_fmt="fp16"),
     Scheme("fp16 + e3m2 (bf6, MX both sides) corrections", 1.5, _corr_x("e3m2", True), _corr_w("e3m2"),
            [(0, 0), (1, 2), (2, 1)], "", _HI_PLUS_RESIDUAL),
     Scheme("fp16 + e2m1 (fp4, MX both sides) corrections", 1.5, _corr_x("e2m1", True), _corr_w("e2m1"),
@@ -250,6 +272,8 @@ def forward(tokens, W, layer_scheme):
     def head(x, hname, sch_v, sch_store):
         P = w[f"{hname}_patches"]
         weff = w[f"{hname}_w_mult"][0] * w[f"{hname}_w_summer"][0, :, 0].reshape(4, 128)[None]
+        if sch_store.weff_fmt:
+            weff = rnd(weff.astype(np.float32).astype(np.float64), sch_store.weff_fmt)
         xs = stored(x, sch_store)
         m = np.einsum("bpjc,pjc->bp", xs[:, P[:, :, 0], :], weff) + w[f"{hname}_w_bias"]
         alpha = IO._softmax(m @ w[f"{hname}_w_qk"])
@@ -315,6 +339,7 @@ def main():
     ap.add_argument("--quick", action="store_true", help="only the headline schemes")
     ap.add_argument("--only", nargs="+", default=None, help="substrings selecting schemes (no per-layer mixes)")
     ap.add_argument("--out", default=os.path.join(ROOT, "profiles", "r02_precision_study.json"))
+    ap.add_argument("--merge", action="store_true", help="keep the rows --out already holds for other schemes (with --only)")
     args = ap.parse_args()
     names = [s.name for s in SCHEMES]
     per_layer = [("fp16x3", "fp16x1"), ("fp16x3", "fp16x2 (hh+lh: x 2 limbs, w 1)"),
@@ -327,6 +352,9 @@ def main():
         names = [n for n in names if any(o in n for o in args.only)]
         per_layer = []
     rows = run(args.windows, args.seeds, names, per_layer)
+    if args.merge and os.path.exists(args.out):
+        new = {(r["seed"], r["scheme"]) for r in rows}
+        rows = [r for r in json.load(open(args.out))["rows"] if (r["seed"], r["scheme"]) not in new] + rows
     with open(args.out, "w") as f:
         json.dump({"windows": args.windows, "tolerance": 1e-4,
                    "note": "max |dscore| vs the fp64 oracle; operands rounded like the hardware formats, products "
