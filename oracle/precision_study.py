@@ -197,6 +197,18 @@ SCHEMES = [
            [(0, 0), (1, 2), (2, 1)], "f16c6 variant, not built", lambda l: l[0]),
     Scheme("fp16 + e2m3 corrections, folded IGLOO weights in f16", 1.5, _corr_x("e2m3", True), _corr_w("e2m3"),
            [(0, 0), (1, 2), (2, 1)], "f16c6 variant, not built", _HI_PLUS_RESIDUAL, weff_fmt="fp16"),
+    # error-source split of f16c6: one of the four 4-bit images exact at a time (and all four: what the dropped xl*wl term costs)
+    Scheme("fp16 + e2m3 corrections, x image exact", 1.5, lambda x: [rnd(x, "fp16"), np.asarray(x, np.float64), rnd_mx(x - rnd(x, "fp16"), "e2m3", -1)],
+           _corr_w("e2m3"), [(0, 0), (1, 2), (2, 1)], "diagnostic", _HI_PLUS_RESIDUAL),
+    Scheme("fp16 + e2m3 corrections, x residual exact", 1.5, lambda x: [rnd(x, "fp16"), rnd_mx(x, "e2m3", -1), x - rnd(x, "fp16")],
+           _corr_w("e2m3"), [(0, 0), (1, 2), (2, 1)], "diagnostic", _HI_PLUS_RESIDUAL),
+    Scheme("fp16 + e2m3 corrections, w image exact", 1.5, _corr_x("e2m3", True),
+           lambda w: [rnd(w, "fp16"), np.asarray(w, np.float64), rnd_mx(w - rnd(w, "fp16"), "e2m3", 0)], [(0, 0), (1, 2), (2, 1)], "diagnostic", _HI_PLUS_RESIDUAL),
+    Scheme("fp16 + e2m3 corrections, w residual exact", 1.5, _corr_x("e2m3", True),
+           lambda w: [rnd(w, "fp16"), rnd_mx(w, "e2m3", 0), w - rnd(w, "fp16")], [(0, 0), (1, 2), (2, 1)], "diagnostic", _HI_PLUS_RESIDUAL),
+    Scheme("fp16 + e2m3 corrections, all four images exact (only xl*wl dropped)", 1.5,
+           lambda x: [rnd(x, "fp16"), np.asarray(x, np.float64), x - rnd(x, "fp16")],
+           lambda w: [rnd(w, "fp16"), np.asarray(w, np.float64), w - rnd(w, "fp16")], [(0, 0), (1, 2), (2, 1)], "diagnostic", _HI_PLUS_RESIDUAL),
     Scheme("fp16 + e3m2 (bf6, MX both sides) corrections", 1.5, _corr_x("e3m2", True), _corr_w("e3m2"),
            [(0, 0), (1, 2), (2, 1)], "", _HI_PLUS_RESIDUAL),
     Scheme("fp16 + e2m1 (fp4, MX both sides) corrections", 1.5, _corr_x("e2m1", True), _corr_w("e2m1"),
