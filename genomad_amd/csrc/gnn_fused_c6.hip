@@ -471,14 +471,17 @@ __device__ __forceinline__ uint16_t prow_make(uint32_t lo, uint32_t hi, int t) {
 // 16 channels of BOTH rows (4 loads per table row: the 8 lanes of a row cover one whole 128-B line per load, a wave 8 lines —
 // with 4 lanes per row it was 16 half lines, and the vector memory path is paid per line touched), sums the three table rows,
 // and the two lanes then swap halves (16 DPP moves) so that each holds all 32 channels of ONE row for the conversion.
+// (Assigning the loads by role instead — each lane fetching the lower half of the row it keeps and the upper half of its
+// partner's — removes the 44 lane-parity selects of gather_store but makes every load touch 16 half lines again: measured
+// 18.64 vs 18.30 ms per 4096 windows, profiles/r02c6_ab_gather_roles.txt.)
 struct GatherUnit {
     f32x4 v[2][3][4];      // [row A / B][table][i]
 };
 __device__ __forceinline__ float dpp_xor1(float v) {     // value of lane ^ 1 (quad_perm [1,0,3,2])
-    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, false));
+    return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true));
 }
 __device__ __forceinline__ float dpp_xor2(float v) {     // value of lane ^ 2 (quad_perm [2,3,0,1])
-    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, false));
+    return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, true));
 }
 // ua = first row of the lane pair (even), pq = 2 p + q
 __device__ __forceinline__ void gather_issue(GatherUnit& g, const uint16_t* __restrict__ prow, const float* __restrict__ pt, int ua, int pq) {
