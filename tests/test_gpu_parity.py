@@ -754,3 +754,27 @@ def test_f16c6_padding_skip_is_bit_identical(engine):
     assert np.array_equal(full, skip)
     exact = engine.classify(bases, "f32")
     assert np.abs(skip - exact).max() <= SCORE_TOL
+
+
+def test_f16c6_rejects_a_misaligned_window_buffer(engine):
+    """The f16c6 kernel fetches the bases of its pair rows as aligned dwords: a device buffer that does not start on a
+    4-byte boundary is refused with an error (every gnn_dev_alloc / staging buffer is aligned), other modes take it."""
+    from genomad_amd._lib import GnnError
+    buf = engine.alloc(2 * 6000 + 8)
+    out = engine.alloc(2 * 12)
+    try:
+        engine.synth_windows_dev(0, 2, buf.ptr)
+        engine.sync()
+        host = buf.download((2 * 6000 + 8,), np.uint8)
+        shifted = np.concatenate([np.zeros(1, np.uint8), host[:2 * 6000]])
+        buf.upload(np.concatenate([shifted, np.zeros(7, np.uint8)]))
+        with pytest.raises(GnnError, match="4-byte aligned"):
+            engine.classify_dev(buf.ptr + 1, 2, out.ptr, "f16c6")
+        engine.classify_dev(buf.ptr + 1, 2, out.ptr, "f16c8")
+        engine.sync()
+        got = out.download((2, 3), np.float32)
+        want = engine.classify(host[:2 * 6000].reshape(2, 6000), "f16c8")
+        assert np.array_equal(got, want)
+    finally:
+        buf.free()
+        out.free()
