@@ -152,13 +152,16 @@ __device__ __forceinline__ void load_xf(XF& f, const unsigned char* __restrict__
         for (int mb = 0; mb < NMB; ++mb) f.v[s][mb] = *reinterpret_cast<const uint4*>(xh + TOFF + mb * 32 * ROW6 + (J * 2 + s) * 32);
 }
 // xq = lane base of the tap row's fp6 planes (x image for lanes 0-31, residual image for lanes 32-63)
-// x8 = the same + 64 +- 8 * swz(row): its slot J is the row's swizzled slot for even J (+) / odd J (-)
+// x8[mb] = the 8-B parts of m-block mb's tap row, + 8 * swz(row) for even J / - 8 * swz(row) for odd J (slot J is then the
+// row's swizzled slot).  One opaque pointer per m-block: with a common base the compiler fuses the b64 reads of two m-blocks
+// into one ds_read2st64_b64, whose four result registers then have to be MOVED behind the two b128 parts to form the 6-register
+// MFMA operands - 8 v_mov per k32 step, 14 % of all VALU instructions of the workgroup.
 template <int J, int TOFF>
-__device__ __forceinline__ void load_xc(XC& f, const unsigned char* __restrict__ xq, const unsigned char* __restrict__ x8) {
+__device__ __forceinline__ void load_xc(XC& f, const unsigned char* __restrict__ xq, const unsigned char* const (&x8)[NMB]) {
 #pragma unroll
     for (int mb = 0; mb < NMB; ++mb) {
         const uint4 a = *reinterpret_cast<const uint4*>(xq + TOFF + mb * 32 * ROW6 + J * 16);
-        const uint2 b = *reinterpret_cast<const uint2*>(x8 + mb * 32 * ROW6 + J * 8);
+        const uint2 b = *reinterpret_cast<const uint2*>(x8[mb] + J * 8);
         f.v[mb] = i32x8{(int)a.x, (int)a.y, (int)a.z, (int)a.w, (int)b.x, (int)b.y, 0, 0};
     }
 }
@@ -206,7 +209,7 @@ __device__ __forceinline__ void mfma_c6_phase(const WStep& w, const XC& x, int w
 template <bool SWAP, int J, int JN, bool LW, bool LX, int TOFF, int TOFFN>
 __device__ __forceinline__ void k32_step(const WStep& wcur, WStep& wload, XF& xf, XC& xc, int (&sx)[NMB],
                                          const unsigned char* __restrict__ xh, const unsigned char* __restrict__ xq,
-                                         const unsigned char* __restrict__ x8, const unsigned char* __restrict__ xs, wrsrc_t wr, int wnext,
+                                         const unsigned char* const (&x8)[NMB], const unsigned char* __restrict__ xs, wrsrc_t wr, int wnext,
                                          uint32_t l16, int ws, f32x16 (&acc)[NMB]) {
     // GNN_ABL_*: measurement-only ablations (scripts/mkvariant.sh) that compile parts of the work out — wrong results
     // by construction, used to see what the launch time is made of (profiles/README.md)
@@ -297,7 +300,9 @@ __device__ __forceinline__ void gemm_tile(const unsigned char* __restrict__ smem
     XC xc;
     int sx[NMB];
     int ws = ring.ws, ws_next = 0;
-    const unsigned char *te = xq, *to = xq;
+    const unsigned char *te[NMB], *to[NMB];
+#pragma unroll
+    for (int mb = 0; mb < NMB; ++mb) te[mb] = to[mb] = xq;
     load_xf<0, 0>(xf, xh);
     GNN_REGION_END();
     static_for(std::make_integer_sequence<int, NK>{}, [&](auto kc) {
@@ -311,8 +316,14 @@ __device__ __forceinline__ void gemm_tile(const unsigned char* __restrict__ smem
         if constexpr (J == 0) {
             // 8-B parts of this tap's rows: slot J for even J (te) / odd J (to), see swz()
             const int sw8 = swz((lane & 31) + tap + ROW0) * 8;
-            te = xq + TOFF + (X6B - X6A) + sw8;
-            to = xq + TOFF + (X6B - X6A) - sw8;
+#pragma unroll
+            for (int mb = 0; mb < NMB; ++mb) {
+                uint32_t oe = rowoff + X6B + (lane >> 5) * (L6A - X6A) + TOFF + mb * 32 * ROW6 + sw8, oo = oe - 2 * sw8;
+                asm volatile("" : "+v"(oe));
+                asm volatile("" : "+v"(oo));
+                te[mb] = smem + oe;
+                to[mb] = smem + oo;
+            }
             if constexpr (tap > 0) ws = ws_next;
             if constexpr (tap + 1 < NTAPS)
                 ws_next = (int)__builtin_amdgcn_raw_buffer_load_b32(wr, lane_s, NK * WSTEP_B + (tap + 1) * 1024 + hw * 256, 0);
