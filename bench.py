@@ -253,7 +253,9 @@ def main():
     eng.sync()
 
     def step(k):
-        eng.classify_dev(bases.ptr + k * wps_local * 6000, wps_local, scores.ptr + k * wps_local * 12, args.precision)
+        # asynchronous form: the back end of this step's last launch runs beside the front end of the next step's first
+        # launch (all steps are one job; the gather / download below orders everything)
+        eng.classify_dev_async(bases.ptr + k * wps_local * 6000, wps_local, scores.ptr + k * wps_local * 12, args.precision)
 
     for i in range(args.warmup):
         step(i % K)
@@ -263,6 +265,7 @@ def main():
     t0 = time.perf_counter()
     for k in range(K):
         step(k)
+    eng.flush()
     if comm is not None:          # ONE gather of every rank's (n_local, 3) f32 scores to rank 0 (ncclGather over xGMI)
         comm.gather_dev(scores.ptr, gathered_dev.ptr if gathered_dev is not None else None, n_local * 12, 0)
     host_scores = None

@@ -66,6 +66,8 @@ SIGNATURES = {
     "gnn_onehot_dev": (_int, [_vp, _vp, _i64, _int, _vp]),
     "gnn_classify": (_int, [_vp, _vp, _i64, _int, _vp]),
     "gnn_classify_dev": (_int, [_vp, _vp, _i64, _int, _vp]),
+    "gnn_classify_dev_async": (_int, [_vp, _vp, _i64, _int, _vp]),
+    "gnn_classify_flush": (_int, [_vp]),
     "gnn_segment_mean": (_int, [_vp, _vp, _vp, _i64, _i64, _vp]),
     "gnn_span_byte_count": (_int, [_vp, _vp, _vp, _vp, _i64, _int, _vp]),
     "gnn_classify_spans": (_int, [_vp, _vp, _vp, _vp, _i64, _int, _vp]),

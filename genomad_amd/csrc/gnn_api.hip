@@ -135,13 +135,24 @@ static int ensure_ws(gnn_ctx* ctx, Workspace& ws, int64_t chunk, int64_t x_chunk
     return GNN_OK;
 }
 
-static int check_ctx(gnn_ctx* ctx) {
+int flush_backend(gnn_ctx* ctx) {
+    for (int i = 0; i < 2; ++i)
+        if (ctx->back_pending[i]) {
+            GNN_HIP(hipStreamWaitEvent(ctx->stream, ctx->ev_back[i], 0));
+            ctx->back_pending[i] = false;
+        }
+    return GNN_OK;
+}
+
+// every entry point but gnn_classify_dev_async: what an earlier asynchronous classification left on the second stream is
+// ordered before anything this call enqueues on ctx->stream
+static int check_ctx(gnn_ctx* ctx, bool flush = true) {
     if (!ctx) {
         set_error("ctx is NULL");
         return GNN_ERR_ARG;
     }
     GNN_HIP(hipSetDevice(ctx->device));
-    return GNN_OK;
+    return flush ? flush_backend(ctx) : GNN_OK;
 }
 
 // conv1 pair tables.  conv1 on the one-hot input is sum_k W1[k][tok[t-5+k]] (model.py:11 +
@@ -176,7 +187,7 @@ void build_conv1_pair_tables(const float* k1, std::vector<float>& pt) {
 }
 
 // One pass of the hot path over n windows whose bases are on the device.
-int classify_chunks(gnn_ctx* ctx, const uint8_t* bases_dev, int64_t n, int precision, float* scores_dev) {
+int classify_chunks(gnn_ctx* ctx, const uint8_t* bases_dev, int64_t n, int precision, float* scores_dev, bool defer_last) {
     if (!ctx->has_weights) {
         set_error("gnn_load_weights has not been called");
         return GNN_ERR_STATE;
@@ -190,11 +201,16 @@ int classify_chunks(gnn_ctx* ctx, const uint8_t* bases_dev, int64_t n, int preci
     const int64_t chunk = std::min<int64_t>(f32 ? ctx->chunk_f32 : ctx->chunk_fused, std::max<int64_t>(n, 1));
     int rc = ensure_ws(ctx, ctx->ws, chunk, f32 ? chunk : 0);
     if (rc) return rc;
-    // More than one chunk of a fused precision: the back end of chunk i (five small, mostly HBM-bound kernels, 5 % of
-    // the time) is enqueued on a second stream and runs beside the front end of chunk i+1, on whatever the power-bound
-    // fused kernel leaves idle between its workgroups; two workspaces alternate.  GNN_NO_BACKEND_OVERLAP=1 disables it.
+    // More than one chunk of a fused precision, or an asynchronous call: the back end of chunk i (five small, mostly
+    // HBM-bound kernels, 5 % of the time) is enqueued on a second stream and runs beside the front end of chunk i+1 (of this
+    // call or of the next one), on whatever the power-bound fused kernel leaves idle between its workgroups; two workspaces
+    // alternate.  GNN_NO_BACKEND_OVERLAP=1 disables it.
     static const bool allow_overlap = std::getenv("GNN_NO_BACKEND_OVERLAP") == nullptr;
-    const bool overlap = allow_overlap && !f32 && n > chunk;
+    const bool pending = ctx->back_pending[0] || ctx->back_pending[1];
+    if (pending && (f32 || !allow_overlap)) {
+        if ((rc = flush_backend(ctx))) return rc;
+    }
+    const bool overlap = allow_overlap && !f32 && (n > chunk || defer_last || pending);
     if (overlap) {
         if ((rc = ensure_ws(ctx, ctx->ws_alt, chunk, 0))) return rc;
         if (!ctx->stream2) {
@@ -210,15 +226,13 @@ int classify_chunks(gnn_ctx* ctx, const uint8_t* bases_dev, int64_t n, int preci
         hipStream_t main;
         ~StreamGuard() { c->stream = main; }
     } guard{ctx, ctx->stream};
-    int64_t idx = 0;
-    bool back_pending[2] = {false, false};
-    for (int64_t a = 0; a < n; a += chunk, ++idx) {
+    for (int64_t a = 0; a < n; a += chunk) {
         const int64_t m = std::min(chunk, n - a);
         const uint8_t* b = bases_dev + a * W;
-        const int buf = (int)(idx & 1);
-        if (overlap) {
-            if (idx > 0) std::swap(ctx->ws, ctx->ws_alt);
-            if (back_pending[buf]) GNN_HIP(hipStreamWaitEvent(guard.main, ctx->ev_back[buf], 0));   // back end of chunk i-2 is done with it
+        const int buf = ctx->buf_cur;
+        if (overlap && ctx->back_pending[buf]) {      // the back end that last used this workspace
+            GNN_HIP(hipStreamWaitEvent(guard.main, ctx->ev_back[buf], 0));
+            ctx->back_pending[buf] = false;
         }
         if (f32) {
             ProfScope ps(ctx, GNN_K_F32_FRONT);
@@ -242,15 +256,15 @@ int classify_chunks(gnn_ctx* ctx, const uint8_t* bases_dev, int64_t n, int preci
         if (overlap) {
             if (!rc) {
                 GNN_HIP(hipEventRecord(ctx->ev_back[buf], ctx->stream2));
-                back_pending[buf] = true;
+                ctx->back_pending[buf] = true;
             }
             ctx->stream = guard.main;
+            std::swap(ctx->ws, ctx->ws_alt);          // the next chunk (of this or of the next call) takes the other workspace
+            ctx->buf_cur ^= 1;
         }
         if (rc) return rc;
     }
-    for (int i = 0; i < 2; ++i)         // the caller synchronises ctx->stream only
-        if (back_pending[i]) GNN_HIP(hipStreamWaitEvent(guard.main, ctx->ev_back[i], 0));
-    return GNN_OK;
+    return defer_last ? GNN_OK : flush_backend(ctx);     // the caller synchronises ctx->stream only
 }
 
 }  // namespace gnn
@@ -636,6 +650,19 @@ int gnn_classify_dev(gnn_ctx* ctx, const uint8_t* bases_dev, int64_t n, int prec
     if (n == 0) return GNN_OK;
     return classify_chunks(ctx, bases_dev, n, precision, scores_dev);
 }
+
+int gnn_classify_dev_async(gnn_ctx* ctx, const uint8_t* bases_dev, int64_t n, int precision, float* scores_dev) {
+    int rc = check_ctx(ctx, false);
+    if (rc) return rc;
+    if (n < 0 || (n > 0 && (!bases_dev || !scores_dev))) {
+        set_error("bad argument to gnn_classify_dev_async");
+        return GNN_ERR_ARG;
+    }
+    if (n == 0) return GNN_OK;
+    return classify_chunks(ctx, bases_dev, n, precision, scores_dev, true);
+}
+
+int gnn_classify_flush(gnn_ctx* ctx) { return check_ctx(ctx); }
 
 int gnn_classify(gnn_ctx* ctx, const uint8_t* bases_host, int64_t n, int precision, float* scores_host) {
     return gnn_debug_forward(ctx, bases_host, n, precision, scores_host, nullptr);

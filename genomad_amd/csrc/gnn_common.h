@@ -126,6 +126,8 @@ struct gnn_ctx {
     gnn::Workspace ws_alt;
     hipStream_t stream2 = nullptr;
     hipEvent_t ev_front[2] = {nullptr, nullptr}, ev_back[2] = {nullptr, nullptr};
+    bool back_pending[2] = {false, false};   // ev_back[i] recorded on stream2 and not yet waited for by `stream`
+    int buf_cur = 0;                         // which of the two alternating workspaces `ws` currently is
     int64_t chunk_fused = 2048;
     int64_t chunk_f32 = 64;
     bool profile = false;
@@ -157,7 +159,10 @@ int launch_front_f32(gnn_ctx* ctx, const uint8_t* bases, int64_t n);         // 
 int launch_front_fused(gnn_ctx* ctx, const uint8_t* bases, int64_t n, int precision);  // -> ws.mp, ws.yp
 int launch_backend(gnn_ctx* ctx, int64_t n, int precision, float* scores_dev);   // ws.mp, ws.yp -> scores
 // one pass of the hot path over n windows whose padded bases are on the device (gnn_api.hip)
-int classify_chunks(gnn_ctx* ctx, const uint8_t* bases_dev, int64_t n, int precision, float* scores_dev);
+// defer_last: leave the last chunk's back end pending on the second stream (gnn_classify_dev_async); flush_backend()
+// makes ctx->stream wait for whatever is pending - every entry point that enqueues on ctx->stream or reads scores calls it
+int classify_chunks(gnn_ctx* ctx, const uint8_t* bases_dev, int64_t n, int precision, float* scores_dev, bool defer_last = false);
+int flush_backend(gnn_ctx* ctx);
 void free_contig_ws(gnn_ctx* ctx);     // gnn_contigs.hip
 
 int launch_front_c8(gnn_ctx* ctx, const uint8_t* bases, int64_t n);             // GNN_PREC_F16C8 -> ws.mp, ws.yp

@@ -111,6 +111,10 @@ extern "C" int gnn_classify_contigs(gnn_ctx* ctx, const uint8_t* seq, int seq_on
         return GNN_ERR_ARG;
     }
     GNN_HIP(hipSetDevice(ctx->device));
+    {
+        const int frc = flush_backend(ctx);
+        if (frc) return frc;
+    }
     if (n_contigs < 0 || seq_bytes < 0 || !offsets_host || !n_windows_out || (n_contigs > 0 && !contig_scores_host) ||
         (seq_bytes > 0 && !seq)) {
         set_error("bad argument to gnn_classify_contigs");

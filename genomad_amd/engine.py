@@ -133,6 +133,14 @@ class NNEngine:
         check(self.lib.gnn_classify_dev(self.ctx, bases_ptr, int(n), _lib.PRECISIONS[precision],
                                         scores_ptr))
 
+    def classify_dev_async(self, bases_ptr: int, n: int, scores_ptr: int, precision="f16c6"):
+        """classify_dev whose last back end may still run beside the next call's front end; call :meth:`flush`
+        (or sync / download / a collective) before reading the scores."""
+        check(self.lib.gnn_classify_dev_async(self.ctx, bases_ptr, int(n), _lib.PRECISIONS[precision], scores_ptr))
+
+    def flush(self):
+        check(self.lib.gnn_classify_flush(self.ctx))
+
     def debug_forward(self, bases, precision="f32", taps=("m_a", "m_b", "yp_a", "yp_b",
                                                          "alpha_a", "alpha_b", "feat")):
         """Scores plus the requested intermediates as a dict of numpy arrays."""

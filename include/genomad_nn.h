@@ -156,6 +156,14 @@ int gnn_onehot_dev(gnn_ctx* ctx, const uint8_t* bases_dev, int64_t n_windows, in
  * scores[n][3] = softmax class scores per window.  precision: gnn_precision. */
 int gnn_classify(gnn_ctx* ctx, const uint8_t* bases_host, int64_t n_windows, int precision,
                  float* scores_host);
+/* gnn_classify_dev_async: the same, but the back end (pair-product reduction, logits, attention sum, dense head) of the call's
+ * last chunk may still be running on the library's second stream when the call returns, beside the front end of the NEXT
+ * asynchronous call — for loops over batches that fit one launch.  scores_dev is complete once gnn_classify_flush (or any
+ * other entry point of this ctx: gnn_sync, gnn_memcpy_d2h, gnn_comm_gather_dev, gnn_classify_dev ...) has been called and
+ * the ctx stream has been synchronised; results are bit-identical to gnn_classify_dev. */
+int gnn_classify_dev_async(gnn_ctx* ctx, const uint8_t* bases_dev, int64_t n_windows, int precision, float* scores_dev);
+int gnn_classify_flush(gnn_ctx* ctx);
+
 int gnn_classify_dev(gnn_ctx* ctx, const uint8_t* bases_dev, int64_t n_windows, int precision,
                      float* scores_dev);   /* asynchronous on the ctx stream */
 

@@ -778,3 +778,41 @@ def test_f16c6_rejects_a_misaligned_window_buffer(engine):
     finally:
         buf.free()
         out.free()
+
+
+def test_asynchronous_classification_is_bit_identical(engine):
+    """gnn_classify_dev_async leaves the last back end of a call on the second stream, beside the next call's front end
+    (two alternating workspaces).  Many small calls (one launch each), mixed sizes, interleaved with synchronous calls and a
+    debug forward: after gnn_classify_flush + sync the scores are the bits the synchronous entry point produces."""
+    n = 6 * 1024 + 300
+    bases = engine.alloc(n * 6000)
+    a = engine.alloc(n * 12)
+    b = engine.alloc(n * 12)
+    try:
+        engine.synth_windows_dev(4242, n, bases.ptr)
+        engine.classify_dev(bases.ptr, n, a.ptr, "f16c6")
+        engine.sync()
+        want = a.download((n, 3), np.float32)
+        cuts = [0, 1024, 1030, 2048, 3072, 3073, 5000, 6144, n]
+        for lo, hi in zip(cuts[:-1], cuts[1:]):
+            engine.classify_dev_async(bases.ptr + lo * 6000, hi - lo, b.ptr + lo * 12, "f16c6")
+            if lo == 2048:          # a tapped forward in between reads ITS workspace, whatever is pending
+                tb = synthetic.synth_windows(7, 4)
+                s1, t1 = engine.debug_forward(tb, "f16c6")
+                s2, t2 = engine.debug_forward(tb, "f16c6")
+                assert np.array_equal(s1, s2) and all(np.array_equal(t1[k], t2[k]) for k in t1)
+                assert np.isfinite(t1["feat"]).all() and np.abs(t1["feat"]).max() > 0
+        engine.flush()
+        engine.sync()
+        got = b.download((n, 3), np.float32)
+        assert np.array_equal(got, want)
+        # no explicit flush: a download orders the pending back end as well
+        engine.classify_dev_async(bases.ptr, 512, b.ptr, "f16c8")
+        engine.classify_dev_async(bases.ptr + 512 * 6000, 512, b.ptr + 512 * 12, "f16c8")
+        got8 = b.download((1024, 3), np.float32)
+        engine.classify_dev(bases.ptr, 1024, a.ptr, "f16c8")
+        engine.sync()
+        assert np.array_equal(got8, a.download((1024, 3), np.float32))
+    finally:
+        for buf in (bases, a, b):
+            buf.free()
