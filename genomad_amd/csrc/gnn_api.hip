@@ -80,6 +80,10 @@ static void free_ws(Workspace& ws) {
 
 // Make sure the workspace holds `chunk` windows (and the f32 activation buffers `x_chunk`).
 static int ensure_ws(gnn_ctx* ctx, Workspace& ws, int64_t chunk, int64_t x_chunk) {
+    if (ws.chunk < chunk || ws.x_chunk < x_chunk) {      // growing: nothing may still be reading the old buffers, on either stream
+        if (ctx->stream2) GNN_HIP(hipStreamSynchronize(ctx->stream2));
+        ctx->back_pending[0] = ctx->back_pending[1] = false;
+    }
     if (ws.chunk < chunk) {
         GNN_HIP(hipStreamSynchronize(ctx->stream));
         auto re = [&](auto*& p, size_t bytes) -> int {

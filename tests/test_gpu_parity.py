@@ -816,3 +816,20 @@ def test_asynchronous_classification_is_bit_identical(engine):
     finally:
         for buf in (bases, a, b):
             buf.free()
+
+
+def test_asynchronous_calls_survive_a_growing_workspace(synth_weights):
+    """A pending asynchronous back end must be finished before a later, larger call re-allocates the workspaces."""
+    from genomad_amd.engine import NNEngine
+    with NNEngine(0, synth_weights, chunk=2048) as eng:
+        n = 2048
+        bases, a, b = eng.alloc(n * 6000), eng.alloc(n * 12), eng.alloc(n * 12)
+        eng.synth_windows_dev(99, n, bases.ptr)
+        eng.classify_dev_async(bases.ptr, 256, b.ptr, "f16c6")               # small workspaces, back end left pending
+        eng.classify_dev_async(bases.ptr + 256 * 6000, n - 256, b.ptr + 256 * 12, "f16c6")   # grows them
+        eng.flush()
+        eng.sync()
+        got = b.download((n, 3), np.float32)
+        eng.classify_dev(bases.ptr, n, a.ptr, "f16c6")
+        eng.sync()
+        assert np.array_equal(got, a.download((n, 3), np.float32))
