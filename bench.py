@@ -278,6 +278,19 @@ def main():
     kid = _lib.K_F32_FRONT if args.precision == "f32" else _lib.K_FUSED
     front_ms, front_launches = eng.profile_get(kid)
     back_ms, _ = eng.profile_get(_lib.K_BACKEND)
+    eng.profile_enable(False)
+
+    # Untimed: every window of this rank once more through the synchronous entry point.  The timed steps used the
+    # asynchronous one (back ends deferred to a second stream across calls); they must have produced the same bits.
+    mine = scores.download((n_local, 3), np.float32)
+    for k in range(K):
+        eng.classify_dev(bases.ptr + k * wps_local * 6000, wps_local, scores.ptr + k * wps_local * 12, args.precision)
+    eng.sync()
+    again = scores.download((n_local, 3), np.float32)
+    mismatching = int(max_over_ranks(float(np.count_nonzero((mine != again).any(axis=1)))))
+    if mismatching:
+        print(f"bench.py: {mismatching} windows of a rank differ between the asynchronous steps and their synchronous "
+              f"re-run", file=sys.stderr)
 
     if rank == 0:
         out = {
@@ -337,6 +350,8 @@ def main():
             out["dscore_windows"] = int(m)
             out["dscore_reference"] = "tests/golden/config2_golden.npz: reference create_classifier() graph, float32"
             out["dscore_tolerance"] = 1e-4
+        out["steps_verified"] = {"windows_per_rank": int(n_local), "mismatching_windows_max_over_ranks": mismatching,
+                                 "against": "untimed re-run of every step through the synchronous gnn_classify_dev, bit for bit"}
         if world == 1 and args.cpu_sample > 0:
             base, cpu_scores = cpu_baseline(weights, args.cpu_sample)
             out["cpu_baseline"] = base

@@ -148,15 +148,26 @@ int flush_backend(gnn_ctx* ctx) {
     return GNN_OK;
 }
 
-// every entry point but gnn_classify_dev_async: what an earlier asynchronous classification left on the second stream is
-// ordered before anything this call enqueues on ctx->stream
+int finish_pending(gnn_ctx* ctx) {
+    if (ctx->back_pending[0] || ctx->back_pending[1]) {
+        GNN_HIP(hipStreamSynchronize(ctx->stream2));
+        ctx->back_pending[0] = ctx->back_pending[1] = false;
+    }
+    return GNN_OK;
+}
+
+// Every entry point but gnn_classify_dev_async: what an earlier asynchronous classification left on the second stream is
+// finished before this call does anything.  A host-side wait, not an event wait on ctx->stream: these entry points copy
+// between host and device, allocate and free, and read the workspaces - none of them is on a path where the few hundred
+// microseconds matter, and nothing they do can then depend on how a cross-stream dependency is resolved
+// (profiles/r02c6_async_flake.md).  Callers that never use the asynchronous entry point never have anything pending here.
 static int check_ctx(gnn_ctx* ctx, bool flush = true) {
     if (!ctx) {
         set_error("ctx is NULL");
         return GNN_ERR_ARG;
     }
     GNN_HIP(hipSetDevice(ctx->device));
-    return flush ? flush_backend(ctx) : GNN_OK;
+    return flush ? finish_pending(ctx) : GNN_OK;
 }
 
 // conv1 pair tables.  conv1 on the one-hot input is sum_k W1[k][tok[t-5+k]] (model.py:11 +

@@ -77,7 +77,7 @@ static int need_comm(gnn_ctx* ctx) {
         return GNN_ERR_STATE;
     }
     GNN_HIP(hipSetDevice(ctx->device));
-    return flush_backend(ctx);     // scores of an asynchronous classification are ordered before the collective
+    return finish_pending(ctx);     // scores of an asynchronous classification are ordered before the collective
 }
 
 // grow-only device staging buffer of the communicator

@@ -159,10 +159,12 @@ int launch_front_f32(gnn_ctx* ctx, const uint8_t* bases, int64_t n);         // 
 int launch_front_fused(gnn_ctx* ctx, const uint8_t* bases, int64_t n, int precision);  // -> ws.mp, ws.yp
 int launch_backend(gnn_ctx* ctx, int64_t n, int precision, float* scores_dev);   // ws.mp, ws.yp -> scores
 // one pass of the hot path over n windows whose padded bases are on the device (gnn_api.hip)
-// defer_last: leave the last chunk's back end pending on the second stream (gnn_classify_dev_async); flush_backend()
-// makes ctx->stream wait for whatever is pending - every entry point that enqueues on ctx->stream or reads scores calls it
+// defer_last: leave the last chunk's back end pending on the second stream (gnn_classify_dev_async).  flush_backend()
+// makes ctx->stream wait for whatever is pending (the end of a synchronous classify_chunks); finish_pending() waits for it on
+// the host - every other entry point that enqueues on ctx->stream, reads scores or touches the workspaces calls it first
 int classify_chunks(gnn_ctx* ctx, const uint8_t* bases_dev, int64_t n, int precision, float* scores_dev, bool defer_last = false);
 int flush_backend(gnn_ctx* ctx);
+int finish_pending(gnn_ctx* ctx);
 void free_contig_ws(gnn_ctx* ctx);     // gnn_contigs.hip
 
 int launch_front_c8(gnn_ctx* ctx, const uint8_t* bases, int64_t n);             // GNN_PREC_F16C8 -> ws.mp, ws.yp

@@ -79,7 +79,7 @@ template <typename Launch>
 static int run_f64(gnn_ctx* ctx, std::initializer_list<std::pair<const double*, size_t>> ins, int64_t n,
                    double* out_host, Launch launch) {
     GNN_HIP(hipSetDevice(ctx->device));
-    if (int frc = flush_backend(ctx)) return frc;
+    if (int frc = finish_pending(ctx)) return frc;
     std::vector<double*> dev;
     int rc = GNN_OK;
     auto fail = [&](hipError_t e, const char* what) {

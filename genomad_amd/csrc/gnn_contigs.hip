@@ -112,7 +112,7 @@ extern "C" int gnn_classify_contigs(gnn_ctx* ctx, const uint8_t* seq, int seq_on
     }
     GNN_HIP(hipSetDevice(ctx->device));
     {
-        const int frc = flush_backend(ctx);
+        const int frc = finish_pending(ctx);
         if (frc) return frc;
     }
     if (n_contigs < 0 || seq_bytes < 0 || !offsets_host || !n_windows_out || (n_contigs > 0 && !contig_scores_host) ||

@@ -55,7 +55,7 @@ extern "C" int gnn_mfma_probe(gnn_ctx* ctx, int ms_target, double* tflops_out) {
         return GNN_ERR_ARG;
     }
     GNN_HIP(hipSetDevice(ctx->device));
-    if (int frc = flush_backend(ctx)) return frc;
+    if (int frc = finish_pending(ctx)) return frc;
     const int blocks = ctx->cu_count > 0 ? ctx->cu_count : 256;
     std::vector<uint16_t> host(8 * 64 * 8);
     uint32_t x = 0x12345u;
