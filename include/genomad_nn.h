@@ -159,8 +159,9 @@ int gnn_classify(gnn_ctx* ctx, const uint8_t* bases_host, int64_t n_windows, int
 /* gnn_classify_dev_async: the same, but the back end (pair-product reduction, logits, attention sum, dense head) of the call's
  * last chunk may still be running on the library's second stream when the call returns, beside the front end of the NEXT
  * asynchronous call — for loops over batches that fit one launch.  scores_dev is complete once gnn_classify_flush (or any
- * other entry point of this ctx: gnn_sync, gnn_memcpy_d2h, gnn_comm_gather_dev, gnn_classify_dev ...) has been called and
- * the ctx stream has been synchronised; results are bit-identical to gnn_classify_dev. */
+ * other entry point of this ctx: gnn_sync, gnn_memcpy_d2h, gnn_comm_gather_dev, gnn_classify_dev ...) has been called — they
+ * wait on the host for what is pending on the second stream — and the ctx stream has been synchronised; results are
+ * bit-identical to gnn_classify_dev (bench.py checks every window of every run). */
 int gnn_classify_dev_async(gnn_ctx* ctx, const uint8_t* bases_dev, int64_t n_windows, int precision, float* scores_dev);
 int gnn_classify_flush(gnn_ctx* ctx);
 
