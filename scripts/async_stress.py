@@ -1,8 +1,7 @@
 """Stress of gnn_classify_dev_async beside synchronous entry points: many in-process repetitions of the mix the GPU test
 test_asynchronous_classification_is_bit_identical runs once, in variants that isolate what a mismatch depends on (tiny calls,
-a debug forward in between, how pending back ends are flushed).  Prints mismatch counts and where the rows differ.
+a debug forward in between).  Prints mismatch counts and where the rows differ.
 Usage: async_stress.py [iterations per variant] [variant ...]"""
-import os
 import sys
 import time
 
@@ -50,11 +49,7 @@ def ranges(idx):
     return out
 
 
-def run(cuts, middle, hostsync):
-    if hostsync:
-        os.environ["GNN_DBG_FLUSH_HOSTSYNC"] = "1"
-    else:
-        os.environ.pop("GNN_DBG_FLUSH_HOSTSYNC", None)
+def run(cuts, middle):
     bad_main, bad_mid, notes = 0, 0, []
     for it in range(iters):
         b.upload(nan)
@@ -89,18 +84,17 @@ def run(cuts, middle, hostsync):
 
 
 VARIANTS = {
-    "full": (TINY, "debug", False),
-    "no_middle": (TINY, None, False),
-    "sync4_middle": (TINY, "sync4", False),
-    "round_cuts_debug": (ROUND, "debug", False),
-    "round_cuts_no_middle": (ROUND, None, False),
-    "full_hostsync_flush": (TINY, "debug", True),
+    "full": (TINY, "debug"),
+    "no_middle": (TINY, None),
+    "sync4_middle": (TINY, "sync4"),
+    "round_cuts_debug": (ROUND, "debug"),
+    "round_cuts_no_middle": (ROUND, None),
 }
-for name, (cuts, middle, hostsync) in VARIANTS.items():
+for name, (cuts, middle) in VARIANTS.items():
     if only and name not in only:
         continue
     t = time.time()
-    bm, bd, notes = run(cuts, middle, hostsync)
+    bm, bd, notes = run(cuts, middle)
     print(f"{name}: {bm}/{iters} async mismatches, {bd} middle mismatches  ({time.time() - t:.1f} s)", flush=True)
     for s in notes[:6]:
         print("    " + s, flush=True)

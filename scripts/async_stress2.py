@@ -2,7 +2,6 @@
 0-10 ms between the asynchronous calls and the forward, two alternating window sets (so that a stale buffer shows up as the
 other set's scores), with and without a host copy of the bases.
 Usage: async_stress2.py [iterations]"""
-import os
 import sys
 import time
 
@@ -36,11 +35,7 @@ def describe(s, t, k):
     return f"rows {rows} (equal to the OTHER set's scores: {other}) taps {taps}"
 
 
-def run(name, use_async, mode, hostsync=False):
-    if hostsync:
-        os.environ["GNN_DBG_FLUSH_HOSTSYNC"] = "1"
-    else:
-        os.environ.pop("GNN_DBG_FLUSH_HOSTSYNC", None)
+def run(name, use_async, mode):
     bad = {d: 0 for d in DELAYS}
     bad_async = 0
     notes = []
@@ -79,4 +74,3 @@ def run(name, use_async, mode, hostsync=False):
 run("host forward alone", False, "host")
 run("host forward beside async", True, "host")
 run("device forward beside async", True, "dev")
-run("host forward beside async, host-sync flush", True, "host", True)
