@@ -167,11 +167,19 @@ def check_provirus_execution(outputs: Outputs, input_file) -> bool:   # utils.py
 
 def write_tsv(path, names, predictions):
     """nn_classification.py:344-348: '%.4f' columns joined by tabs, no trailing tab."""
+    p = np.asarray(predictions)
     with open(path, "w") as fout:
         fout.write(TSV_HEADER)
-        for name, scores in zip(names, predictions):
-            row = "".join(map(lambda x: f"{x:.4f}\t", scores)).strip()
-            fout.write(f"{name}\t{row}\n")
+        if p.ndim == 2 and p.shape[1] == 3:      # the module's only shape: one formatted write per 64 Ki contigs
+            cols = [p[:, j].tolist() for j in range(3)]        # exact float32 -> float conversions: the same digits
+            for lo in range(0, len(p), 1 << 16):
+                hi = lo + (1 << 16)
+                fout.write("".join(f"{n}\t{a:.4f}\t{b:.4f}\t{c:.4f}\n" for n, a, b, c in
+                                   zip(names[lo:hi], cols[0][lo:hi], cols[1][lo:hi], cols[2][lo:hi])))
+        else:
+            for name, scores in zip(names, p):
+                row = "\t".join(f"{x:.4f}" for x in scores)
+                fout.write(f"{name}\t{row}\n")
 
 
 def find_weights() -> Path:
