@@ -405,13 +405,13 @@ int gnn_create(int device, gnn_ctx** out) {
 int gnn_destroy(gnn_ctx* ctx) {
     if (!ctx) return GNN_OK;
     (void)hipSetDevice(ctx->device);
+    if (ctx->stream2) (void)hipStreamSynchronize(ctx->stream2);     // back ends an asynchronous call left pending
     (void)hipStreamSynchronize(ctx->stream);
     if (ctx->comm || ctx->comm_scratch) (void)gnn_comm_destroy(ctx);
     free_contig_ws(ctx);
     free_ws(ctx->ws);
     free_ws(ctx->ws_alt);
     if (ctx->stream2) {
-        (void)hipStreamSynchronize(ctx->stream2);
         for (int i = 0; i < 2; ++i) {
             if (ctx->ev_front[i]) (void)hipEventDestroy(ctx->ev_front[i]);
             if (ctx->ev_back[i]) (void)hipEventDestroy(ctx->ev_back[i]);
