@@ -4,10 +4,12 @@
     python bench.py [--gpus N] [--steps K] [--warmup W]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
-(torch.distributed.run is only the process launcher: RANK / LOCAL_RANK / WORLD_SIZE / MASTER_PORT are read
-from the environment.  Nothing here imports torch: device memory, streams and events come from the C ABI
-of libgenomad_nn_hip.so, the barrier / max-over-ranks / final gather are RCCL through its gnn_comm_* entry
-points — genomad_amd/rccl.py.)
+One process per GPU.  Under a launcher (torch.distributed.run is only that: RANK / LOCAL_RANK / WORLD_SIZE /
+MASTER_PORT are read from the environment) every process is one rank; a PLAIN `python bench.py --gpus N` with
+N > 1 spawns its N ranks itself (spawn_ranks) and rank 0's JSON line is the output.  Nothing here imports
+torch: device memory, streams and events come from the C ABI of libgenomad_nn_hip.so; the barrier, the
+max-over-ranks and the final gather are RCCL through its gnn_comm_* entry points (genomad_amd/rccl.py) — at
+N = 1 too: the communicator is always created, so the N = 1 line goes through the same ncclGather as N = 8.
 
 Workload (config.workload): synthetic 6 kbp windows (seed 1234) + synthetic weights (seed 42) of the
 reference shapes, resident in HBM before the timed region.  A "step" is one pass of the whole hot path
@@ -22,6 +24,10 @@ reference shapes, resident in HBM before the timed region.  A "step" is one pass
       gathered on rank 0.
 `value` = windows of all ranks / max-over-ranks wall time, barrier + stream sync on both sides, the gather
 and the copy of the scores to the host of rank 0 inside the timed region.
+
+After the timed region (untimed) every window of the job is classified once more with the exact-f32 device path and,
+bit for bit, through the synchronous entry point: `parity` reports max |dscore| over ALL timed windows, how many exceed
+1e-4 and 5e-5, and the process exits non-zero if any window exceeds the 1e-4 tolerance or any bit differs.
 
 Extra objects in the JSON line:
   roofline      dominant kernel (fused front end): algorithmic FLOP per launch / HIP-event duration measured
@@ -89,7 +95,55 @@ def cpu_baseline(weights, sample: int, batch: int = 128):
             np.concatenate(scores))
 
 
+def spawn_ranks(n: int, cmd, env=None) -> int:
+    """Run `cmd` as n local ranks (one per GPU) the way a launcher would: RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR /
+    MASTER_PORT in the environment, plus a private rendezvous directory and nonce for the RCCL unique id
+    (genomad_amd/rccl.py).  Rank 0 inherits stdout (its one JSON line is the output); the other ranks' stdout goes to
+    stderr.  Returns the first non-zero exit code (the remaining ranks are terminated by pid), else 0."""
+    import secrets
+    import shutil
+    import socket
+    import subprocess
+    import tempfile
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    rdzv = tempfile.mkdtemp(prefix="genomad_amd_bench_")          # 0700, ours
+    base = dict(os.environ if env is None else env)
+    base.update(WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), GENOMAD_AMD_RDZV_DIR=rdzv,
+                GENOMAD_AMD_RDZV_NONCE=secrets.token_hex(8), GENOMAD_AMD_RDZV_PARENT=str(os.getpid()))
+    base.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    procs = []
+    try:
+        for r in range(n):
+            e = dict(base, RANK=str(r), LOCAL_RANK=str(r))
+            procs.append(subprocess.Popen(list(cmd), env=e, stdout=None if r == 0 else sys.stderr))
+        rc, live = 0, set(range(n))
+        while live and rc == 0:
+            for r in sorted(live):
+                code = procs[r].poll()
+                if code is not None:
+                    live.discard(r)
+                    if code != 0:
+                        rc = code
+                        print(f"bench.py: rank {r} exited with {code}; stopping the other ranks", file=sys.stderr)
+                        break
+            time.sleep(0.05)
+        return rc
+    finally:
+        for p_ in procs:
+            if p_.poll() is None:
+                p_.terminate()
+        for p_ in procs:
+            try:
+                p_.wait(timeout=30)
+            except subprocess.TimeoutExpired:
+                p_.kill()
+        shutil.rmtree(rdzv, ignore_errors=True)
+
+
 def main():
+    from genomad_amd._lib import DEFAULT_PRECISION
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=64)
@@ -98,7 +152,15 @@ def main():
                     "or of every rank (weak)")
     ap.add_argument("--scaling", default="strong", choices=["strong", "weak"])
     ap.add_argument("--chunk", type=int, default=4096, help="windows per launch of the fused kernel")
-    ap.add_argument("--precision", default="f16c6", choices=["f16c6", "f16c8", "f16x3", "bf16x3", "bf16", "f32"])
+    ap.add_argument("--precision", default=DEFAULT_PRECISION, choices=["f16c6", "f16c8", "f16x3", "bf16x3", "bf16", "f32"],
+                    help=f"arithmetic of the fused front end (default {DEFAULT_PRECISION}: the fastest mode with margin inside the 1e-4 "
+                         "tolerance; f16c6 / f16c8 are faster and exceed it on a few of 10^6 windows)")
+    ap.add_argument("--async-steps", action="store_true",
+                    help="step with gnn_classify_dev_async (the last back end of a step beside the next step's front end) "
+                         "instead of the synchronous entry point")
+    ap.add_argument("--check", default="all", choices=["all", "golden", "none"],
+                    help="untimed parity pass: 'all' = every timed window against the exact-f32 device path (+ the golden "
+                         "file), 'golden' = only the committed reference-graph scores of the first 10 000 windows")
     ap.add_argument("--cpu-sample", type=int, default=1024, help="windows for the CPU baseline (0 = skip)")
     ap.add_argument("--kernel", default="classify", choices=["classify", "encoder"],
                     help="'encoder' benches the stand-alone byte->one-hot HBM kernel instead")
@@ -109,9 +171,12 @@ def main():
     ap.add_argument("--gbp-total", type=float, default=None, help="metagenome: Gbp of the whole job (default: "
                     "steps x gbp-per-step per GPU); BASELINE configs[4] is 60")
     ap.add_argument("--gbp-per-step", type=float, default=0.6, help="metagenome: Gbp resident in HBM per step and GPU")
-    ap.add_argument("--force-dist", action="store_true",
-                    help="create the RCCL communicator and run the barrier/gather path even with one rank")
+    ap.add_argument("--force-dist", action="store_true", help="(kept for old command lines: the communicator is always created now)")
     args = ap.parse_args()
+
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        # a plain process asked for N GPUs: become the launcher of N ranks of this same command line
+        sys.exit(spawn_ranks(args.gpus, [sys.executable, os.path.abspath(__file__)] + sys.argv[1:]))
 
     import numpy as np
     from genomad_amd import _lib, rccl, sharding, synthetic
@@ -119,26 +184,23 @@ def main():
 
     rccl.prepare_env()
     rank, world, local_rank = rccl.world_from_env()
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            sys.exit(f"--gpus {args.gpus} needs a launch with {args.gpus} ranks (python -m torch.distributed.run "
-                     f"--nproc-per-node {args.gpus} ...)")
-        args.gpus = world
+    args.gpus = world                    # under a launcher the launcher's world is the truth
 
     weights = synthetic.synth_weights()
     eng = NNEngine(local_rank, weights, chunk=args.chunk)
     info = eng.device_info()
-    use_dist = world > 1 or args.force_dist
-    comm = rccl.RcclComm(eng, rank, world) if use_dist else None
+    comm = rccl.RcclComm(eng, rank, world)          # always: the N = 1 line takes the same RCCL path as N = 8
+    rccl_ranks, rccl_rank = ctypes.c_int(), ctypes.c_int()
+    _lib.check(eng.lib.gnn_comm_info(eng.ctx, ctypes.byref(rccl_ranks), ctypes.byref(rccl_rank)))
+    assert rccl_ranks.value == world and rccl_rank.value == rank
 
     def barrier():
         eng.sync()
-        if comm is not None:
-            comm.barrier()
-            eng.sync()
+        comm.barrier()
+        eng.sync()
 
     def max_over_ranks(x: float) -> float:
-        return comm.allreduce_max(x) if comm is not None else x
+        return comm.allreduce_max(x)
 
     wps, K = args.windows_per_step, args.steps
 
@@ -211,7 +273,7 @@ def main():
         _, preds, _, total_windows = sharding.gather_contig_parts(comm, parts)
         barrier()
         dt = max_over_ranks(time.perf_counter() - t0)
-        tot = comm.allgather_i64([n_bp]).sum() if comm is not None else n_bp
+        tot = comm.allgather_i64([n_bp]).sum()
         if rank == 0:
             print(json.dumps({
                 "metric": "6 kbp windows classified/sec", "value": round(total_windows / dt, 1),
@@ -229,8 +291,7 @@ def main():
                                        f"5 kernels per {args.chunk}-window launch, launch overhead < 0.1 %, no hipGraph",
                            "precision": args.precision, "contigs": int(len(preds)),
                            "mean_contig_score": [round(float(x), 6) for x in preds.mean(axis=0)]}}))
-        if comm is not None:
-            comm.close()
+        comm.close()
         return
 
     # ---- windows workload (BASELINE configs[2]/[3])
@@ -247,15 +308,15 @@ def main():
     n_local = wps_local * K
     bases = eng.alloc(max(n_local * 6000, 1))
     scores = eng.alloc(max(n_local * 12, 1))
-    gathered_dev = eng.alloc(max(total * 12, 1)) if (comm is not None and rank == 0) else None
+    gathered_dev = eng.alloc(max(total * 12, 1)) if rank == 0 else None
     for k in range(K):
         eng.synth_windows_dev(first + k * wps_local, wps_local, bases.ptr + k * wps_local * 6000)
     eng.sync()
 
+    classify_step = eng.classify_dev_async if args.async_steps else eng.classify_dev
+
     def step(k):
-        # asynchronous form: the back end of this step's last launch runs beside the front end of the next step's first
-        # launch (all steps are one job; the gather / download below orders everything)
-        eng.classify_dev_async(bases.ptr + k * wps_local * 6000, wps_local, scores.ptr + k * wps_local * 12, args.precision)
+        classify_step(bases.ptr + k * wps_local * 6000, wps_local, scores.ptr + k * wps_local * 12, args.precision)
 
     for i in range(args.warmup):
         step(i % K)
@@ -266,31 +327,54 @@ def main():
     for k in range(K):
         step(k)
     eng.flush()
-    if comm is not None:          # ONE gather of every rank's (n_local, 3) f32 scores to rank 0 (ncclGather over xGMI)
-        comm.gather_dev(scores.ptr, gathered_dev.ptr if gathered_dev is not None else None, n_local * 12, 0)
+    eng.sync()
+    t_own = time.perf_counter() - t0             # this rank's own K steps (reported per rank; `value` uses the max below)
+    # ONE gather of every rank's (n_local, 3) f32 scores to rank 0 (ncclGather over xGMI; at N = 1 the same call) ...
+    comm.gather_dev(scores.ptr, gathered_dev.ptr if gathered_dev is not None else None, n_local * 12, 0)
     host_scores = None
     if rank == 0:                 # ... and on to the host of rank 0, still inside the timed region
-        host_scores = (gathered_dev if comm is not None else scores).download((total if comm is not None else n_local, 3),
-                                                                              np.float32)
+        host_scores = gathered_dev.download((total, 3), np.float32)
     barrier()
     dt = max_over_ranks(time.perf_counter() - t0)
+    own_us = comm.allgather_i64([int(t_own * 1e6)])[:, 0]
 
     kid = _lib.K_F32_FRONT if args.precision == "f32" else _lib.K_FUSED
     front_ms, front_launches = eng.profile_get(kid)
     back_ms, _ = eng.profile_get(_lib.K_BACKEND)
     eng.profile_enable(False)
 
-    # Untimed: every window of this rank once more through the synchronous entry point.  The timed steps used the
-    # asynchronous one (back ends deferred to a second stream across calls); they must have produced the same bits.
+    # ---- untimed checks of what was just timed, on every rank over ITS windows
     mine = scores.download((n_local, 3), np.float32)
+    # (1) bit for bit against a second run through the synchronous entry point
     for k in range(K):
         eng.classify_dev(bases.ptr + k * wps_local * 6000, wps_local, scores.ptr + k * wps_local * 12, args.precision)
     eng.sync()
     again = scores.download((n_local, 3), np.float32)
-    mismatching = int(max_over_ranks(float(np.count_nonzero((mine != again).any(axis=1)))))
+    mismatching = int(comm.allgather_i64([int(np.count_nonzero((mine != again).any(axis=1)))])[:, 0].sum())
+    # (2) every timed window against the exact-f32 device path (itself 4e-6 from the fp64 oracle and 1.1e-5 from the
+    #     reference-graph golden on config 2: tests/test_gpu_parity.py): max |dscore|, and how many windows pass 1e-4 / 5e-5
+    parity = None
+    if args.check == "all" and args.precision != "f32":
+        t_chk = time.perf_counter()
+        for k in range(K):
+            eng.classify_dev(bases.ptr + k * wps_local * 6000, wps_local, scores.ptr + k * wps_local * 12, "f32")
+        eng.sync()
+        exact = scores.download((n_local, 3), np.float32)
+        d = np.abs(mine - exact).max(axis=1) if n_local else np.zeros(0, np.float32)
+        finite = bool(np.isfinite(mine).all())
+        worst = float(d.max()) if len(d) else 0.0
+        cnt = comm.allgather_i64([int((d > 1e-4).sum()), int((d > 5e-5).sum()), int(not finite), int(n_local)]).sum(axis=0)
+        parity = {"max_abs_dscore_all": max_over_ranks(worst if np.isfinite(worst) else 1e9), "windows": int(cnt[3]),
+                  "over_1e-4": int(cnt[0]), "over_5e-5": int(cnt[1]), "non_finite_ranks": int(cnt[2]), "tolerance": 1e-4,
+                  "against": "exact-f32 device path (GNN_PREC_F32) on every timed window of every rank, untimed",
+                  "seconds": round(time.perf_counter() - t_chk, 1)}
+        parity["ok"] = parity["over_1e-4"] == 0 and parity["non_finite_ranks"] == 0 and parity["max_abs_dscore_all"] <= 1e-4
+    failed = []
     if mismatching:
-        print(f"bench.py: {mismatching} windows of a rank differ between the asynchronous steps and their synchronous "
-              f"re-run", file=sys.stderr)
+        failed.append(f"{mismatching} windows differ bit-wise between the timed steps and their synchronous re-run")
+    if parity is not None and not parity["ok"]:
+        failed.append(f"{parity['over_1e-4']} of {parity['windows']} timed windows exceed the 1e-4 score tolerance against the "
+                      f"exact-f32 path (max {parity['max_abs_dscore_all']:.3e})")
 
     if rank == 0:
         out = {
@@ -298,13 +382,16 @@ def main():
             "n_gpus": world, "steps": K, "warmup": args.warmup, "ms_per_step": round(dt / K * 1e3, 3),
             "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,
             "dtype": DTYPE_TEXT[args.precision], "data": "synthetic",
+            "rccl_ranks": int(rccl_ranks.value),
+            "per_rank_windows_per_s": [round(n_local / (u * 1e-6), 1) for u in own_us.tolist()],
             "config": {"workload": f"{total} synthetic 6 kbp windows ({K} steps x {wps}{' per GPU' if args.scaling == 'weak' else ''}), "
                                    f"{'sharded contiguously over' if args.scaling == 'strong' else 'on each of'} {world} GPU(s) "
                                    f"= {n_local} per GPU, synthetic weights of the reference shapes, HBM-resident input, "
-                                   f"scores gathered to rank 0 with one RCCL gather and copied to its host "
-                                   f"(BASELINE.json configs[2]/[3]); 5 kernels per {min(args.chunk, wps_local)}-window "
-                                   f"launch, launch overhead < 0.1 %, no hipGraph",
+                                   f"scores gathered to rank 0 with one ncclGather over {int(rccl_ranks.value)} RCCL rank(s) and "
+                                   f"copied to its host (BASELINE.json configs[2]/[3]); 5 kernels per "
+                                   f"{min(args.chunk, wps_local)}-window launch, launch overhead < 0.1 %, no hipGraph",
                        "precision": args.precision, "windows_per_launch": min(args.chunk, wps_local),
+                       "entry_point": "gnn_classify_dev_async" if args.async_steps else "gnn_classify_dev",
                        "device": info["name"].strip(), "cus": info["cus"]},
         }
         win_per_launch = n_local / max(front_launches, 1)
@@ -340,25 +427,34 @@ def main():
             out["roofline"]["issued_mfma_tflops_bf16_equivalent"] = round(tflops * passes, 1)
             out["roofline"]["mfma_probe_sustained_tflops"] = round(probe.value, 1)
             out["roofline"]["issued_vs_probe"] = round(tflops * passes / probe.value, 4)
-        # parity of what was just timed: the first windows of the job against the committed outputs of the
-        # reference's own graph (tests/golden/config2_golden.npz, windows 0..9999) — and the CPU baseline
+        # parity of what was just timed: every window against the exact-f32 device path (above), and the first windows of
+        # the job against the committed outputs of the reference's own graph (tests/golden/config2_golden.npz, windows 0..9999)
+        if parity is not None:
+            out["parity"] = parity
         gpath = os.path.join(ROOT, "tests", "golden", "config2_golden.npz")
-        if os.path.exists(gpath):
+        if os.path.exists(gpath) and args.check != "none":
             g = np.load(gpath)["scores_refgraph32"]
             m = min(len(g), len(host_scores) if args.scaling == "strong" or world == 1 else n_local)
             out["max_abs_dscore"] = float(np.abs(host_scores[:m] - g[:m]).max())
             out["dscore_windows"] = int(m)
             out["dscore_reference"] = "tests/golden/config2_golden.npz: reference create_classifier() graph, float32"
             out["dscore_tolerance"] = 1e-4
-        out["steps_verified"] = {"windows_per_rank": int(n_local), "mismatching_windows_max_over_ranks": mismatching,
+            if not out["max_abs_dscore"] <= 1e-4:
+                failed.append(f"max |dscore| {out['max_abs_dscore']:.3e} against the reference-graph golden exceeds 1e-4")
+        out["steps_verified"] = {"windows_all_ranks": int(total), "mismatching_windows_all_ranks": mismatching,
                                  "against": "untimed re-run of every step through the synchronous gnn_classify_dev, bit for bit"}
         if world == 1 and args.cpu_sample > 0:
             base, cpu_scores = cpu_baseline(weights, args.cpu_sample)
             out["cpu_baseline"] = base
             out["max_abs_dscore_vs_cpu_baseline"] = float(np.abs(host_scores[:args.cpu_sample] - cpu_scores).max())
-        print(json.dumps(out))
-    if comm is not None:
-        comm.close()
+        if failed:
+            out["failed"] = failed
+        print(json.dumps(out), flush=True)
+    comm.close()
+    if failed:
+        if rank == 0:
+            print("bench.py: FAILED: " + "; ".join(failed), file=sys.stderr)
+        sys.exit(3)
 
 
 if __name__ == "__main__":

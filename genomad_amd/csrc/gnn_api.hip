@@ -167,7 +167,10 @@ static int check_ctx(gnn_ctx* ctx, bool flush = true) {
         return GNN_ERR_ARG;
     }
     GNN_HIP(hipSetDevice(ctx->device));
-    return flush ? finish_pending(ctx) : GNN_OK;
+    if (!flush) return GNN_OK;
+    // GNN_ASYNC_EVENT_WAIT=1 (scripts/async_hunt.py only): the ordering round 2 first shipped, an event wait on ctx->stream
+    static const bool event_wait = std::getenv("GNN_ASYNC_EVENT_WAIT") != nullptr;
+    return event_wait ? flush_backend(ctx) : finish_pending(ctx);
 }
 
 // conv1 pair tables.  conv1 on the one-hot input is sum_k W1[k][tok[t-5+k]] (model.py:11 +
@@ -199,6 +202,77 @@ void build_conv1_pair_tables(const float* k1, std::vector<float>& pt) {
         // row 1537: both positions before the window start (causal zero padding) -> zeros
         for (int b = 0; b <= 256; ++b) add(row(j, 1538 + b), 2 * j + 1, b);   // only the first is absent
     }
+}
+
+// ---- persistent staging of the host-buffer entry points (gnn_classify, gnn_debug_forward)
+constexpr int64_t STAGE_MAX_WINDOWS = 32768;          // windows per slab: 197 MB of bases on the device at most
+constexpr size_t PIN_BYTES = (size_t)8 << 20;         // one bounce buffer
+
+void free_stage(gnn_ctx* ctx) {
+    if (ctx->stage_bases) (void)hipFree(ctx->stage_bases);
+    if (ctx->stage_scores) (void)hipFree(ctx->stage_scores);
+    if (ctx->stage_scores_host) (void)hipHostFree(ctx->stage_scores_host);
+    ctx->stage_bases = nullptr;
+    ctx->stage_scores = nullptr;
+    ctx->stage_scores_host = nullptr;
+    ctx->stage_windows = 0;
+    for (int i = 0; i < 2; ++i) {
+        if (ctx->pin[i]) (void)hipHostFree(ctx->pin[i]);
+        if (ctx->pin_ev[i]) (void)hipEventDestroy(ctx->pin_ev[i]);
+        ctx->pin[i] = nullptr;
+        ctx->pin_ev[i] = nullptr;
+        ctx->pin_busy[i] = false;
+    }
+}
+
+static int ensure_stage(gnn_ctx* ctx, int64_t windows) {
+    for (int i = 0; i < 2; ++i)
+        if (!ctx->pin[i]) {
+            GNN_HIP(hipHostMalloc(&ctx->pin[i], PIN_BYTES, hipHostMallocDefault));
+            GNN_HIP(hipEventCreateWithFlags(&ctx->pin_ev[i], hipEventDisableTiming));
+        }
+    if (ctx->stage_windows >= windows) return GNN_OK;
+    GNN_HIP(hipStreamSynchronize(ctx->stream));
+    const int64_t want = std::max<int64_t>(windows, std::min<int64_t>(2 * ctx->stage_windows, STAGE_MAX_WINDOWS));
+    if (ctx->stage_bases) (void)hipFree(ctx->stage_bases);
+    if (ctx->stage_scores) (void)hipFree(ctx->stage_scores);
+    if (ctx->stage_scores_host) (void)hipHostFree(ctx->stage_scores_host);
+    ctx->stage_bases = nullptr;
+    ctx->stage_scores = nullptr;
+    ctx->stage_scores_host = nullptr;
+    ctx->stage_windows = 0;
+    void *b = nullptr, *sc = nullptr, *sh = nullptr;
+    int rc = dev_buffer(ctx, (size_t)want * W, &b);
+    if (!rc) rc = dev_buffer(ctx, (size_t)want * GNN_CLASSES * sizeof(float), &sc);
+    if (!rc && hipHostMalloc(&sh, (size_t)want * GNN_CLASSES * sizeof(float), hipHostMallocDefault) != hipSuccess) {
+        set_error("hipHostMalloc of the score landing buffer failed");
+        rc = GNN_ERR_NOMEM;
+    }
+    if (rc) {
+        if (b) (void)hipFree(b);
+        if (sc) (void)hipFree(sc);
+        return rc;
+    }
+    ctx->stage_bases = static_cast<uint8_t*>(b);
+    ctx->stage_scores = static_cast<float*>(sc);
+    ctx->stage_scores_host = static_cast<float*>(sh);
+    ctx->stage_windows = want;
+    return GNN_OK;
+}
+
+// host windows -> the device slab, through the two bounce buffers (pageable source: the runtime would otherwise pin or
+// stage it anew on every call)
+static int stage_upload(gnn_ctx* ctx, const uint8_t* src, size_t bytes) {
+    int j = 0;
+    for (size_t off = 0; off < bytes; off += PIN_BYTES, j ^= 1) {
+        const size_t len = std::min(PIN_BYTES, bytes - off);
+        if (ctx->pin_busy[j]) GNN_HIP(hipEventSynchronize(ctx->pin_ev[j]));
+        std::memcpy(ctx->pin[j], src + off, len);
+        GNN_HIP(hipMemcpyAsync(ctx->stage_bases + off, ctx->pin[j], len, hipMemcpyHostToDevice, ctx->stream));
+        GNN_HIP(hipEventRecord(ctx->pin_ev[j], ctx->stream));
+        ctx->pin_busy[j] = true;
+    }
+    return GNN_OK;
 }
 
 // One pass of the hot path over n windows whose bases are on the device.
@@ -248,6 +322,19 @@ int classify_chunks(gnn_ctx* ctx, const uint8_t* bases_dev, int64_t n, int preci
         if (overlap && ctx->back_pending[buf]) {      // the back end that last used this workspace
             GNN_HIP(hipStreamWaitEvent(guard.main, ctx->ev_back[buf], 0));
             ctx->back_pending[buf] = false;
+        }
+        // GNN_DEBUG_POISON=1 (debug aid): every workspace tensor is filled with NaN bit patterns before the front end runs,
+        // so a kernel that reads something this launch has not written yet turns the scores into NaN instead of reading the
+        // previous launch's values (which are the right ones whenever the same windows are classified again)
+        static const bool poison = std::getenv("GNN_DEBUG_POISON") != nullptr;
+        if (poison) {
+            const Workspace& ws = ctx->ws;
+            GNN_HIP(hipMemsetAsync(ws.mp, 0xFF, (size_t)m * 2 * NPAIR * sizeof(float), guard.main));
+            GNN_HIP(hipMemsetAsync(ws.m, 0xFF, (size_t)m * 2 * NP * sizeof(float), guard.main));
+            GNN_HIP(hipMemsetAsync(ws.yp, 0xFF, (size_t)m * 2 * POOLED * C * sizeof(float), guard.main));
+            GNN_HIP(hipMemsetAsync(ws.logits, 0xFF, (size_t)m * 2 * POOLED * sizeof(float), guard.main));
+            GNN_HIP(hipMemsetAsync(ws.alpha, 0xFF, (size_t)m * 2 * POOLED * sizeof(float), guard.main));
+            GNN_HIP(hipMemsetAsync(ws.feat, 0xFF, (size_t)m * FEAT * sizeof(float), guard.main));
         }
         if (f32) {
             ProfScope ps(ctx, GNN_K_F32_FRONT);
@@ -409,6 +496,7 @@ int gnn_destroy(gnn_ctx* ctx) {
     (void)hipStreamSynchronize(ctx->stream);
     if (ctx->comm || ctx->comm_scratch) (void)gnn_comm_destroy(ctx);
     free_contig_ws(ctx);
+    free_stage(ctx);
     free_ws(ctx->ws);
     free_ws(ctx->ws_alt);
     if (ctx->stream2) {
@@ -704,15 +792,21 @@ int gnn_debug_forward(gnn_ctx* ctx, const uint8_t* bases_host, int64_t n, int pr
             return GNN_ERR_ARG;
         }
     }
-    void *b = nullptr, *s = nullptr;
-    if ((rc = dev_buffer(ctx, (size_t)n * W, &b))) return rc;
-    if ((rc = dev_buffer(ctx, (size_t)n * GNN_CLASSES * sizeof(float), &s))) {
-        (void)hipFree(b);
-        return rc;
+    // windows go up and scores come back through the ctx's persistent staging, a slab of at most STAGE_MAX_WINDOWS at a time
+    // (the reference calls predict() once per batch of 128 windows, nn_classification.py:316-317: nothing is allocated here)
+    const int64_t slab = std::min<int64_t>(n, STAGE_MAX_WINDOWS);
+    if ((rc = ensure_stage(ctx, slab))) return rc;
+    for (int64_t a0 = 0; a0 < n && !rc; a0 += slab) {
+        const int64_t m = std::min(slab, n - a0);
+        rc = stage_upload(ctx, bases_host + a0 * W, (size_t)m * W);
+        if (!rc) rc = classify_chunks(ctx, ctx->stage_bases, m, precision, ctx->stage_scores);
+        if (!rc) {
+            GNN_HIP(hipMemcpyAsync(ctx->stage_scores_host, ctx->stage_scores, (size_t)m * GNN_CLASSES * sizeof(float),
+                                   hipMemcpyDeviceToHost, ctx->stream));
+            GNN_HIP(hipStreamSynchronize(ctx->stream));
+            std::memcpy(scores_host + a0 * GNN_CLASSES, ctx->stage_scores_host, (size_t)m * GNN_CLASSES * sizeof(float));
+        }
     }
-    rc = gnn_memcpy_h2d(ctx, b, bases_host, (size_t)n * W);
-    if (!rc) rc = classify_chunks(ctx, (const uint8_t*)b, n, precision, (float*)s);
-    if (!rc) rc = gnn_memcpy_d2h(ctx, scores_host, s, (size_t)n * GNN_CLASSES * sizeof(float));
     if (!rc && taps) {
         const Workspace& ws = ctx->ws;
         auto out = [&](float* dst, const float* src, size_t count) {
@@ -737,8 +831,6 @@ int gnn_debug_forward(gnn_ctx* ctx, const uint8_t* bases_host, int64_t n, int pr
         out2(taps->alpha_a, taps->alpha_b, ws.alpha, (size_t)POOLED);
         out2(taps->m_a, taps->m_b, ws.m, (size_t)NP);
     }
-    (void)hipFree(b);
-    (void)hipFree(s);
     return rc;
 }
 

@@ -138,6 +138,16 @@ struct gnn_ctx {
     bool c6_pad_skip = true;                      // f16c6: copy the all-N tail of a window instead of computing it (gnn_debug_set_pad_skip)
     unsigned long long* phase_cycles = nullptr;   // non-null: fused kernel runs its instrumented build
     gnn::ContigWorkspace* contig_ws = nullptr;    // gnn_contigs.hip: persistent buffers of gnn_classify_contigs
+    // gnn_classify / gnn_debug_forward (host windows in, host scores out): persistent, grow-only staging - a device slab for
+    // the windows and their scores, two pinned bounce buffers the windows go through in pieces (the copy of piece i+1 into
+    // its bounce buffer overlaps the DMA of piece i) and a pinned landing buffer for the scores.  No allocation per call.
+    uint8_t* stage_bases = nullptr;
+    float* stage_scores = nullptr;
+    float* stage_scores_host = nullptr;
+    int64_t stage_windows = 0;
+    void* pin[2] = {nullptr, nullptr};
+    hipEvent_t pin_ev[2] = {nullptr, nullptr};
+    bool pin_busy[2] = {false, false};
     // RCCL communicator of this ctx (gnn_comm.hip); ncclComm_t kept opaque here
     void* comm = nullptr;
     int comm_ranks = 1, comm_rank = 0;
@@ -166,6 +176,7 @@ int classify_chunks(gnn_ctx* ctx, const uint8_t* bases_dev, int64_t n, int preci
 int flush_backend(gnn_ctx* ctx);
 int finish_pending(gnn_ctx* ctx);
 void free_contig_ws(gnn_ctx* ctx);     // gnn_contigs.hip
+void free_stage(gnn_ctx* ctx);         // gnn_api.hip: staging of the host-buffer entry points
 
 int launch_front_c8(gnn_ctx* ctx, const uint8_t* bases, int64_t n);             // GNN_PREC_F16C8 -> ws.mp, ws.yp
 int launch_front_c6(gnn_ctx* ctx, const uint8_t* bases, int64_t n);             // GNN_PREC_F16C6 -> ws.mp, ws.yp

@@ -50,7 +50,8 @@ constexpr int BUF6_ROWS = CARRY + FT6;
 constexpr int BUF6_BYTES = BUF6_ROWS * ROW6;
 constexpr int PROW_OFF = 2 * BUF6_BYTES;
 constexpr int PROW_N = FT6 + 4;              // pair rows a step's conv1 gather reads
-constexpr int BIAS_OFF = PROW_OFF + ((PROW_N * 2 + 15) / 16) * 16;   // conv2 | conv3 bias, 2 x 128 f32
+constexpr int PROW_BYTES = ((PROW_N * 2 + 15) / 16) * 16;
+constexpr int BIAS_OFF = PROW_OFF + 2 * PROW_BYTES;                   // two pair-row buffers (step parity), then conv2 | conv3 bias, 2 x 128 f32
 constexpr int LAST_OFF = BIAS_OFF + 2 * C * 4;                        // index of the window's last ACGT base
 constexpr int SMEM6 = LAST_OFF + 16;
 constexpr int WNBLK_B = 3584;                // weight bytes per (k32 step, n-block): f16 k16 even | f16 k16 odd | fp6 16-B parts | fp6 8-B parts
@@ -453,8 +454,10 @@ __device__ __forceinline__ void wv_pool_store(const f32x16 (&acc)[NMB], wrsrc_t 
 }
 
 // Pair row of the adjacent positions (t, t + 1) from the aligned 8 bytes that hold bases[t .. t+4] (sequence.py:170-193 in
-// closed form, gnn_fused_common.h).  The bytes of the step after next are requested one step early (prow_fetch) and
-// turned into the pair row at the top of the next step (prow_make): no memory round trip sits in front of the step.
+// closed form, gnn_fused_common.h).  The bytes are requested a step before they are turned into pair rows (prow_fetch ->
+// prow_make), and the pair rows of step s+2 are written between the barriers B3 and B4 of step s into the buffer of that
+// parity: a workgroup barrier always lies between a thread writing a pair row and the other waves' gathers reading it, and
+// no memory round trip sits in front of a step.
 __device__ __forceinline__ int prow_base(int t) { return min(max(t, 0) & ~3, W - 8); }
 __device__ __forceinline__ void prow_fetch(const uint8_t* __restrict__ bases, int t, uint32_t& lo, uint32_t& hi) {
     const uint32_t* src = reinterpret_cast<const uint32_t*>(bases + prow_base(t));   // windows start 4-byte aligned (checked at launch)
@@ -646,7 +649,7 @@ __global__ __launch_bounds__(512, 2) void fused_front_c6_kernel(Args a) {
     __shared__ __attribute__((aligned(16))) unsigned char smem[SMEM6];
     unsigned char* bufX = smem;
     unsigned char* bufY = smem + BUF6_BYTES;
-    uint16_t* prow = reinterpret_cast<uint16_t*>(smem + PROW_OFF);
+    auto prow2 = [&](int parity) { return reinterpret_cast<uint16_t*>(smem + PROW_OFF + parity * PROW_BYTES); };
     float* bias_s = reinterpret_cast<float*>(smem + BIAS_OFF);   // read at the head of every conv tile: LDS, not an L2 round trip
     int* s_last = reinterpret_cast<int*>(smem + LAST_OFF);
     const int tid = threadIdx.x;
@@ -679,11 +682,15 @@ __global__ __launch_bounds__(512, 2) void fused_front_c6_kernel(Args a) {
             if (base_code_f(bases[i]) >= 0) last = i;
         if (last >= 0) atomicMax(s_last, last);
     }
-    // pair rows of step 0: prow[i] = pair row of positions (t0 - 5 + i, t0 - 4 + i)
+    // pair rows of steps 0 and 1: prow2(s & 1)[i] = pair row of positions (t0 - 5 + i, t0 - 4 + i), t0 = s * FT6
     if (tid < PROW_N) {
-        uint32_t lo, hi;
-        prow_fetch(bases, tid - CARRY, lo, hi);
-        prow[tid] = prow_make(lo, hi, tid - CARRY);
+#pragma unroll
+        for (int s01 = 0; s01 < 2; ++s01) {
+            uint32_t lo, hi;
+            const int t = s01 * FT6 - CARRY + tid;
+            prow_fetch(bases, t, lo, hi);
+            prow2(s01)[tid] = prow_make(lo, hi, t);
+        }
     }
     __syncthreads();
     // steps [0, nsteps) contain a row t < p + 15 and are computed (at least one: an all-N window computes its first step)
@@ -750,24 +757,18 @@ __global__ __launch_bounds__(512, 2) void fused_front_c6_kernel(Args a) {
 #pragma unroll
             for (int k = 0; k < GROUNDS; ++k)
                 if (gua + 64 * k < FT6) {
-                    gather_issue(g, prow, a.conv1_k, gua + 64 * k, gpq);
+                    gather_issue(g, prow2(0), a.conv1_k, gua + 64 * k, gpq);
                     gather_finish(g, bufX, gua + 64 * k, gpq);
                 }
         }
-        uint32_t nlo = 0, nhi = 0;                       // bytes of this thread's pair row of the NEXT step
-        if (ht < PROW_N) prow_fetch(bases, FT6 - CARRY + ht, nlo, nhi);
+        uint32_t nlo = 0, nhi = 0;                       // bytes of this thread's pair row of the step AFTER next
+        if (ht < PROW_N) prow_fetch(bases, 2 * FT6 - CARRY + ht, nlo, nhi);
         __syncthreads();
         if constexpr (PROF) tick_ = __builtin_readcyclecounter();
 #pragma unroll 1
         for (int step = 0; step < nsteps; ++step) {
             const int t0 = step * FT6;
-            // pair rows of the next step (its gather runs behind B1; the previous gather finished before B4), from the
-            // bytes requested a step ago; then the request for the step after
-            if (ht < PROW_N) {
-                const int t = t0 + FT6 - CARRY + ht;
-                prow[ht] = prow_make(nlo, nhi, t);
-                prow_fetch(bases, t + FT6, nlo, nhi);
-            }
+            const uint16_t* prow = prow2((step + 1) & 1);                        // pair rows of the next step: written before B4 of the previous one
             GNN_TICK(10)
             {
                 const int sb = max(step - 1, 0);                                 // step 0: empty head-B range
@@ -820,6 +821,13 @@ __global__ __launch_bounds__(512, 2) void fused_front_c6_kernel(Args a) {
             __syncthreads();                                                     // ---- B3
             GNN_TICK(14)
             if (ht < CARRY * ROW_U4) *reinterpret_cast<uint4*>(bufY + cr * ROW6 + cc * 16) = carry;
+            // pair rows of step s+2 into the buffer step s's rows were in (last read before B1 of step s-1), from the bytes
+            // requested a step ago; then the request for the step after
+            if (ht < PROW_N) {
+                const int t = t0 + 2 * FT6 - CARRY + ht;
+                prow2(step & 1)[ht] = prow_make(nlo, nhi, t);
+                prow_fetch(bases, t + FT6, nlo, nhi);
+            }
 #if defined(GNN_C6_X1B_LATE) && !defined(GNN_ABL_NOHELP)
             gather_store(s1, bufX, gua + 64, gpq);                              // measurement variant: in the conv3 epilogue window
 #endif

@@ -120,7 +120,7 @@ class NNEngine:
             db.free()
             do.free()
 
-    def classify(self, bases, precision="f16c6") -> np.ndarray:
+    def classify(self, bases, precision=_lib.DEFAULT_PRECISION) -> np.ndarray:
         """(n,6000) uint8 windows -> (n,3) float32 class scores (chromosome, plasmid, virus)."""
         b = self._check_bases(bases)
         out = np.empty((len(b), _lib.CLASSES), dtype=np.float32)
@@ -128,12 +128,12 @@ class NNEngine:
                                     out.ctypes.data))
         return out
 
-    def classify_dev(self, bases_ptr: int, n: int, scores_ptr: int, precision="f16c6"):
+    def classify_dev(self, bases_ptr: int, n: int, scores_ptr: int, precision=_lib.DEFAULT_PRECISION):
         """Asynchronous: device pointers in and out, enqueued on the engine's stream."""
         check(self.lib.gnn_classify_dev(self.ctx, bases_ptr, int(n), _lib.PRECISIONS[precision],
                                         scores_ptr))
 
-    def classify_dev_async(self, bases_ptr: int, n: int, scores_ptr: int, precision="f16c6"):
+    def classify_dev_async(self, bases_ptr: int, n: int, scores_ptr: int, precision=_lib.DEFAULT_PRECISION):
         """classify_dev whose last back end may still run beside the next call's front end; call :meth:`flush`
         (or sync / download / a collective) before reading the scores."""
         check(self.lib.gnn_classify_dev_async(self.ctx, bases_ptr, int(n), _lib.PRECISIONS[precision], scores_ptr))
@@ -158,7 +158,7 @@ class NNEngine:
         return scores, arrays
 
     def classify_contigs(self, seq: np.ndarray, offsets: np.ndarray, single_window: bool = False,
-                         precision="f16c6"):
+                         precision=_lib.DEFAULT_PRECISION):
         """Contig front end: packed raw contig bytes -> per-contig scores.
 
         Does what generate_data + the predict loop + segment_mean do (nn_classification.py:54-82,
@@ -172,7 +172,7 @@ class NNEngine:
         return self._classify_contigs(seq.ctypes.data, 1, seq.nbytes, offsets, single_window, precision)
 
     def classify_contigs_dev(self, seq_ptr: int, offsets: np.ndarray, single_window: bool = False,
-                             precision="f16c6"):
+                             precision=_lib.DEFAULT_PRECISION):
         """Same as :meth:`classify_contigs` for a packed contig buffer that is already resident in
         HBM (``seq_ptr`` = device address of byte 0, ``offsets`` = (n_contigs+1,) byte offsets)."""
         offsets = np.ascontiguousarray(offsets, dtype=np.int64)
@@ -193,7 +193,7 @@ class NNEngine:
         return scores, ids[:n.value].copy()
 
     def classify_contigs_spans(self, seq_ptr: int, offsets: np.ndarray, single_window: bool = False,
-                               precision="f16c6"):
+                               precision=_lib.DEFAULT_PRECISION):
         """The same result assembled on the host from the span-level entry points (gnn_span_byte_count,
         gnn_classify_spans, gnn_segment_mean) — kept as an independently coded cross-check for the tests."""
         from . import sequence as S

@@ -33,11 +33,12 @@ from pathlib import Path
 import numpy as np
 
 from . import sequence
+from ._lib import DEFAULT_PRECISION
 
-# arithmetic of the fused front end: "f16c6" = f16 MFMA + MX-fp6 corrections (fastest inside the 1e-4 tolerance on BASELINE
-# config 2, no head-room: DESIGN.md section 2), "f16c8" = the same with fp8 corrections, "f16x3" = split-f16 three passes
-# (f32-class accuracy), "bf16x3" = split-bf16 three passes (f32 range), "f32" = exact f32 reference kernels
-DEFAULT_PRECISION = "f16c6"
+# arithmetic of the fused front end (GENOMAD_AMD_PRECISION overrides): "f16x3" = split-f16 three passes, f32-class accuracy -
+# the default, because the TSV prints four decimals and the 1e-4 tolerance has to hold with margin on inputs and weights
+# nobody has measured; "f16c6" / "f16c8" = f16 MFMA + MX-fp6 / fp8 corrections (1.55x / 1.3x faster, no head-room: DESIGN.md
+# section 2), "bf16x3" = split-bf16 three passes (f32 range), "f32" = exact f32 reference kernels
 MODULE_NAME = "nn_classification"   # utils.write_execution_info("nn_classification", ...) :207-212
 TSV_HEADER = "seq_name\tchromosome_score\tplasmid_score\tvirus_score\n"   # :345
 

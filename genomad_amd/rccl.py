@@ -4,13 +4,18 @@ entry points (genomad_amd/csrc/gnn_comm.hip, which dlopens librccl.so), called t
 One process per GPU, launched e.g. by ``python -m torch.distributed.run`` (only as a process launcher: RANK,
 LOCAL_RANK, WORLD_SIZE, MASTER_PORT are read from the environment; the launcher's own store is not used).
 Bootstrap of the communicator: rank 0 asks RCCL for a unique id (``ncclGetUniqueId``) and publishes its 128
-bytes in a file in the node-local temp directory; the other ranks read it; every rank then runs
-``ncclCommInitRank`` on its own device.  (One node, as the bench contract says; a shared directory can be
-named with GENOMAD_AMD_RDZV_DIR otherwise.)
+bytes, tagged with a hash of what identifies THIS launch and a timestamp, in a file of a per-user 0700
+directory under the node-local temp directory (created exclusively, renamed into place; a leftover of a
+crashed run is removed first and is never accepted by the readers: wrong tag or too old); the other ranks
+poll for it; every rank then runs ``ncclCommInitRank`` on its own device.  (One node, as the bench contract
+says; a shared directory can be named with GENOMAD_AMD_RDZV_DIR otherwise.)
 """
 import contextlib
 import ctypes as C
+import hashlib
 import os
+import stat
+import struct
 import sys
 import tempfile
 import time
@@ -22,6 +27,7 @@ from ._lib import check
 
 ID_BYTES = 128
 _SEQ = 0
+_PROCESS_START = time.time()
 
 
 def world_from_env():
@@ -45,14 +51,82 @@ def prepare_env():
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
 
+_MAGIC = b"GNNRCCL2"
+_STALE_S = 900.0          # a published id older than this can only be a leftover of another run
+
+
+def _run_tag(seq: int) -> bytes:
+    """16 bytes every rank of ONE launch derives identically and another launch does not: the launcher's port, run id,
+    restart count and pid (the ranks' common parent), an optional nonce the launcher exports (bench.py's own spawner does),
+    and the number of communicators this process has created so far."""
+    parts = (os.environ.get("MASTER_PORT", "0"), os.environ.get("TORCHELASTIC_RUN_ID", "none"),
+             os.environ.get("TORCHELASTIC_RESTART_COUNT", "0"), os.environ.get("GENOMAD_AMD_RDZV_NONCE", ""),
+             os.environ.get("GENOMAD_AMD_RDZV_PARENT", str(os.getppid())), seq)
+    return hashlib.sha256("|".join(str(x) for x in parts).encode()).digest()[:16]
+
+
+def _rdzv_dir() -> Path:
+    """Directory of the id file: GENOMAD_AMD_RDZV_DIR (a shared one for several nodes), else a per-user directory under the
+    temp dir, created 0700; a directory that is a symlink, is owned by someone else or is writable by others is refused
+    (a predictable name in a world-writable /tmp must not be squattable)."""
+    explicit = os.environ.get("GENOMAD_AMD_RDZV_DIR")
+    d = Path(explicit) if explicit else Path(tempfile.gettempdir()) / f"genomad_amd_rdzv_{os.getuid()}"
+    try:
+        os.mkdir(d, 0o700)
+    except FileExistsError:
+        pass
+    st = os.lstat(d)
+    if not stat.S_ISDIR(st.st_mode) or st.st_uid != os.getuid() or (not explicit and st.st_mode & 0o022):
+        raise PermissionError(f"refusing the RCCL rendezvous directory {d}: not a directory of this user / writable by others")
+    return d
+
+
 def _id_file(seq: int) -> Path:
     explicit = os.environ.get("GENOMAD_AMD_RDZV_FILE")
     if explicit:
         return Path(f"{explicit}.{seq}")
-    base = Path(os.environ.get("GENOMAD_AMD_RDZV_DIR", tempfile.gettempdir()))
-    tag = "_".join(str(x) for x in (os.environ.get("MASTER_PORT", "0"), os.environ.get("TORCHELASTIC_RUN_ID", "none"),
-                                    os.getppid(), seq))
-    return base / f"genomad_amd_rccl_{tag}.id"
+    return _rdzv_dir() / f"rccl_{_run_tag(seq).hex()}.id"
+
+
+def _publish_id(path: Path, tag: bytes, uid: bytes):
+    """rank 0: remove whatever a crashed run left under this name, then create the file exclusively (0600, no symlink
+    followed) under a temporary name and rename it into place: a reader sees either nothing or the whole record."""
+    record = _MAGIC + tag + bytes(uid) + struct.pack("<d", time.time())
+    try:
+        os.unlink(path)
+    except FileNotFoundError:
+        pass
+    tmp = path.with_name(path.name + f".tmp{os.getpid()}")
+    try:
+        os.unlink(tmp)
+    except FileNotFoundError:
+        pass
+    fd = os.open(tmp, os.O_WRONLY | os.O_CREAT | os.O_EXCL | getattr(os, "O_NOFOLLOW", 0), 0o600)
+    try:
+        os.write(fd, record)
+    finally:
+        os.close(fd)
+    os.replace(tmp, path)
+
+
+def _read_id(path: Path, tag: bytes, started: float):
+    """Another rank: the 128 id bytes once a COMPLETE record of THIS launch is there, else None.  A record with another
+    tag, or published long before this process started (a leftover rank 0 has not replaced yet), is not accepted."""
+    try:
+        fd = os.open(path, os.O_RDONLY | getattr(os, "O_NOFOLLOW", 0))
+    except OSError:
+        return None
+    try:
+        data = os.read(fd, 4096)
+    finally:
+        os.close(fd)
+    want = len(_MAGIC) + 16 + ID_BYTES + 8
+    if len(data) != want or data[:len(_MAGIC)] != _MAGIC or data[len(_MAGIC):len(_MAGIC) + 16] != tag:
+        return None
+    (published,) = struct.unpack("<d", data[-8:])
+    if published < started - _STALE_S:
+        return None
+    return data[len(_MAGIC) + 16:len(_MAGIC) + 16 + ID_BYTES]
 
 
 @contextlib.contextmanager
@@ -81,26 +155,28 @@ class RcclComm:
         global _SEQ
         self.engine, self.lib, self.ctx = engine, engine.lib, engine.ctx
         self.rank, self.world = int(rank), int(world)
-        path = _id_file(_SEQ)
+        path, tag = _id_file(_SEQ), _run_tag(_SEQ)
         _SEQ += 1
         uid = (C.c_uint8 * ID_BYTES)()
         if self.rank == 0:
             with _c_stdout_to_stderr():
                 check(self.lib.gnn_comm_unique_id(uid))
-            tmp = path.with_suffix(f".tmp{os.getpid()}")
-            tmp.write_bytes(bytes(uid))
-            os.replace(tmp, path)
+            if self.world > 1:
+                _publish_id(path, tag, bytes(uid))
         else:
             deadline = time.time() + timeout
-            while not (path.is_file() and path.stat().st_size == ID_BYTES):
+            while True:
+                got = _read_id(path, tag, _PROCESS_START)
+                if got is not None:
+                    break
                 if time.time() > deadline:
-                    raise TimeoutError(f"rank {self.rank}: no RCCL unique id at {path} after {timeout:.0f} s")
+                    raise TimeoutError(f"rank {self.rank}: no RCCL unique id of this launch at {path} after {timeout:.0f} s")
                 time.sleep(0.01)
-            C.memmove(uid, path.read_bytes(), ID_BYTES)
+            C.memmove(uid, got, ID_BYTES)
         with _c_stdout_to_stderr():
             check(self.lib.gnn_comm_init(self.ctx, self.world, self.rank, uid))
             self.barrier()
-        if self.rank == 0:
+        if self.rank == 0 and self.world > 1:
             try:
                 path.unlink()
             except OSError:

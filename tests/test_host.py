@@ -775,6 +775,28 @@ def test_rccl_unique_id_bootstrap_with_three_ranks(tmp_path):
     d = tmp_path / "rdzv"
     d.mkdir()
     (tmp_path / "side").mkdir()
+    # leftovers of a crashed run under the very name this launch will use: a bare 128-byte id (the round-2 format), then a
+    # well-formed record of ANOTHER launch (wrong tag) - the polling ranks must accept neither, rank 0 replaces the file
+    import struct
+    import time as _time
+    from genomad_amd import rccl
+    env = dict(MASTER_PORT="29999", GENOMAD_AMD_RDZV_DIR=str(d), TORCHELASTIC_RUN_ID="t1", GENOMAD_AMD_RDZV_PARENT=str(os.getpid()))
+    old = {k: os.environ.get(k) for k in env}
+    os.environ.update(env)
+    try:
+        stale = rccl._id_file(0)
+        tag = rccl._run_tag(0)
+    finally:
+        for k, v in old.items():
+            os.environ.pop(k, None) if v is None else os.environ.__setitem__(k, v)
+    assert stale.parent == d
+    stale.write_bytes(b"\x55" * 128)
+    assert rccl._read_id(stale, tag, _time.time()) is None
+    stale.write_bytes(rccl._MAGIC + bytes(16) + b"\x55" * 128 + struct.pack("<d", _time.time()))
+    assert rccl._read_id(stale, tag, _time.time()) is None
+    stale.write_bytes(rccl._MAGIC + tag + b"\x55" * 128 + struct.pack("<d", _time.time() - 86400))     # right tag, a day old
+    assert rccl._read_id(stale, tag, _time.time()) is None
+    stale.write_bytes(rccl._MAGIC + bytes(16) + b"\x55" * 128 + struct.pack("<d", _time.time()))
     procs = [ctx.Process(target=_rccl_bootstrap_worker, args=(r, 3, 29999, str(d), q)) for r in range(3)]
     for p in procs:
         p.start()
@@ -786,3 +808,69 @@ def test_rccl_unique_id_bootstrap_with_three_ranks(tmp_path):
     assert [g[1] for g in got] == [(3, r, want_id) for r in range(3)]
     assert all(g[2] >= 1 for g in got)
     assert got[0][3] == []                     # the id file is gone once everybody has joined
+
+
+# ------------------------------------------------------------------ bench.py as its own launcher
+from pathlib import Path  # noqa: E402
+
+_SPAWN_WORKER = '''
+import json, os, sys, time
+sys.path.insert(0, {root!r})
+from tests.test_host import _FakeCommLib
+from genomad_amd import rccl
+rank, world, local = rccl.world_from_env()
+box = {{"side": os.environ["SIDE"]}}
+eng = type("E", (), {{"lib": _FakeCommLib(box), "ctx": object()}})()
+comm = rccl.RcclComm(eng, rank, world, timeout=30)
+if os.environ.get("FAIL_RANK") == str(rank):
+    sys.exit(7)
+if os.environ.get("FAIL_RANK") is not None:
+    time.sleep(120)          # the launcher has to stop this rank when the failing one exits
+print(json.dumps({{"rank": rank, "world": world, "local": local, "id": box["init"][2].hex()[:8],
+                  "rdzv": os.environ["GENOMAD_AMD_RDZV_DIR"]}}), flush=True)
+'''
+
+
+def test_bench_spawns_its_own_ranks(tmp_path):
+    """`python bench.py --gpus N` from a plain process (no launcher environment) has to become N ranks itself: RANK /
+    LOCAL_RANK / WORLD_SIZE / MASTER_* exported, a private rendezvous directory for the RCCL unique id, rank 0's stdout =
+    the output, the first failing rank's exit code returned and the others stopped.  The ranks here bootstrap RcclComm over
+    the fake comm library above (no GPU)."""
+    import subprocess
+    import time
+    root = str(Path(__file__).resolve().parents[1])
+    worker = tmp_path / "worker.py"
+    worker.write_text(_SPAWN_WORKER.format(root=root))
+    (tmp_path / "side").mkdir()
+    launch = (f"import sys; sys.path.insert(0, {root!r}); import bench; "
+              f"sys.exit(bench.spawn_ranks(3, [sys.executable, {str(worker)!r}]))")
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT", "FAIL_RANK")}
+    env["SIDE"] = str(tmp_path / "side")
+    r = subprocess.run([sys.executable, "-c", launch], env=env, capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stderr
+    lines = [json.loads(x) for x in r.stdout.splitlines() if x.startswith("{")]
+    assert len(lines) == 1 and lines[0]["rank"] == 0 and lines[0]["world"] == 3      # only rank 0 owns stdout
+    others = sorted(json.loads(x)["rank"] for x in r.stderr.splitlines() if x.startswith("{"))
+    assert others == [1, 2]
+    assert not os.path.exists(lines[0]["rdzv"])                                      # the private directory is removed
+    # a failing rank: its exit code comes back, and quickly (the sleeping ranks are terminated, not waited for)
+    for f in (tmp_path / "side").iterdir():
+        f.unlink()
+    env["FAIL_RANK"] = "1"
+    t = time.time()
+    r = subprocess.run([sys.executable, "-c", launch], env=env, capture_output=True, text=True, timeout=120)
+    assert r.returncode == 7 and time.time() - t < 60, (r.returncode, r.stderr)
+
+
+def test_bench_cli_self_launch_reaches_the_ranks(tmp_path):
+    """The driver's form, `python bench.py --gpus 2 ...`, in a process without launcher variables: both ranks start and fail
+    where a box without GPUs must fail (creating the engine), i.e. after the spawn - not with the round-2 refusal."""
+    import subprocess
+    root = Path(__file__).resolve().parents[1]
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT")}
+    env["HIP_VISIBLE_DEVICES"] = ""            # no device, whatever the box has: the ranks stop at gnn_create
+    r = subprocess.run([sys.executable, str(root / "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0", "--cpu-sample", "0"],
+                       env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0
+    assert "needs a launch with" not in r.stderr
+    assert "rank" in r.stderr and "exited with" in r.stderr          # the launcher's report of the first failing rank
