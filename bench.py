@@ -172,6 +172,9 @@ def main():
                     "steps x gbp-per-step per GPU); BASELINE configs[4] is 60")
     ap.add_argument("--gbp-per-step", type=float, default=0.6, help="metagenome: Gbp resident in HBM per step and GPU")
     ap.add_argument("--force-dist", action="store_true", help="(kept for old command lines: the communicator is always created now)")
+    ap.add_argument("--share-devices", action="store_true",
+                    help="testing aid for boxes with fewer GPUs than ranks: rank r uses device r mod (visible devices), so the "
+                         "spawn and the RCCL bootstrap run as far as RCCL's own duplicate-device check")
     args = ap.parse_args()
 
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
@@ -187,6 +190,10 @@ def main():
     args.gpus = world                    # under a launcher the launcher's world is the truth
 
     weights = synthetic.synth_weights()
+    if args.share_devices:
+        n_dev = ctypes.c_int()
+        _lib.check(_lib.load().gnn_device_count(ctypes.byref(n_dev)))
+        local_rank %= max(n_dev.value, 1)
     eng = NNEngine(local_rank, weights, chunk=args.chunk)
     info = eng.device_info()
     comm = rccl.RcclComm(eng, rank, world)          # always: the N = 1 line takes the same RCCL path as N = 8

@@ -235,10 +235,10 @@ __device__ __forceinline__ void wv_pool(const unsigned char* __restrict__ xbuf, 
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
         const int mb = i >> 2, rg = i & 3;
-        const float v = fmaxf(fmaxf(acc[mb][rg * 4], acc[mb][rg * 4 + 1]), fmaxf(acc[mb][rg * 4 + 2], acc[mb][rg * 4 + 3]));
+        const float v = max_nan(max_nan(acc[mb][rg * 4], acc[mb][rg * 4 + 1]), max_nan(acc[mb][rg * 4 + 2], acc[mb][rg * 4 + 3]));
         const unsigned bits = __float_as_uint(v);
         const auto sw = __builtin_amdgcn_permlane32_swap(bits, bits, false, false);
-        m[i] = fmaxf(v, __uint_as_float(lane < 32 ? sw[1] : sw[0]));
+        m[i] = max_nan(v, __uint_as_float(lane < 32 ? sw[1] : sw[0]));
     }
     const int q0 = t0 / GNN_POOL;
     const int nq = min(16, POOLED - q0);              // pooled rows of this step that exist (q < 749)

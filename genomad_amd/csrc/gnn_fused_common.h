@@ -24,6 +24,12 @@ constexpr int FRAG_U4 = 64;                  // one fragment = 64 lanes x uint4
 // LeakyReLU(0.1) = max(v, 0.1 v) since the slope is < 1: two VALU ops instead of mul + compare + select
 __device__ __forceinline__ float lrelu_f(float v) { return fmaxf(v, v * LRELU); }
 
+// Maximum that PROPAGATES NaN (IEEE 754-2019 maximum; v_maximum3_f32 on gfx950), for the max-pool of y @ w_v: fmaxf returns
+// the other operand when one is NaN, which would let the pooling hide an overflow of the f16-operand arithmetic behind
+// finite scores; callers rely on non-finite scores to detect it (nn_classification.py: fallback to bf16x3).  Bit-identical
+// to fmaxf on everything else.
+__device__ __forceinline__ float max_nan(float a, float b) { return __builtin_elementwise_maximum(a, b); }
+
 __device__ __forceinline__ int base_code_f(uint32_t b) {
     return b == 65 ? 0 : (b == 67 ? 1 : (b == 71 ? 2 : (b == 84 ? 3 : -1)));
 }

@@ -257,10 +257,10 @@ def _natural(s):
     return [int(t) if t.isdigit() else t for t in re.split(r"(\d+)", s)]
 
 
-def assign(datasets: dict, keras_order=None) -> dict:
+def assign(datasets: dict, keras_order=None, return_paths=False):
     """Map {h5 path: array} to the repo's weight schema by leaf name + shape (see module docstring);
     ``keras_order`` (from :func:`read_keras_order`) switches on the cross-check against the order Keras'
-    own loader would follow."""
+    own loader would follow.  ``return_paths``: also return {schema key: h5 path} (the dry run prints it)."""
     items = []
     for path, arr in datasets.items():
         leaf = path.rsplit("/", 1)[-1].split(":")[0]
@@ -339,18 +339,62 @@ def assign(datasets: dict, keras_order=None) -> dict:
         missing = sorted(p for p in rank if p not in datasets)
         if missing:
             raise ValueError(f"weight_names lists datasets the file does not contain: {missing}")
-    return W.validate(out)
+    paths = {k: path_of[id(a)] for k, a in out.items()}
+    weights = W.validate(out)
+    return (weights, paths) if return_paths else weights
 
 
 def load_h5(path) -> dict:
     return assign(read_datasets(path), read_keras_order(path))
 
 
+def describe(h5_path) -> str:
+    """The dry run: which dataset of ``h5_path`` becomes which tensor of the schema, as a table.  Raises exactly what
+    :func:`convert` would raise (ValueError naming the missing / ambiguous / unplaced datasets)."""
+    datasets = read_datasets(h5_path)
+    order = read_keras_order(h5_path)
+    weights, paths = assign(datasets, order, return_paths=True)
+    lines = [f"{h5_path}: {len(datasets)} datasets; Keras layer_names / weight_names attributes "
+             f"{'found (' + str(len(order)) + ' weights): assignment cross-checked against the order Keras loads in' if order is not None else 'NOT found: name + shape matching only'}",
+             f"{'schema tensor':22s} {'shape':18s} {'dtype':8s} {'min':>11s} {'max':>11s}  <- h5 dataset"]
+    for key in sorted(weights, key=lambda k: (_natural(paths[k].rsplit('/', 1)[0]), k)):
+        a = np.asarray(weights[key])
+        lines.append(f"{key:22s} {str(tuple(a.shape)):18s} {str(a.dtype):8s} {float(a.min()):11.4g} {float(a.max()):11.4g}  <- {paths[key]}")
+    unused = sorted(set(datasets) - set(paths.values()))
+    lines.append(f"datasets not used (optimizer state etc.): {unused if unused else 'none'}")
+    return "\n".join(lines)
+
+
 def convert(h5_path, npz_path) -> None:
     W.save_npz(npz_path, load_h5(h5_path))
 
 
+def _main(argv=None) -> int:
+    """python -m genomad_amd.h5weights convert [--dry-run] nn_classifier.h5 [weights.npz]"""
+    import argparse
+    ap = argparse.ArgumentParser(prog="python -m genomad_amd.h5weights",
+                                 description="Convert the reference's trained weights (genomad/data/nn_classifier.h5, Keras legacy "
+                                             "HDF5) into the .npz schema nn_classification.main() loads (GENOMAD_AMD_WEIGHTS).")
+    sub = ap.add_subparsers(dest="cmd", required=True)
+    c = sub.add_parser("convert", help="write the schema .npz; --dry-run only prints the dataset -> tensor assignment")
+    c.add_argument("--dry-run", action="store_true")
+    c.add_argument("h5")
+    c.add_argument("npz", nargs="?")
+    args = ap.parse_args(argv)
+    try:
+        print(describe(args.h5))
+        if args.dry_run:
+            print("dry run: nothing written")
+            return 0
+        if not args.npz:
+            ap.error("convert needs the output .npz (or --dry-run)")
+        convert(args.h5, args.npz)
+        print(f"wrote {args.npz}")
+        return 0
+    except ValueError as e:      # the matching refused: say which rule, change nothing
+        print(f"genomad_amd.h5weights: {args.h5} does not look like the nn_classifier.h5 of model.py / igloo.py: {e}", file=__import__("sys").stderr)
+        return 2
+
+
 if __name__ == "__main__":
-    import sys
-    convert(sys.argv[1], sys.argv[2])
-    print(f"wrote {sys.argv[2]}")
+    raise SystemExit(_main())

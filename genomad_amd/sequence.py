@@ -270,20 +270,25 @@ def iter_text_chunks(path, chunk_bytes: int = 128 << 20):
     (a line beginning with '>'), so that every chunk can be packed on its own and the chunks tile the
     file.  A record longer than a chunk simply makes that chunk longer."""
     with _open_binary(path) as fin:
-        carry = b""
+        carry = []                       # blocks of a record that is longer than one read: joined ONCE, when it ends
         while True:
             block = fin.read(chunk_bytes)
             if not block:
                 break
-            data = carry + block if carry else block
-            cut = data.rfind(b"\n>")
-            if cut < 0:
-                carry = data
+            # the record start may straddle two reads ("\n" ends one block, ">" starts the next)
+            cut = block.rfind(b"\n>")
+            if cut < 0 and carry and carry[-1].endswith(b"\n") and block.startswith(b">"):
+                yield np.frombuffer(bytearray(b"".join(carry)), dtype=np.uint8)
+                carry = [block]
                 continue
-            yield np.frombuffer(bytearray(data[:cut + 1]), dtype=np.uint8)
-            carry = data[cut + 1:]
-        if carry:
-            yield np.frombuffer(bytearray(carry), dtype=np.uint8)
+            if cut < 0:
+                carry.append(block)
+                continue
+            carry.append(block[:cut + 1])
+            yield np.frombuffer(bytearray(b"".join(carry)), dtype=np.uint8)
+            carry = [block[cut + 1:]]
+        if carry and any(carry):
+            yield np.frombuffer(bytearray(b"".join(carry)), dtype=np.uint8)
 
 
 def pack_text(text: np.ndarray, strip_n: bool = True):

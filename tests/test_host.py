@@ -514,6 +514,33 @@ def test_keras_legacy_saver_layout_and_attribute_cross_check(synth_weights, tmp_
     assert all(np.array_equal(h5.load_h5(plain)[k], w[k]) for k in w)
 
 
+def test_h5weights_cli_dry_run_prints_the_assignment_and_names_the_failing_rule(synth_weights, tmp_path, capsys):
+    """`python -m genomad_amd.h5weights convert --dry-run nn_classifier.h5`: the one command the first person with the real
+    blob runs.  It prints dataset -> schema tensor for all 36 tensors (and whether Keras' own load order was available for
+    the cross-check), writes nothing; on a file that does not match it exits 2 with the rule that failed."""
+    h5 = pytest.importorskip("genomad_amd.h5weights")
+    try:
+        h5._h5()
+    except RuntimeError as exc:
+        pytest.skip(str(exc))
+    w = synth_weights
+    good = tmp_path / "nn_classifier.h5"
+    h5.write_keras_legacy(good, _keras_legacy_layers(w))
+    assert h5._main(["convert", "--dry-run", str(good)]) == 0
+    out = capsys.readouterr().out
+    assert "cross-checked against the order Keras loads in" in out and "dry run: nothing written" in out
+    assert "conv3_kernel" in out and "<- model/conv1d_2/kernel:0" in out and "<- model/igloo1d_kernel_1/w_qk:0" in out
+    assert sum(1 for line in out.splitlines() if " <- " in line and not line.startswith("schema tensor")) == len(w)
+    assert not list(tmp_path.glob("*.npz"))
+    assert h5._main(["convert", str(good), str(tmp_path / "w.npz")]) == 0 and (tmp_path / "w.npz").exists()
+    capsys.readouterr()
+    bad = tmp_path / "swapped.h5"
+    h5.write_keras_legacy(bad, _keras_legacy_layers(w, ":0", swap_convs=True))
+    assert h5._main(["convert", "--dry-run", str(bad)]) == 2
+    err = capsys.readouterr().err
+    assert "does not look like the nn_classifier.h5" in err and "disagrees with the order" in err
+
+
 def test_gen_patches_follows_the_reference_initializer():
     """synthetic.gen_patches restates gen_filters_igloo(4, 2100, 5997, return_sequences=False,
     build_backbone=False) (igloo.py:220-302, the initializer of `random_patches`, :106-115).  The reference
