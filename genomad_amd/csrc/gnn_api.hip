@@ -341,8 +341,14 @@ int classify_chunks(gnn_ctx* ctx, const uint8_t* bases_dev, int64_t n, int preci
             if ((rc = launch_front_f32(ctx, b, m))) return rc;
         } else {
             ProfScope ps(ctx, GNN_K_FUSED);
+            // the three-pass modes run the streaming kernel of gnn_fused_x3.hip; the round-1 kernel (gnn_fused.hip) keeps the
+            // single-pass bf16 mode, window buffers that are not 4-byte aligned, and GNN_X3_ROUND1=1 (A/B measurements)
+            static const bool x3_round1 = std::getenv("GNN_X3_ROUND1") != nullptr;
+            const bool x3 = (precision == GNN_PREC_F16X3 || precision == GNN_PREC_BF16X3) && !x3_round1 &&
+                            !(reinterpret_cast<uintptr_t>(b) & 3u);
             rc = precision == GNN_PREC_F16C6   ? launch_front_c6(ctx, b, m)
                  : precision == GNN_PREC_F16C8 ? launch_front_c8(ctx, b, m)
+                 : x3                          ? launch_front_x3(ctx, b, m, precision)
                                                : launch_front_fused(ctx, b, m, precision);
             if (rc) return rc;
         }
@@ -649,6 +655,7 @@ int gnn_load_weights(gnn_ctx* ctx, const gnn_weights* w) {
     if ((rc = pack_fused_weights(ctx, w))) return rc;
     if ((rc = pack_fused_c8_weights(ctx, w))) return rc;
     if ((rc = pack_fused_c6_weights(ctx, w))) return rc;
+    if ((rc = pack_fused_x3_consts(ctx))) return rc;
     ctx->has_weights = true;
     return GNN_OK;
 }

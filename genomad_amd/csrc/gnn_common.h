@@ -91,6 +91,8 @@ struct DeviceWeights {
     int32_t* bucket_ptr6[2] = {nullptr, nullptr};
     float* c6_yp_const = nullptr;   // (2, 749, 128) / (2, 8400): the f16c6 kernel's yp and mp of an all-N window (padding skip)
     float* c6_mp_const = nullptr;
+    float* x3_yp_const[2] = {nullptr, nullptr};   // the same of gnn_fused_x3.hip: [0] bf16 limbs, [1] f16 limbs
+    float* x3_mp_const[2] = {nullptr, nullptr};
 };
 
 struct Workspace {
@@ -180,6 +182,8 @@ void free_stage(gnn_ctx* ctx);         // gnn_api.hip: staging of the host-buffe
 
 int launch_front_c8(gnn_ctx* ctx, const uint8_t* bases, int64_t n);             // GNN_PREC_F16C8 -> ws.mp, ws.yp
 int launch_front_c6(gnn_ctx* ctx, const uint8_t* bases, int64_t n);             // GNN_PREC_F16C6 -> ws.mp, ws.yp
+int launch_front_x3(gnn_ctx* ctx, const uint8_t* bases, int64_t n, int precision);   // GNN_PREC_F16X3 / BF16X3 (gnn_fused_x3.hip) -> ws.mp, ws.yp
+int pack_fused_x3_consts(gnn_ctx* ctx);                                          // all-N window outputs of that kernel (after the other packs)
 
 // host-side packing for the fused paths (gnn_fused.hip, gnn_fused_c8.hip)
 int pack_fused_weights(gnn_ctx* ctx, const gnn_weights* w);

@@ -723,8 +723,9 @@ def test_second_weight_set_and_engine(synth_weights):
     assert not np.array_equal(got, np.zeros_like(got))
 
 
-def test_f16c6_padding_skip_is_bit_identical(engine):
-    """The f16c6 kernel copies the yp rows and pair products of a window's all-N tail from an all-N window instead of
+@pytest.mark.parametrize("prec", ["f16c6", "f16x3", "bf16x3"])
+def test_padding_skip_is_bit_identical(engine, prec):
+    """The streaming kernels (f16c6; f16x3 / bf16x3 of gnn_fused_x3.hip) copy the yp rows and pair products of a window's all-N tail from an all-N window instead of
     computing them (the padding of a contig's last window, nn_classification.py:72).  With the skip switched off the
     scores AND the intermediates must be the same bits: windows of every length class (empty, shorter than a step,
     ending exactly on / one base around a step boundary, N runs inside, IUPAC codes and lower case in the tail, full)."""
@@ -743,9 +744,9 @@ def test_f16c6_padding_skip_is_bit_identical(engine):
     taps = ("m_a", "m_b", "yp_a", "yp_b", "feat")
     try:
         _lib.check(engine.lib.gnn_debug_set_pad_skip(engine.ctx, 0))
-        full, tfull = engine.debug_forward(bases, "f16c6", taps=taps)
+        full, tfull = engine.debug_forward(bases, prec, taps=taps)
         _lib.check(engine.lib.gnn_debug_set_pad_skip(engine.ctx, 1))
-        skip, tskip = engine.debug_forward(bases, "f16c6", taps=taps)
+        skip, tskip = engine.debug_forward(bases, prec, taps=taps)
     finally:
         _lib.check(engine.lib.gnn_debug_set_pad_skip(engine.ctx, 1))
     assert np.isfinite(full).all()
@@ -775,6 +776,14 @@ def test_f16c6_rejects_a_misaligned_window_buffer(engine):
         got = out.download((2, 3), np.float32)
         want = engine.classify(host[:2 * 6000].reshape(2, 6000), "f16c8")
         assert np.array_equal(got, want)
+        # the three-pass modes take it too: the round-1 kernel (byte loads) serves such a buffer instead of the streaming
+        # one; same arithmetic, sums in another order -> equal within f32 rounding, far inside the tolerance
+        for prec in ("f16x3", "bf16x3"):
+            engine.classify_dev(buf.ptr + 1, 2, out.ptr, prec)
+            engine.sync()
+            got = out.download((2, 3), np.float32)
+            want = engine.classify(host[:2 * 6000].reshape(2, 6000), prec)
+            assert np.abs(got - want).max() <= 1e-5, prec
     finally:
         buf.free()
         out.free()
