@@ -312,9 +312,8 @@ struct PairCompute {
 // Barriers B1..B4 per step as in gnn_fused_c6.hip:
 //   matrix : w_v A(s), conv2 loop [bufX] | B1 | epilogue -> bufY (x2) | B2 | conv3 loop [bufY] | B3 |
 //            epilogue -> bufY (x3) | B4 | w_v B(s) [bufY]   -> straight into step s+1
-//   helpers: pair products B(s-1) [bufY] and A(s) [bufX], gather(s+1) table loads | B1 | x1 carry rows,
-//            first half of x1(s+1) -> bufX | B2 | second half of x1(s+1) -> bufX, read x2 carry | B3 | x2 carry rows -> bufY,
-//            pair rows of step s+2 | B4
+//   helpers: pair products B(s-1) [bufY] and A(s) [bufX], gather(s+1) table loads | B1 | x1 carry rows | B2 |
+//            x1(s+1) -> bufX (both halves), read x2 carry | B3 | x2 carry rows -> bufY, pair rows of step s+2 | B4
 template <bool F16, bool PROF>
 __global__ __launch_bounds__(512, 2) void fused_front_x3_kernel(Args a) {
     __shared__ __attribute__((aligned(16))) unsigned char smem[SMEMX];
@@ -389,7 +388,11 @@ __global__ __launch_bounds__(512, 2) void fused_front_x3_kernel(Args a) {
             wv_pool_store(acc, yp_w[0], t0, hw, lane);
             GNN_TICK(0)
             acc_init_bias(acc, bias_s, hw, lane);
+#ifndef GNN_ABL_NOCONV2
             gemm_tile<true, F16, KS, KS>(smem, 0, cw[0], cw[1], woff, ring, acc, lane);
+#else       // measurement only (wrong results): the launch without conv2's MFMAs - what a table-lookup conv2 would leave on the matrix pipe
+            prefetch_w(ring, cw[1], woff, lane);
+#endif
             GNN_TICK(1)
             __syncthreads();                                                     // ---- B1
             GNN_TICK(2)
@@ -452,7 +455,9 @@ __global__ __launch_bounds__(512, 2) void fused_front_x3_kernel(Args a) {
             __syncthreads();                                                     // ---- B1
             GNN_TICK(11)
             if (ht < CARRY * ROW_U4) *reinterpret_cast<uint4*>(bufX + cr * ROWX + cc * 16) = carry;
-#ifndef GNN_ABL_NOHELP
+#if !defined(GNN_ABL_NOHELP) && defined(GNN_X3_GATHER_EARLY)
+            // measurement variant (the f16c6 placement): first half converted between B1 and B2 - the matrix waves then wait
+            // at B2 for the table loads' latency (conv2 epilogue + B2: 3.9 k instead of 2 k cycles per step)
             gather_finish<F16>(g0, bufX, gua, gpq);
             GatherSum s1;
             gather_sum(s1, g1);
@@ -461,6 +466,14 @@ __global__ __launch_bounds__(512, 2) void fused_front_x3_kernel(Args a) {
             __syncthreads();                                                     // ---- B2
             GNN_TICK(13)
 #ifndef GNN_ABL_NOHELP
+            // both halves of x1(s+1) beside the conv3 loop: bufX is free from B1 on, the helpers have nothing else to do here
+            // (they waited 17 k cycles per step at B3), and this kernel's row conversion is light enough (two packed
+            // conversions per pair, no block maxima, no fp6 images) to run beside the MFMA stream
+#ifndef GNN_X3_GATHER_EARLY
+            gather_finish<F16>(g0, bufX, gua, gpq);
+            GatherSum s1;
+            gather_sum(s1, g1);
+#endif
             gather_store<F16>(s1, bufX, gua + 64, gpq);
 #endif
             if (ht < CARRY * ROW_U4) carry = *reinterpret_cast<const uint4*>(bufY + (FTX + cr) * ROWX + cc * 16);

@@ -3,6 +3,8 @@
 TEST INFRASTRUCTURE ONLY — see oracle/__init__.py.  Run in the build container (needs /root/reference):
 
     python -m oracle.make_golden_config2 [--n 10000] [--chunk 50] [--threads 4]
+    python -m oracle.make_golden_config2 --n 2048 --stride 512 --out tests/golden/config3_strided_golden.npz \
+        --scratch /tmp/config3_golden        # BASELINE config 3: every 512th of its 1 048 576 windows
 
 For synthetic windows 0 … n-1 (seed 1234) and the seed-42 synthetic weights it stores
 
@@ -30,6 +32,8 @@ def main():
     ap.add_argument("--n", type=int, default=10000)
     ap.add_argument("--chunk", type=int, default=50)
     ap.add_argument("--threads", type=int, default=4)
+    ap.add_argument("--stride", type=int, default=1, help="window j of the fixture is synthetic window first + j * stride")
+    ap.add_argument("--first", type=int, default=0)
     ap.add_argument("--scratch", default="/tmp/config2_golden")
     ap.add_argument("--out", default=os.path.join(ROOT, "tests", "golden", "config2_golden.npz"))
     args = ap.parse_args()
@@ -49,7 +53,10 @@ def main():
             with np.load(path) as z:
                 r32.append(z["r32"]), o64.append(z["o64"])
             continue
-        bases = synthetic.synth_windows(a, b - a)
+        if args.stride == 1:
+            bases = synthetic.synth_windows(args.first + a, b - a)
+        else:
+            bases = np.concatenate([synthetic.synth_windows(args.first + j * args.stride, 1) for j in range(a, b)])
         tokens = sequence_oracle.tokenize_closed_form(bases)
         ref = reference_harness.reference_classifier_scores(tokens, W, np.float32).astype(np.float32)
         orc = igloo_oracle.forward(tokens, W, dtype=np.float64, literal=False)
@@ -61,6 +68,7 @@ def main():
     r32, o64 = np.concatenate(r32), np.concatenate(o64)
     np.savez_compressed(
         args.out, scores_refgraph32=r32, scores_oracle64=o64, n=np.array(args.n),
+        indices=args.first + np.arange(args.n, dtype=np.int64) * args.stride,
         data_seed=np.array(synthetic.DATA_SEED if hasattr(synthetic, "DATA_SEED") else 1234),
         weights_sha256=np.array(hashlib.sha256(b"".join(W[k].tobytes() for k in sorted(W))).hexdigest()))
     print("wrote", args.out, r32.shape, "max|ref32-oracle64| = %.3e" % np.abs(r32 - o64).max())

@@ -16,7 +16,7 @@ arm() {   # name, env assignments...
   if [ -n "$ONLY" ] && [ "$ONLY" != auto ] && ! grep -qw "$name" <<<"$ONLY"; then return; fi
   local fail=0 t0=$(date +%s)
   for i in $(seq 1 "$N"); do
-    out=$(env "$@" timeout 120 python scripts/async_hunt.py 2 2>&1 | tail -1)
+    out=$(env "$@" timeout 120 python scripts/async_hunt.py 2 ${HUNT_PREC:-f16c6} 2>&1 | tail -1)
     if [[ "$out" != OK* ]]; then
       fail=$((fail + 1))
       [ "$fail" -le 4 ] && echo "  [$name #$i] ${out:0:1500}"
@@ -28,6 +28,7 @@ arm() {   # name, env assignments...
 arm old_order        GNN_ASYNC_EVENT_WAIT=1 GENOMAD_AMD_LIB=build_variants/lib_prowold.so
 arm old_order_newk   GNN_ASYNC_EVENT_WAIT=1
 arm default          GNN_DUMMY=0
+HUNT_PREC=f16x3 arm default_f16x3 GNN_DUMMY=0          # the default arithmetic: the streaming kernel of gnn_fused_x3.hip
 if [ "$ONLY" = auto ] && [ "$TOTAL_FAIL" -eq 0 ]; then echo "auto: nothing failed on this box, bisecting settings skipped"; exit 0; fi
 arm new_order_oldk   GENOMAD_AMD_LIB=build_variants/lib_prowold.so
 arm poison           GNN_DEBUG_POISON=1

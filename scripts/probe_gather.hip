@@ -7,6 +7,7 @@
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdlib>
+#include <string>
 #include <vector>
 
 template <int ROW_BYTES>
@@ -56,7 +57,35 @@ static void run(const char* name, int positions) {
     hipFree(table); hipFree(idx); hipFree(out);
 }
 
-int main() {
+// probe_gather loop <seconds>: the f32-row gather back to back for about that long (to run BESIDE another process's kernels),
+// one line per second with the rate sustained
+static void loop_f32(double seconds) {
+    constexpr int ROW_BYTES = 512;
+    const int positions = 4096 * 5997 / 4;
+    const size_t table_bytes = (size_t)6 * 262144 * ROW_BYTES;
+    uint4* table; uint32_t* idx; uint4* out;
+    hipMalloc(&table, table_bytes); hipMalloc(&idx, (size_t)(positions + 8) * 4); hipMalloc(&out, (size_t)65536 * ROW_BYTES);
+    hipMemset(table, 0, table_bytes);
+    std::vector<uint32_t> h(positions + 8);
+    uint32_t code = 12345u; uint64_t s = 88172645463325252ull;
+    for (auto& v : h) { s ^= s << 13; s ^= s >> 7; s ^= s << 17; code = ((code << 2) | (uint32_t)(s & 3)) & 262143u; v = code; }
+    hipMemcpy(idx, h.data(), h.size() * 4, hipMemcpyHostToDevice);
+    hipEvent_t a, b; hipEventCreate(&a); hipEventCreate(&b);
+    double total = 0;
+    while (total < seconds) {
+        hipEventRecord(a);
+        int n = 0;
+        for (; n < 100; ++n) hipLaunchKernelGGL(gather_kernel<ROW_BYTES>, dim3(256 * 8), dim3(256), 0, 0, table, idx, positions, out);
+        hipEventRecord(b); hipEventSynchronize(b);
+        float ms; hipEventElapsedTime(&ms, a, b);
+        total += ms * 1e-3;
+        printf("gather beside: %.2f TB/s (%.3f ms per quarter launch)\n", (double)positions * 6 * ROW_BYTES * n / (ms * 1e-3) / 1e12, ms / n);
+        fflush(stdout);
+    }
+}
+
+int main(int argc, char** argv) {
+    if (argc > 2 && std::string(argv[1]) == "loop") { loop_f32(atof(argv[2])); return 0; }
     const int positions = 4096 * 5997 / 4;               // a quarter of a 4096-window launch
     run<512>("f32 rows (805 MB)", positions);
     run<384>("f16 hi + fp8 lo rows (604 MB)", positions);

@@ -480,24 +480,40 @@ def test_config2_10k_windows_vs_reference_graph_golden(engine, golden_dir):
     print("config 2 max |dscore| (vs reference graph f32, vs fp64 oracle):", worst)
 
 
-def test_config3_1m_windows_sharding_and_determinism(engine):
-    """BASELINE configs 3/4 (1 M windows): size-independent properties — run-to-run bit identity, and
-    8 contiguous shards (what 8 ranks compute) concatenated == one pass, bit for bit."""
+def test_config3_1m_windows_sharding_determinism_and_accuracy(engine, golden_dir):
+    """BASELINE configs 3/4 (1 M windows) with the DEFAULT arithmetic (the one bench.py times): size-independent
+    properties — run-to-run bit identity, and 8 contiguous shards (what 8 ranks compute) concatenated == one pass, bit for
+    bit — and accuracy where it can be pinned at this size: every 512th window of the 1 048 576 against the outputs of the
+    REFERENCE'S OWN graph for exactly those windows (tests/golden/config3_strided_golden.npz, oracle/make_golden_config2.py
+    --stride 512) within HALF the tolerance, and a 16 384-window strided sample against the exact-f32 device path."""
+    from genomad_amd._lib import DEFAULT_PRECISION as prec
     n = 1 << 20
-    one = _classify_resident(engine, 0, n, "f16c8")
-    again = _classify_resident(engine, 0, n, "f16c8")
+    one = _classify_resident(engine, 0, n, prec)
+    again = _classify_resident(engine, 0, n, prec)
     assert hashlib.sha256(one.tobytes()).hexdigest() == hashlib.sha256(again.tobytes()).hexdigest()
-    sharded = _classify_resident(engine, 0, n, "f16c8", shards=8)
+    sharded = _classify_resident(engine, 0, n, prec, shards=8)
     assert np.array_equal(one, sharded)
     assert np.isfinite(one).all() and np.abs(one.sum(1) - 1.0).max() < 1e-5
     # the counter-based generator makes any slice addressable: windows 777000.. must score the same
     # when classified on their own
-    sub = _classify_resident(engine, 777_000, 512, "f16c8")
+    sub = _classify_resident(engine, 777_000, 512, prec)
     assert np.array_equal(one[777_000:777_512], sub)
-    # the other fused arithmetic agrees on a sample spread over the whole range
-    idx = np.arange(0, n, 4099)[:256]
-    other = np.concatenate([_classify_resident(engine, int(i), 1, "bf16x3") for i in idx[:32]])
-    assert np.abs(other - one[idx[:32]]).max() <= SCORE_TOL
+    # accuracy over the whole range, not just its first 10 000 windows
+    g = np.load(os.path.join(golden_dir, "config3_strided_golden.npz"))
+    idx = g["indices"]
+    assert idx.max() < n and len(idx) >= 1024
+    e32 = float(np.abs(one[idx] - g["scores_refgraph32"]).max())
+    e64 = float(np.abs(one[idx] - g["scores_oracle64"]).max())
+    print(f"config 3, {len(idx)} windows strided over 2^20, {prec}: max |dscore| vs reference graph {e32:.3e}, vs fp64 oracle {e64:.3e}")
+    assert e32 <= SCORE_TOL / 2 and e64 <= SCORE_TOL / 2
+    sample = np.arange(0, n, 64)
+    exact = np.concatenate([_classify_resident(engine, int(a), 1, "f32") for a in sample[:512]])
+    assert np.abs(one[sample[:512]] - exact).max() <= SCORE_TOL / 2
+    # the opt-in fast modes on the same strided windows: inside the tolerance here or not, they must stay in its neighbourhood
+    # (1.2e-4 was seen on 10^6 windows, DESIGN.md section 2) - a regression to 1e-3 class errors fails
+    for fast in ("f16c6", "f16c8"):
+        got = np.concatenate([_classify_resident(engine, int(a), 1, fast) for a in idx[:256]])
+        assert np.abs(got - g["scores_refgraph32"][:256]).max() <= 2 * SCORE_TOL, fast
 
 
 # ------------------------------------------------------------------ contig front end (SURVEY §8f rank 1)
@@ -700,9 +716,32 @@ def test_downstream_consumers_match_the_reference_functions(engine, golden_dir, 
     assert consumers.branch_attention(engine, np.zeros(0), np.zeros((0, 3)), np.zeros((0, 3))).shape == (0, 3)
 
 
+def _calibrated_weights(seed, n_cal=64):
+    """synthetic.synth_weights(seed) with the output bias re-centred for THAT seed: the constant of synth_weights is tuned
+    for seed 42, other seeds saturate one class (score std 0: a vacuous test).  The mean logits over a few windows come from
+    the device's exact-f32 features (debug tap) and the dense head in numpy."""
+    from genomad_amd.engine import NNEngine
+    w = synthetic.synth_weights(seed=seed)
+    bases = synthetic.synth_windows(100_000, n_cal)
+    with NNEngine(0, w) as e:
+        _, t = e.debug_forward(bases, "f32", taps=("feat",))
+    f = t["feat"].astype(np.float64)
+
+    def bn(x, p):
+        return w[f"{p}_bn_gamma"] * (x - w[f"{p}_bn_mean"]) / np.sqrt(w[f"{p}_bn_var"] + 1e-3) + w[f"{p}_bn_beta"]
+    h1 = np.maximum(bn(f @ w["enc_dense_kernel"] + w["enc_dense_bias"], "enc"), 0)
+    h2 = np.maximum(bn(h1 @ w["head_dense_kernel"] + w["head_dense_bias"], "head"), 0)
+    logits = h2 @ w["out_dense_kernel"]
+    w["out_dense_bias"] = (-logits.mean(axis=0)).astype(np.float32)
+    return w
+
+
 def test_second_weight_set_and_engine(synth_weights):
     """Nothing is specialised to the seed-42 weights: a second engine with other weights (other patch
-    positions -> other step buckets, larger conv gains) still matches the oracle; two engines coexist."""
+    positions -> other step buckets, larger conv gains) still matches the oracle; two engines coexist.  And a third,
+    NON-DEGENERATE weight set (seed 43, output bias calibrated so that all three class scores vary): the default arithmetic
+    holds the tolerance with margin on 4096 windows, the opt-in fast modes stay in its neighbourhood."""
+    from genomad_amd._lib import DEFAULT_PRECISION
     from genomad_amd.engine import NNEngine
     w2 = synthetic.synth_weights(seed=7)
     w2["conv2_kernel"] = w2["conv2_kernel"] * 1.5          # different dynamic range
@@ -714,13 +753,25 @@ def test_second_weight_set_and_engine(synth_weights):
     with NNEngine(0, w2) as e2:
         got = e2.classify(bases, "bf16x3")
         got8 = e2.classify(bases, "f16c8")
+        got6 = e2.classify(bases, "f16c6")
         got16 = e2.classify(bases, "f16x3")
         exact = e2.classify(bases, "f32")
     assert np.abs(exact - want).max() <= 2e-5
     assert np.abs(got16 - want).max() <= 2e-5
     assert np.abs(got - want).max() <= SCORE_TOL
     assert np.abs(got8 - want).max() <= SCORE_TOL
+    assert np.abs(got6 - want).max() <= SCORE_TOL
     assert not np.array_equal(got, np.zeros_like(got))
+    w3 = _calibrated_weights(43)
+    big = synthetic.synth_windows(200_000, 4096)
+    with NNEngine(0, w3) as e3:
+        exact = e3.classify(big, "f32")
+        assert exact.std(axis=0).min() > 0.05, exact.std(axis=0)          # every class score varies: the check is not vacuous
+        err = {prec: float(np.abs(e3.classify(big, prec) - exact).max()) for prec in ("f16x3", "bf16x3", "f16c8", "f16c6")}
+    print("seed-43 weights (calibrated), 4096 windows, max |dscore| vs the exact-f32 path:", err)
+    assert DEFAULT_PRECISION == "f16x3" and err["f16x3"] <= SCORE_TOL / 4
+    assert err["bf16x3"] <= SCORE_TOL
+    assert err["f16c8"] <= 2 * SCORE_TOL and err["f16c6"] <= 2 * SCORE_TOL
 
 
 @pytest.mark.parametrize("prec", ["f16c6", "f16x3", "bf16x3"])
@@ -857,3 +908,27 @@ def test_asynchronous_calls_survive_a_growing_workspace(synth_weights):
         eng.classify_dev(bases.ptr, n, a.ptr, "f16c6")
         eng.sync()
         assert np.array_equal(got, a.download((n, 3), np.float32))
+
+
+def test_bench_command_line_prints_one_complete_json_line(tmp_path):
+    """The driver's command, at a size that takes seconds: `python bench.py --gpus 1 --steps K --warmup W` prints exactly one
+    JSON line on stdout with the contract's fields, goes through RCCL at N = 1 (rccl_ranks), checks EVERY timed window against
+    the exact-f32 path (parity.ok) and every step bit for bit against the synchronous entry point, and exits 0; the fast opt-in
+    arithmetic is allowed to fail that check but must then say so and exit non-zero, never print a clean line."""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "1", "--steps", "3", "--warmup", "1",
+           "--windows-per-step", "2048", "--cpu-sample", "0"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [x for x in r.stdout.splitlines() if x.strip()]
+    assert len(lines) == 1, r.stdout
+    d = json.loads(lines[0])
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+                "dtype", "data", "config", "roofline", "rccl_ranks", "parity", "steps_verified"):
+        assert key in d, key
+    assert d["n_gpus"] == 1 and d["rccl_ranks"] == 1 and d["steps"] == 3 and d["config"]["precision"] == "f16x3"
+    assert d["parity"]["ok"] and d["parity"]["windows"] == 3 * 2048 and d["parity"]["max_abs_dscore_all"] <= SCORE_TOL / 2
+    assert d["steps_verified"]["mismatching_windows_all_ranks"] == 0
+    assert d["roofline"]["bound"] == "mfma" and 0 < d["roofline"]["frac"] < 1 / 3
+    assert d["value"] > 50_000
