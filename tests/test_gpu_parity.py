@@ -932,3 +932,22 @@ def test_bench_command_line_prints_one_complete_json_line(tmp_path):
     assert d["steps_verified"]["mismatching_windows_all_ranks"] == 0
     assert d["roofline"]["bound"] == "mfma" and 0 < d["roofline"]["frac"] < 1 / 3
     assert d["value"] > 50_000
+
+
+def test_fresh_process_call_mix_is_bit_identical_40_times():
+    """The round-2 mismatch only ever showed up in the first launches of FRESH processes (profiles/r03_pair_row_race.md: a
+    data race on the conv1 pair rows inside the f16c6 kernel that a wave delayed by first-touch latencies exposed; fixed by
+    ordering the pair rows with a barrier).  One process = one sample: 40 fresh processes run the call mix of
+    scripts/async_hunt.py (synchronous reference, asynchronous calls of mixed sizes, tapped host forwards in between, two
+    rounds) — 20 with the f16c6 kernel it was seen in, 20 with the default arithmetic's kernel, which shares the scheme."""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    bad = []
+    for i in range(40):
+        prec = "f16c6" if i % 2 == 0 else "f16x3"
+        r = subprocess.run([sys.executable, os.path.join(root, "scripts", "async_hunt.py"), "2", prec],
+                           capture_output=True, text=True, timeout=300)
+        last = (r.stdout.strip().splitlines() or ["<no output>"])[-1]
+        if r.returncode != 0 or not last.startswith("OK"):
+            bad.append((i, prec, last[:600], r.stderr[-300:]))
+    assert not bad, bad
