@@ -9,11 +9,11 @@ mkdir -p $OUT
 python -c "import __graft_entry__ as g; g.smoke()" > $OUT/smoke.txt 2>&1
 b() { name=$1; shift; timeout 900 python bench.py "$@" > $OUT/bench_$name.json 2> $OUT/bench_$name.err; echo "rc=$?" >> $OUT/bench_$name.err; }
 b default
-b sync_steps --sync-steps --steps 16 --cpu-sample 0
+b async_steps --async-steps --steps 16 --cpu-sample 0
 b power --power --steps 32 --cpu-sample 0 --check none --fast-mode-steps 0
 b power_f16c6 --power --precision f16c6 --steps 32 --cpu-sample 0 --check none
 b 2048_per_step --windows-per-step 2048 --steps 64 --cpu-sample 0
-b 2048_per_step_sync --windows-per-step 2048 --steps 64 --cpu-sample 0 --sync-steps
+b 2048_per_step_async --windows-per-step 2048 --steps 64 --cpu-sample 0 --async-steps
 b f16c6 --precision f16c6 --steps 16 --cpu-sample 0
 b bf16x3 --precision bf16x3 --steps 16 --cpu-sample 0 --check golden
 b f16c8 --precision f16c8 --steps 16 --cpu-sample 0 --check golden
