@@ -50,7 +50,8 @@ typedef enum gnn_status {
 /* Arithmetic of the conv / w_v contractions (everything else is always f32). */
 typedef enum gnn_precision {
     GNN_PREC_F32 = 0,        /* f32 reference path: unfused f32 kernels, activations in HBM   */
-    GNN_PREC_BF16X3 = 1,     /* fused path: split-bf16 (hi+lo), 3 MFMA passes, f32 accumulate */
+    GNN_PREC_BF16X3 = 1,     /* fused path: split-bf16 (hi+lo), 3 MFMA passes, f32 accumulate (gnn_fused_x3.hip); f32 range:
+                                what main() recomputes a batch with when an f16-operand mode returns non-finite scores */
     GNN_PREC_BF16 = 2,       /* fused path: single bf16 MFMA pass (fails the 1e-4 tolerance;
                                 for roofline experiments only)                                */
     GNN_PREC_F16C8 = 3,      /* fused path: one f16 MFMA pass + MX-scaled fp8 (e4m3) MFMA corrections of
@@ -59,11 +60,13 @@ typedef enum gnn_precision {
                                 profiles/r02_precision_study.json); needs |activation| < 65504 (f16 range) */
     GNN_PREC_F16C6 = 5,      /* fused path: one f16 MFMA pass + MX-scaled fp6 (e2m3) MFMA corrections, both operands block
                                 scaled (activations per row and 32 channels at run time) = 1.5 pass equivalents; the
-                                accuracy class of F16C8 (config 2: 8.2e-5); the fastest mode and the
-                                default of bench.py / main(); needs |activation| < 65504 (f16 range) and a 4-byte
-                                aligned window buffer (any gnn_dev_alloc / host staging buffer is)                      */
-    GNN_PREC_F16X3 = 4       /* fused path: split-f16 (hi+lo, 11+11 significant bits), 3 MFMA passes, exact-f32 logits
-                                GEMM: f32-class accuracy (25x below bf16x3) at bf16x3's speed; needs
+                                accuracy class of F16C8 (config 2: 8.2e-5); the fastest mode, OPT-IN:
+                                no head-room under the tolerance (1.2e-4 on a few of 10^6 windows: bench.py exits non-zero
+                                with it); needs |activation| < 65504 (f16 range) and a 4-byte aligned window buffer (any
+                                gnn_dev_alloc / host staging buffer is)                                                 */
+    GNN_PREC_F16X3 = 4       /* THE DEFAULT of main(), NNEngine and bench.py.  Fused path (gnn_fused_x3.hip): split-f16 (hi+lo,
+                                11+11 significant bits), 3 MFMA passes, exact-f32 logits GEMM and dense head: f32-class
+                                accuracy (1.1e-5 from the exact-f32 path over 10^6 windows, 25x below bf16x3); needs
                                 |activation| < 65504 (f16 range)                                   */
 } gnn_precision;
 
@@ -161,7 +164,11 @@ int gnn_classify(gnn_ctx* ctx, const uint8_t* bases_host, int64_t n_windows, int
  * asynchronous call — for loops over batches that fit one launch.  scores_dev is complete once gnn_classify_flush (or any
  * other entry point of this ctx: gnn_sync, gnn_memcpy_d2h, gnn_comm_gather_dev, gnn_classify_dev ...) has been called — they
  * wait on the host for what is pending on the second stream — and the ctx stream has been synchronised; results are
- * bit-identical to gnn_classify_dev (bench.py checks every window of every run). */
+ * bit-identical to gnn_classify_dev (bench.py checks every window of every run).  Worth +8-10 % for F16C6 at 2048 windows per
+ * call, nothing for the power-bound default arithmetic.
+ * Debug switches of the library (environment, read once): GNN_NO_BACKEND_OVERLAP=1 keeps every back end on the ctx stream;
+ * GNN_DEBUG_POISON=1 fills the workspaces with NaN patterns before every launch (a kernel reading what its launch has not
+ * written turns the scores into NaN); GNN_X3_ROUND1=1 serves F16X3 / BF16X3 with the round-1 kernel (A/B measurements). */
 int gnn_classify_dev_async(gnn_ctx* ctx, const uint8_t* bases_dev, int64_t n_windows, int precision, float* scores_dev);
 int gnn_classify_flush(gnn_ctx* ctx);
 
