@@ -110,12 +110,44 @@ __device__ __forceinline__ void unit(const WU& wcur, WU& wload, const XU& xcur, 
 #ifndef GNN_ABL_NOW
     load_wu(wload, wr, l16, wnext);
 #endif
+#if defined(GNN_ABL_CONSTX) || defined(GNN_ABL_CONSTW)
+    // measurement only (wrong results): every load is issued and lands in its registers, but the MFMAs read the SAME operand
+    // registers in every unit - separates what moving the operands costs from what feeding the matrix pipe changing data costs
+    {
+        const uint32_t* px = reinterpret_cast<const uint32_t*>(&xcur);
+        const uint32_t* pw = reinterpret_cast<const uint32_t*>(&wcur);
 #pragma unroll
-    for (int mb = 0; mb < NMB; ++mb) acc[mb] = SWAP ? mma16<F16>(wcur.l, xcur.h[mb], acc[mb]) : mma16<F16>(xcur.h[mb], wcur.l, acc[mb]);
+        for (int i = 0; i < (int)(sizeof(XU) / 4); ++i) asm volatile("" ::"v"(px[i]));
 #pragma unroll
-    for (int mb = 0; mb < NMB; ++mb) acc[mb] = SWAP ? mma16<F16>(wcur.h, xcur.l[mb], acc[mb]) : mma16<F16>(xcur.l[mb], wcur.h, acc[mb]);
+        for (int i = 0; i < (int)(sizeof(WU) / 4); ++i) asm volatile("" ::"v"(pw[i]));
+    }
+#endif
+#ifdef GNN_ABL_CONSTX
+    const uint4 kx = make_uint4(0x3C003C00u + l16, 0x3C003800u, 0x38003C00u, 0x3C003C00u);
+#define GNN_XH(mb) make_uint4(kx.x, kx.y + (mb), kx.z, kx.w)
+#define GNN_XL(mb) make_uint4(kx.x, kx.y, kx.z + (mb), kx.w)
+#else
+#define GNN_XH(mb) xcur.h[mb]
+#define GNN_XL(mb) xcur.l[mb]
+#endif
+#ifdef GNN_ABL_CONSTW
+    const uint4 kw = make_uint4(0x38003C00u + l16, 0x3C003C00u, 0x3C003800u, 0x38003800u);
+#define GNN_WH kw
+#define GNN_WL kw
+#else
+#define GNN_WH wcur.h
+#define GNN_WL wcur.l
+#endif
 #pragma unroll
-    for (int mb = 0; mb < NMB; ++mb) acc[mb] = SWAP ? mma16<F16>(wcur.h, xcur.h[mb], acc[mb]) : mma16<F16>(xcur.h[mb], wcur.h, acc[mb]);
+    for (int mb = 0; mb < NMB; ++mb) acc[mb] = SWAP ? mma16<F16>(GNN_WL, GNN_XH(mb), acc[mb]) : mma16<F16>(GNN_XH(mb), GNN_WL, acc[mb]);
+#pragma unroll
+    for (int mb = 0; mb < NMB; ++mb) acc[mb] = SWAP ? mma16<F16>(GNN_WH, GNN_XL(mb), acc[mb]) : mma16<F16>(GNN_XL(mb), GNN_WH, acc[mb]);
+#pragma unroll
+    for (int mb = 0; mb < NMB; ++mb) acc[mb] = SWAP ? mma16<F16>(GNN_WH, GNN_XH(mb), acc[mb]) : mma16<F16>(GNN_XH(mb), GNN_WH, acc[mb]);
+#undef GNN_XH
+#undef GNN_XL
+#undef GNN_WH
+#undef GNN_WL
 #pragma unroll
     for (int i = 0; i < 3 * NMB; ++i) {
         __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                           // 1 MFMA
