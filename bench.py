@@ -498,6 +498,14 @@ def main():
             out["roofline"]["issued_mfma_tflops_bf16_equivalent"] = round(tflops * passes, 1)
             out["roofline"]["mfma_probe_sustained_tflops"] = round(probe.value, 1)
             out["roofline"]["issued_vs_probe"] = round(tflops * passes / probe.value, 4)
+            if args.precision in ("f16x3", "bf16x3"):
+                # the power floor of THIS arithmetic: register-operand MFMAs of the kernel's own instruction (f16 draws more than
+                # bf16 per MFMA on this chip), nothing else running; the kernel issues `passes` of them per algorithmic product
+                same = ctypes.c_double()
+                _lib.check(eng.lib.gnn_mfma_probe_kind(eng.ctx, 1 if args.precision == "f16x3" else 0, 200, ctypes.byref(same)))
+                out["roofline"]["mfma_probe_same_instruction_tflops"] = round(same.value, 1)
+                out["roofline"]["frac_of_power_floor"] = round(tflops * passes / same.value, 4)
+                out["roofline"]["frac_ceiling_at_power_floor"] = round(same.value / passes / MFMA_PEAK_TFLOPS, 4)
         # parity of what was just timed: every window against the exact-f32 device path (above), and the first windows of
         # the job against the committed outputs of the reference's own graph (tests/golden/config2_golden.npz, windows 0..9999)
         if fast is not None:

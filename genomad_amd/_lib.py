@@ -85,6 +85,7 @@ SIGNATURES = {
     "gnn_set_chunk": (_int, [_vp, _i64]),
     "gnn_phase_cycles": (_int, [_vp, _int, C.POINTER(C.c_uint64)]),
     "gnn_mfma_probe": (_int, [_vp, _int, C.POINTER(C.c_double)]),
+    "gnn_mfma_probe_kind": (_int, [_vp, _int, _int, C.POINTER(C.c_double)]),
     "gnn_fused_rows_per_step": (_int, [_int]),
     "gnn_debug_set_pad_skip": (_int, [_vp, _int]),
     "gnn_debug_pack_c6": (_int, [_f32p, _int, _int, C.POINTER(C.c_uint32), _sz, C.POINTER(_sz)]),

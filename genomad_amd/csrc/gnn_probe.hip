@@ -13,14 +13,19 @@ namespace gnn {
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
+typedef _Float16 f16x8p __attribute__((ext_vector_type(8)));
+
+// KIND 0: bf16 MFMAs (the round-1 probe); KIND 1: f16 MFMAs - the instruction of the default arithmetic (f16x3), same
+// geometry: 12 MFMAs per iteration on 4 accumulators, operands resident in registers
+template <int KIND>
 __global__ __launch_bounds__(256, 1) void mfma_probe_kernel(const uint4* __restrict__ operands, int iters,
                                                             float* __restrict__ sink) {
     const int lane = threadIdx.x & 63;
-    bf16x8 a[4], b[4];
+    uint4 a[4], b[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-        a[i] = __builtin_bit_cast(bf16x8, operands[(i * 2 + 0) * 64 + lane]);
-        b[i] = __builtin_bit_cast(bf16x8, operands[(i * 2 + 1) * 64 + lane]);
+        a[i] = operands[(i * 2 + 0) * 64 + lane];
+        b[i] = operands[(i * 2 + 1) * 64 + lane];
     }
     f32x16 acc[4];
 #pragma unroll
@@ -33,7 +38,10 @@ __global__ __launch_bounds__(256, 1) void mfma_probe_kernel(const uint4* __restr
         for (int rep = 0; rep < 3; ++rep)          // 12 MFMAs per iteration, like one k-step of the fused kernel
 #pragma unroll
             for (int i = 0; i < 4; ++i)
-                acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[(i + rep) & 3], b[i], acc[i], 0, 0, 0);
+                if constexpr (KIND == 1)
+                    acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8p, a[(i + rep) & 3]), __builtin_bit_cast(f16x8p, b[i]), acc[i], 0, 0, 0);
+                else
+                    acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a[(i + rep) & 3]), __builtin_bit_cast(bf16x8, b[i]), acc[i], 0, 0, 0);
     }
     float s = 0.f;
 #pragma unroll
@@ -48,9 +56,11 @@ __global__ __launch_bounds__(256, 1) void mfma_probe_kernel(const uint4* __restr
 using namespace gnn;
 
 // Runs the probe for roughly `ms_target` milliseconds (after a calibration launch) and returns the
-// sustained dense bf16 MFMA rate in TFLOP/s.
-extern "C" int gnn_mfma_probe(gnn_ctx* ctx, int ms_target, double* tflops_out) {
-    if (!ctx || !tflops_out || ms_target < 1) {
+// sustained dense MFMA rate in TFLOP/s: kind 0 = bf16 (gnn_mfma_probe), kind 1 = f16.
+extern "C" int gnn_mfma_probe(gnn_ctx* ctx, int ms_target, double* tflops_out) { return gnn_mfma_probe_kind(ctx, 0, ms_target, tflops_out); }
+
+extern "C" int gnn_mfma_probe_kind(gnn_ctx* ctx, int kind, int ms_target, double* tflops_out) {
+    if (!ctx || !tflops_out || ms_target < 1 || kind < 0 || kind > 1) {
         set_error("bad argument to gnn_mfma_probe");
         return GNN_ERR_ARG;
     }
@@ -59,10 +69,15 @@ extern "C" int gnn_mfma_probe(gnn_ctx* ctx, int ms_target, double* tflops_out) {
     const int blocks = ctx->cu_count > 0 ? ctx->cu_count : 256;
     std::vector<uint16_t> host(8 * 64 * 8);
     uint32_t x = 0x12345u;
-    for (auto& v : host) {                          // random bf16 in roughly [-2, 2)
+    for (auto& v : host) {                          // random values in roughly [-2, 2) in the probe's 16-bit format
         x = x * 1664525u + 1013904223u;
-        const uint32_t sign = (x >> 31) << 15, exp = 126u + ((x >> 29) & 1u), man = (x >> 8) & 0x7Fu;
-        v = (uint16_t)(sign | (exp << 7) | man);
+        if (kind == 1) {                            // f16: 5 exponent bits (bias 15), 10 mantissa bits
+            const uint32_t sign = (x >> 31) << 15, exp = 14u + ((x >> 29) & 1u), man = (x >> 8) & 0x3FFu;
+            v = (uint16_t)(sign | (exp << 10) | man);
+        } else {
+            const uint32_t sign = (x >> 31) << 15, exp = 126u + ((x >> 29) & 1u), man = (x >> 8) & 0x7Fu;
+            v = (uint16_t)(sign | (exp << 7) | man);
+        }
     }
     void *dop = nullptr, *dsink = nullptr;
     GNN_HIP(hipMalloc(&dop, host.size() * 2));
@@ -73,8 +88,10 @@ extern "C" int gnn_mfma_probe(gnn_ctx* ctx, int ms_target, double* tflops_out) {
     GNN_HIP(hipEventCreate(&e1));
     auto run = [&](int iters, float* ms) -> int {
         GNN_HIP(hipEventRecord(e0, ctx->stream));
-        hipLaunchKernelGGL(mfma_probe_kernel, dim3(blocks), dim3(256), 0, ctx->stream, (const uint4*)dop, iters,
-                           (float*)dsink);
+        if (kind == 1)
+            hipLaunchKernelGGL(mfma_probe_kernel<1>, dim3(blocks), dim3(256), 0, ctx->stream, (const uint4*)dop, iters, (float*)dsink);
+        else
+            hipLaunchKernelGGL(mfma_probe_kernel<0>, dim3(blocks), dim3(256), 0, ctx->stream, (const uint4*)dop, iters, (float*)dsink);
         GNN_HIP(hipEventRecord(e1, ctx->stream));
         GNN_HIP(hipEventSynchronize(e1));
         GNN_HIP(hipEventElapsedTime(ms, e0, e1));

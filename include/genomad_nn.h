@@ -294,6 +294,9 @@ int gnn_phase_cycles(gnn_ctx* ctx, int on, unsigned long long* out16);
  * SIMD and register operands, run for about ms_target milliseconds — the practical MFMA ceiling of
  * this (power-managed) chip, reported by bench.py beside the fused kernel's issued-MFMA rate. */
 int gnn_mfma_probe(gnn_ctx* ctx, int ms_target, double* tflops_out);
+/* the same with the MFMA of `kind`: 0 = v_mfma_f32_32x32x16_bf16, 1 = v_mfma_f32_32x32x16_f16 (the instruction of the default
+ * arithmetic: bench.py prints the issued f16 MFMA rate of the f16x3 kernel as a fraction of it, `frac_of_power_floor`) */
+int gnn_mfma_probe_kind(gnn_ctx* ctx, int kind, int ms_target, double* tflops_out);
 
 /* measurement aid: rows (token positions) a workgroup of the fused front end of `precision` streams per step
  * (128 for the f16c8 / x3 kernels; 32 * GNN_C6_NMB for f16c6), 0 for GNN_PREC_F32, negative on a bad enum. */
