@@ -98,7 +98,7 @@ __device__ __forceinline__ void load_xu(XU& f, const unsigned char* __restrict__
     }
 }
 
-// One k16 unit = one scheduling region: its 12 MFMAs (small terms first, as gnn_fused.hip: bit-identical sums) with the
+// One k16 unit = one scheduling region: its 12 MFMAs with the
 // activation fragments of the next unit (8 LDS reads) and the weight fragments of the unit RINGW - 1 ahead (2 L2 loads)
 // issued between them.
 template <bool SWAP, bool F16, bool LX, int OFFN>
@@ -138,12 +138,33 @@ __device__ __forceinline__ void unit(const WU& wcur, WU& wload, const XU& xcur, 
 #define GNN_WH wcur.h
 #define GNN_WL wcur.l
 #endif
+#ifndef GNN_X3_TERM_MAJOR
+    // every MFMA shares one operand register with its predecessor (w_l x_h0, w_h x_h0, w_h x_l0 | w_h x_l1, w_h x_h1, w_l x_h1 |
+    // ...): the matrix pipe draws a little less when one operand does not change - 27.80 vs 28.01 ms per 4096 windows against
+    // the term-major order (all w_l x_h, then all w_h x_l, then all w_h x_h; GNN_X3_TERM_MAJOR), the loop cycles are the same
+    // (three dependent MFMAs per accumulator in a row do not stall): profiles/r03_x3_operand_chain_ab.txt
+#define GNN_MM(W_, X_, mb) acc[mb] = SWAP ? mma16<F16>(W_, X_, acc[mb]) : mma16<F16>(X_, W_, acc[mb])
+#pragma unroll
+    for (int mb = 0; mb < NMB; ++mb) {
+        if (mb % 2 == 0) {
+            GNN_MM(GNN_WL, GNN_XH(mb), mb);
+            GNN_MM(GNN_WH, GNN_XH(mb), mb);
+            GNN_MM(GNN_WH, GNN_XL(mb), mb);
+        } else {
+            GNN_MM(GNN_WH, GNN_XL(mb), mb);
+            GNN_MM(GNN_WH, GNN_XH(mb), mb);
+            GNN_MM(GNN_WL, GNN_XH(mb), mb);
+        }
+    }
+#undef GNN_MM
+#else
 #pragma unroll
     for (int mb = 0; mb < NMB; ++mb) acc[mb] = SWAP ? mma16<F16>(GNN_WL, GNN_XH(mb), acc[mb]) : mma16<F16>(GNN_XH(mb), GNN_WL, acc[mb]);
 #pragma unroll
     for (int mb = 0; mb < NMB; ++mb) acc[mb] = SWAP ? mma16<F16>(GNN_WH, GNN_XL(mb), acc[mb]) : mma16<F16>(GNN_XL(mb), GNN_WH, acc[mb]);
 #pragma unroll
     for (int mb = 0; mb < NMB; ++mb) acc[mb] = SWAP ? mma16<F16>(GNN_WH, GNN_XH(mb), acc[mb]) : mma16<F16>(GNN_XH(mb), GNN_WH, acc[mb]);
+#endif
 #undef GNN_XH
 #undef GNN_XL
 #undef GNN_WH
