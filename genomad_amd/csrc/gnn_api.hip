@@ -383,7 +383,7 @@ extern "C" {
 
 const char* gnn_last_error(void) { return g_last_error.c_str(); }
 
-int gnn_version(void) { return 210; }
+int gnn_version(void) { return 300; }
 
 int gnn_debug_pack_c6(const float* w, int k, int n, uint32_t* out, size_t out_words, size_t* need_words) {
     std::vector<uint32_t> v;
