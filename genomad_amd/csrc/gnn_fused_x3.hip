@@ -213,15 +213,31 @@ __device__ __forceinline__ void prefetch_w(WU (&ring)[RINGW], wrsrc_t wr, int wo
     asm volatile("" ::: "memory");
 }
 
-// two values -> packed 16-bit hi / lo words: hi = round16(x) (RNE), lo = round16(x - hi); written on pairs so that hipcc
-// selects the packed conversions
+// two values -> packed 16-bit hi / lo words: hi = round16(x) (RNE), lo = round16(x - hi).  The conv epilogues are the matrix
+// waves' only VALU-bound phase (12 % of a step), so the f16 form is spelled out: v_cvt_pk_f16_f32 for hi, x - hi straight from
+// the packed f16 halves with v_fma_mix_f32 (hi * -1.0 + x: exact, the same value as converting back and subtracting), one more
+// v_cvt_pk for lo: 4 instructions per pair instead of 6; LeakyReLU as a raw v_max_f32 (hipcc wraps fmaxf of values it cannot
+// prove quiet in two canonicalising v_max: 2 more per pair).  NaN stays NaN (max(NaN, 0.1 NaN)); 7 instead of 10 per pair.
+__device__ __forceinline__ float vmax_raw(float a, float b) {
+    float d;
+    asm("v_max_f32 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b));
+    return d;
+}
+__device__ __forceinline__ float sub_f16_lo(float x, uint32_t h) {      // x - (float)(low half of h)
+    float d;
+    asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=v"(d) : "v"(h), "v"(x));
+    return d;
+}
+__device__ __forceinline__ float sub_f16_hi(float x, uint32_t h) {      // x - (float)(high half of h)
+    float d;
+    asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(d) : "v"(h), "v"(x));
+    return d;
+}
 template <bool F16>
 __device__ __forceinline__ void split2(f32x2 v, uint32_t& hi, uint32_t& lo) {
     if constexpr (F16) {
-        const f16x2 h = __builtin_convertvector(v, f16x2);
-        hi = __builtin_bit_cast(uint32_t, h);
-        const f32x2 back = {(float)h[0], (float)h[1]};
-        lo = __builtin_bit_cast(uint32_t, __builtin_convertvector(v - back, f16x2));
+        hi = __builtin_bit_cast(uint32_t, __builtin_convertvector(v, f16x2));
+        lo = __builtin_bit_cast(uint32_t, __builtin_convertvector(f32x2{sub_f16_lo(v[0], hi), sub_f16_hi(v[1], hi)}, f16x2));
     } else {
         hi = __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2));
         const f32x2 back = {__uint_as_float(hi << 16), __uint_as_float(hi & 0xFFFF0000u)};
@@ -231,7 +247,7 @@ __device__ __forceinline__ void split2(f32x2 v, uint32_t& hi, uint32_t& lo) {
 template <bool F16>
 __device__ __forceinline__ void lrelu_split2(f32x2 v, uint32_t& hi, uint32_t& lo) {
     const f32x2 s = v * LRELU;
-    split2<F16>(f32x2{fmaxf(v[0], s[0]), fmaxf(v[1], s[1])}, hi, lo);
+    split2<F16>(f32x2{vmax_raw(v[0], s[0]), vmax_raw(v[1], s[1])}, hi, lo);
 }
 
 // bias pre-loaded into the accumulators, D = W^T X^T layout: register r of lane l = channel 8 (r >> 2) + 4 (l >> 5) + (r & 3)
