@@ -291,8 +291,9 @@ __device__ __forceinline__ void wv_pool_store(const f32x16 (&acc)[NMB], wrsrc_t 
         const int mb = i >> 2, rg = i & 3;
         const float v = max_nan(max_nan(acc[mb][rg * 4], acc[mb][rg * 4 + 1]), max_nan(acc[mb][rg * 4 + 2], acc[mb][rg * 4 + 3]));
         const unsigned bits = __float_as_uint(v);
+        // v_permlane32_swap(v, v) = {[v.lo | v.lo], [v.hi | v.hi]}: their maximum is the 8-row maximum in BOTH lane halves, no select
         const auto sw = __builtin_amdgcn_permlane32_swap(bits, bits, false, false);
-        m[i] = max_nan(v, __uint_as_float(lane < 32 ? sw[1] : sw[0]));
+        m[i] = max_nan(__uint_as_float(sw[0]), __uint_as_float(sw[1]));
     }
     const int q0 = t0 / GNN_POOL;
     const int nq = min(4 * NMB, POOLED - q0);
@@ -328,8 +329,9 @@ __device__ __forceinline__ void gather_store(const GatherSum& g, unsigned char* 
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             const float got = dpp_xor1(odd ? sa[k] : sb[k]);             // even lane keeps row A and gets the partner's row A half
-            x[4 * i + k] = lrelu_f(odd ? got : sa[k]);                   // channels 0..15 of the block
-            x[16 + 4 * i + k] = lrelu_f(odd ? sb[k] : got);              // channels 16..31
+            const float c0 = odd ? got : sa[k], c1 = odd ? sb[k] : got;
+            x[4 * i + k] = vmax_raw(c0, c0 * LRELU);                     // channels 0..15 of the block
+            x[16 + 4 * i + k] = vmax_raw(c1, c1 * LRELU);                // channels 16..31
         }
     }
     store_block32<F16>(xbuf, CARRY + ua + (odd ? 1 : 0), pq >> 1, x);
