@@ -56,7 +56,7 @@ HBM_PEAK_GBS = 8000.0
 MFMA_PASSES = {"f16c6": 1.5, "f16c8": 2.0, "f16x3": 3.0, "bf16x3": 3.0, "bf16": 1.0}
 DTYPE_TEXT = {"f16c6": "f16 MFMA + MX-fp6 (e2m3, both operands block scaled) correction MFMAs, f32 accumulate (1.5 f16-pass equivalents)",
               "f16c8": "f16 MFMA + MX-fp8 (e4m3) correction MFMAs, f32 accumulate (2.0 bf16-pass equivalents)",
-              "f16x3": "f16x3 (split-f16 MFMA, 3 passes, f32 accumulate, exact-f32 logits GEMM)",
+              "f16x3": "f16x3 (split-f16 MFMA, 3 passes, f32 accumulate; logits GEMM split-f16 x 3 as well, dense head exact f32)",
               "bf16x3": "bf16x3 (split-bf16 MFMA, 3 passes, f32 accumulate)", "bf16": "bf16", "f32": "f32"}
 
 

@@ -8,6 +8,8 @@
 //   feat      = sum_q alpha[q] * yp[q,:]   (both heads, concat)   igloo.py:213-214, :83
 //   h1 = relu(BN(feat@D1+d1)); h2 = relu(BN(h1@D2+d2)); scores = softmax(h2@D3+d3)   model.py:28-44
 //   contig score = segment mean of window scores                  nn_classification.py:320
+#include <cstdlib>
+
 #include "gnn_common.h"
 
 namespace gnn {
@@ -139,29 +141,48 @@ __device__ __forceinline__ void qk_load(QkA& a, QkB& b, const float* __restrict_
     }
 }
 
-template <int PASSES>
+// F16 = false: split-bf16 limbs (8 + 8 significant bits, any f32 range); F16 = true: split-f16 limbs (11 + 11 bits: the three
+// products then carry 22 bits, f32 class - the logits GEMM of GNN_PREC_F16X3, whose operands (m: |.| < 1e2, w_qk: ~1e-2) are
+// far inside the f16 range)
+template <int PASSES, bool F16>
 __device__ __forceinline__ void qk_mfma(const QkA& a, const QkB& b, f32x16 (&acc)[2][2]) {
     typedef float f32x8 __attribute__((ext_vector_type(8)));
+    typedef _Float16 f16x8q __attribute__((ext_vector_type(8)));
 #pragma unroll
     for (int mb = 0; mb < 2; ++mb) {
         const f32x8 x = {a.v[mb][0].x, a.v[mb][0].y, a.v[mb][0].z, a.v[mb][0].w,
                          a.v[mb][1].x, a.v[mb][1].y, a.v[mb][1].z, a.v[mb][1].w};
-        const bf16x8 ah = __builtin_convertvector(x, bf16x8);
-        const bf16x8 al = __builtin_convertvector(x - __builtin_convertvector(ah, f32x8), bf16x8);
+        if constexpr (F16) {
+            const f16x8q ah = __builtin_convertvector(x, f16x8q);
+            const f16x8q al = __builtin_convertvector(x - __builtin_convertvector(ah, f32x8), f16x8q);
 #pragma unroll
-        for (int nb = 0; nb < 2; ++nb) {
-            const bf16x8 bh = __builtin_bit_cast(bf16x8, b.v[nb][0]);
-            if constexpr (PASSES == 3) {
-                const bf16x8 bl = __builtin_bit_cast(bf16x8, b.v[nb][1]);
-                acc[mb][nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc[mb][nb], 0, 0, 0);
-                acc[mb][nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc[mb][nb], 0, 0, 0);
+            for (int nb = 0; nb < 2; ++nb) {
+                const f16x8q bh = __builtin_bit_cast(f16x8q, b.v[nb][0]);
+                if constexpr (PASSES == 3) {
+                    const f16x8q bl = __builtin_bit_cast(f16x8q, b.v[nb][1]);
+                    acc[mb][nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl, acc[mb][nb], 0, 0, 0);
+                    acc[mb][nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, acc[mb][nb], 0, 0, 0);
+                }
+                acc[mb][nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, acc[mb][nb], 0, 0, 0);
             }
-            acc[mb][nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc[mb][nb], 0, 0, 0);
+        } else {
+            const bf16x8 ah = __builtin_convertvector(x, bf16x8);
+            const bf16x8 al = __builtin_convertvector(x - __builtin_convertvector(ah, f32x8), bf16x8);
+#pragma unroll
+            for (int nb = 0; nb < 2; ++nb) {
+                const bf16x8 bh = __builtin_bit_cast(bf16x8, b.v[nb][0]);
+                if constexpr (PASSES == 3) {
+                    const bf16x8 bl = __builtin_bit_cast(bf16x8, b.v[nb][1]);
+                    acc[mb][nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc[mb][nb], 0, 0, 0);
+                    acc[mb][nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc[mb][nb], 0, 0, 0);
+                }
+                acc[mb][nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc[mb][nb], 0, 0, 0);
+            }
         }
     }
 }
 
-template <int PASSES>
+template <int PASSES, bool F16 = false>
 __global__ __launch_bounds__(256) void logits_mfma_kernel(const float* __restrict__ m, const uint4* __restrict__ frag0,
                                                           const uint4* __restrict__ frag1, int n,
                                                           float* __restrict__ logits) {
@@ -186,9 +207,9 @@ __global__ __launch_bounds__(256) void logits_mfma_kernel(const float* __restric
 #pragma unroll 1
     for (int ks = 0; ks < QK_KSTEPS; ks += 2) {                // QK_KSTEPS is even
         qk_load(a1, b1, mrow0, mrow1, bfrag, ks + 1, lane);
-        qk_mfma<PASSES>(a0, b0, acc);
+        qk_mfma<PASSES, F16>(a0, b0, acc);
         qk_load(a0, b0, mrow0, mrow1, bfrag, min(ks + 2, QK_KSTEPS - 1), lane);
-        qk_mfma<PASSES>(a1, b1, acc);
+        qk_mfma<PASSES, F16>(a1, b1, acc);
     }
     // C/D layout: column = lane&31 (q), row = (reg&3) + 8*(reg>>2) + 4*(lane>>5) (window)
 #pragma unroll
@@ -465,7 +486,12 @@ int launch_backend(gnn_ctx* ctx, int64_t n, int precision, float* scores_dev) {
         hipLaunchKernelGGL(logits_mfma_kernel<3>, qk_grid, dim3(256), 0, ctx->stream, ws.m, qf0, qf1, (int)n, ws.logits);
     else if (precision == GNN_PREC_BF16)
         hipLaunchKernelGGL(logits_mfma_kernel<1>, qk_grid, dim3(256), 0, ctx->stream, ws.m, qf0, qf1, (int)n, ws.logits);
-    else    // GNN_PREC_F32 and GNN_PREC_F16X3 (the accuracy-first fused mode): exact f32 FMAs
+    else if (precision == GNN_PREC_F16X3 && std::getenv("GNN_LOGITS_F32") == nullptr)
+        // the default arithmetic: split-f16 x 3 on the matrix pipe (22 significant bits, f32 accumulate: f32 class; 0.25 instead of
+        // 0.64 ms per 4096 windows for the exact-f32 VALU kernel, which GNN_LOGITS_F32=1 selects for A/B runs)
+        hipLaunchKernelGGL((logits_mfma_kernel<3, true>), qk_grid, dim3(256), 0, ctx->stream, ws.m,
+                           reinterpret_cast<const uint4*>(d.wqk_frag_h[0]), reinterpret_cast<const uint4*>(d.wqk_frag_h[1]), (int)n, ws.logits);
+    else    // GNN_PREC_F32 (and GNN_PREC_F16X3 with GNN_LOGITS_F32=1): exact f32 FMAs
         hipLaunchKernelGGL(logits_kernel, dim3((POOLED + LQ - 1) / LQ, (unsigned)((n + LW - 1) / LW), 2), dim3(256), 0,
                            ctx->stream, ws.m, d.w_qk[0], d.w_qk[1], (int)n, ws.logits);
     hipLaunchKernelGGL(attn_kernel, dim3((unsigned)n, 2), dim3(256), 0, ctx->stream, ws.logits, ws.yp, ws.alpha,

@@ -74,6 +74,7 @@ struct DeviceWeights {
     uint16_t* conv_frag[2] = {nullptr, nullptr};  // conv2, conv3: [kstep 48][nblk 4][plane 2][lane 64][8]
     uint16_t* wv_frag[2] = {nullptr, nullptr};    // head A, B:   [kstep 8][nblk 4][plane 2][lane 64][8]
     uint16_t* wqk_frag[2] = {nullptr, nullptr};   // head A, B:   [kstep 132][nblk 24][plane 2][lane 64][8], zero padded
+    uint16_t* wqk_frag_h[2] = {nullptr, nullptr}; // the same with f16 hi / lo limbs (logits GEMM of GNN_PREC_F16X3)
     uint16_t* conv_frag_h[2] = {nullptr, nullptr};   // the same fragment layouts with f16 hi / lo limbs (GNN_PREC_F16X3)
     uint16_t* wv_frag_h[2] = {nullptr, nullptr};
     // f16 + fp8-correction packs (gnn_fused_c8.hip): [k32 step][nblk 4][f16 even | f16 odd | fp8 lo | fp8 hi][lane 64] x 16 B

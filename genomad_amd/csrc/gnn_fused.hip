@@ -488,6 +488,7 @@ int pack_fused_weights(gnn_ctx* ctx, const gnn_weights* w) {
         if ((rc = upload_vec(ctx, pack_frags(ck[i], KS * C, C), &d.conv_frag[i]))) return rc;
         if ((rc = upload_vec(ctx, pack_frags(ig[i]->w_v, C, C), &d.wv_frag[i]))) return rc;
         if ((rc = upload_vec(ctx, pack_frags(ig[i]->w_qk, NP, POOLED), &d.wqk_frag[i]))) return rc;
+        if ((rc = upload_vec(ctx, pack_frags(ig[i]->w_qk, NP, POOLED, true), &d.wqk_frag_h[i]))) return rc;
         if ((rc = upload_vec(ctx, pack_frags(ck[i], KS * C, C, true), &d.conv_frag_h[i]))) return rc;
         if ((rc = upload_vec(ctx, pack_frags(ig[i]->w_v, C, C, true), &d.wv_frag_h[i]))) return rc;
     }

@@ -3,7 +3,7 @@
 //
 //   x * w  ~=  hi(x) * lo(w)  +  lo(x) * hi(w)  +  hi(x) * hi(w)          three v_mfma_f32_32x32x16_{f16,bf16} per k16, f32 accumulate
 //
-// With f16 limbs (11 + 11 significant bits) the class scores are f32-class: max |dscore| 1.1e-5 against the exact-f32 path
+// With f16 limbs (11 + 11 significant bits) the class scores are f32-class: max |dscore| 1-2e-5 against the exact-f32 path
 // over 1 048 576 windows (profiles/), which is why this is the arithmetic main() and bench.py default to; bf16 limbs
 // (8 + 8 bits, 6e-5 ... 1e-4) keep the f32 range and are the fallback when an activation leaves the f16 range.
 //

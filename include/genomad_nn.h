@@ -65,8 +65,8 @@ typedef enum gnn_precision {
                                 with it); needs |activation| < 65504 (f16 range) and a 4-byte aligned window buffer (any
                                 gnn_dev_alloc / host staging buffer is)                                                 */
     GNN_PREC_F16X3 = 4       /* THE DEFAULT of main(), NNEngine and bench.py.  Fused path (gnn_fused_x3.hip): split-f16 (hi+lo,
-                                11+11 significant bits), 3 MFMA passes, exact-f32 logits GEMM and dense head: f32-class
-                                accuracy (1.1e-5 from the exact-f32 path over 10^6 windows, 25x below bf16x3); needs
+                                11+11 significant bits), 3 MFMA passes, logits GEMM split-f16 x 3 on the matrix pipe, dense head exact f32: f32-class
+                                accuracy (within 2e-5 of the exact-f32 path on every one of 10^6 windows, 25x below bf16x3 in emulation); needs
                                 |activation| < 65504 (f16 range)                                   */
 } gnn_precision;
 
