@@ -21,8 +21,19 @@ constexpr int TOK_COUNT = ((FSTEPS * FT + CARRY + KS) + 7) / 8 * 8;   // 6032
 constexpr int SMEM_BYTES = TOK_OFF + ((TOK_COUNT * 2 + 15) / 16) * 16;
 constexpr int FRAG_U4 = 64;                  // one fragment = 64 lanes x uint4
 
+// v_max_f32 as is: hipcc wraps fmaxf of values it cannot prove quiet (MFMA results, loads) in a canonicalising v_max per operand,
+// two more instructions per value in the VALU-bound row producers.  NaN stays NaN when both operands are NaN (LeakyReLU below).
+__device__ __forceinline__ float vmax_raw(float a, float b) {
+    float d;
+    asm("v_max_f32 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b));
+    return d;
+}
 // LeakyReLU(0.1) = max(v, 0.1 v) since the slope is < 1: two VALU ops instead of mul + compare + select
+#ifdef GNN_LRELU_FMAXF      // measurement variant: the compiler's fmaxf (with its canonicalising v_max)
 __device__ __forceinline__ float lrelu_f(float v) { return fmaxf(v, v * LRELU); }
+#else
+__device__ __forceinline__ float lrelu_f(float v) { return vmax_raw(v, v * LRELU); }
+#endif
 
 // Maximum that PROPAGATES NaN (IEEE 754-2019 maximum; v_maximum3_f32 on gfx950), for the max-pool of y @ w_v: fmaxf returns
 // the other operand when one is NaN, which would let the pooling hide an overflow of the f16-operand arithmetic behind
