@@ -498,6 +498,14 @@ def main():
             out["roofline"]["issued_mfma_tflops_bf16_equivalent"] = round(tflops * passes, 1)
             out["roofline"]["mfma_probe_sustained_tflops"] = round(probe.value, 1)
             out["roofline"]["issued_vs_probe"] = round(tflops * passes / probe.value, 4)
+            if args.precision == "f16c6":
+                # the power floor of the opt-in fast arithmetic: its own MFMA mix (8 f16 + 4 MX-fp6 per k32 step) on register operands,
+                # in algorithmic TFLOP/s
+                same = ctypes.c_double()
+                _lib.check(eng.lib.gnn_mfma_probe_kind(eng.ctx, 2, 200, ctypes.byref(same)))
+                out["roofline"]["mfma_probe_same_mix_algorithmic_tflops"] = round(same.value, 1)
+                out["roofline"]["frac_of_power_floor"] = round(tflops / same.value, 4)
+                out["roofline"]["frac_ceiling_at_power_floor"] = round(same.value / MFMA_PEAK_TFLOPS, 4)
             if args.precision in ("f16x3", "bf16x3"):
                 # the power floor of THIS arithmetic: register-operand MFMAs of the kernel's own instruction (f16 draws more than
                 # bf16 per MFMA on this chip), nothing else running; the kernel issues `passes` of them per algorithmic product

@@ -295,7 +295,8 @@ int gnn_phase_cycles(gnn_ctx* ctx, int on, unsigned long long* out16);
  * this (power-managed) chip, reported by bench.py beside the fused kernel's issued-MFMA rate. */
 int gnn_mfma_probe(gnn_ctx* ctx, int ms_target, double* tflops_out);
 /* the same with the MFMA of `kind`: 0 = v_mfma_f32_32x32x16_bf16, 1 = v_mfma_f32_32x32x16_f16 (the instruction of the default
- * arithmetic: bench.py prints the issued f16 MFMA rate of the f16x3 kernel as a fraction of it, `frac_of_power_floor`) */
+ * arithmetic: bench.py prints the issued f16 MFMA rate of the f16x3 kernel as a fraction of it, `frac_of_power_floor`), 2 = the
+ * MFMA mix of f16c6 (8 f16 + 4 MX-fp6 scaled MFMAs per k32 step), reported in algorithmic TFLOP/s (the f16 MFMAs only) */
 int gnn_mfma_probe_kind(gnn_ctx* ctx, int kind, int ms_target, double* tflops_out);
 
 /* measurement aid: rows (token positions) a workgroup of the fused front end of `precision` streams per step
