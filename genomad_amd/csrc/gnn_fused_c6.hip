@@ -347,7 +347,12 @@ __device__ __forceinline__ void store_block32(unsigned char* __restrict__ buf, i
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
         const f16x2 h = __builtin_convertvector(f32x2{x[2 * i], x[2 * i + 1]}, f16x2);
+#ifdef GNN_C6_RESID_CVT      // measurement variant: convert back and subtract (two instructions per value instead of one)
         const float r0 = x[2 * i] - (float)h[0], r1 = x[2 * i + 1] - (float)h[1];
+#else
+        const uint32_t hb = __builtin_bit_cast(uint32_t, h);
+        const float r0 = sub_f16_lo(x[2 * i], hb), r1 = sub_f16_hi(x[2 * i + 1], hb);
+#endif
         hv[2 * i] = h[0];
         hv[2 * i + 1] = h[1];
         re[i] = r0;

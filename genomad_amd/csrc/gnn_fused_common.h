@@ -28,6 +28,18 @@ __device__ __forceinline__ float vmax_raw(float a, float b) {
     asm("v_max_f32 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b));
     return d;
 }
+// x - (float)(one f16 half of the packed word h) in ONE instruction: v_fma_mix_f32 reads the f16 half directly (h * -1.0 + x; exact,
+// the value a v_cvt_f32_f16 + v_sub_f32 pair gives) - the f16 rounding residual of the two-limb splits and of the f16c6 rows
+__device__ __forceinline__ float sub_f16_lo(float x, uint32_t h) {
+    float d;
+    asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=v"(d) : "v"(h), "v"(x));
+    return d;
+}
+__device__ __forceinline__ float sub_f16_hi(float x, uint32_t h) {
+    float d;
+    asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(d) : "v"(h), "v"(x));
+    return d;
+}
 // LeakyReLU(0.1) = max(v, 0.1 v) since the slope is < 1: two VALU ops instead of mul + compare + select
 #ifdef GNN_LRELU_FMAXF      // measurement variant: the compiler's fmaxf (with its canonicalising v_max)
 __device__ __forceinline__ float lrelu_f(float v) { return fmaxf(v, v * LRELU); }

@@ -215,19 +215,10 @@ __device__ __forceinline__ void prefetch_w(WU (&ring)[RINGW], wrsrc_t wr, int wo
 
 // two values -> packed 16-bit hi / lo words: hi = round16(x) (RNE), lo = round16(x - hi).  The conv epilogues are the matrix
 // waves' only VALU-bound phase (12 % of a step), so the f16 form is spelled out: v_cvt_pk_f16_f32 for hi, x - hi straight from
-// the packed f16 halves with v_fma_mix_f32 (hi * -1.0 + x: exact, the same value as converting back and subtracting), one more
+// the packed f16 halves with v_fma_mix_f32 (sub_f16_lo / _hi, gnn_fused_common.h: hi * -1.0 + x, exact, the same value as
+// converting back and subtracting), one more
 // v_cvt_pk for lo: 4 instructions per pair instead of 6; LeakyReLU as a raw v_max_f32 (vmax_raw, gnn_fused_common.h: hipcc wraps
 // fmaxf of values it cannot prove quiet in two canonicalising v_max: 2 more per pair).  NaN stays NaN (max(NaN, 0.1 NaN)); 7 instead of 10 per pair.
-__device__ __forceinline__ float sub_f16_lo(float x, uint32_t h) {      // x - (float)(low half of h)
-    float d;
-    asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=v"(d) : "v"(h), "v"(x));
-    return d;
-}
-__device__ __forceinline__ float sub_f16_hi(float x, uint32_t h) {      // x - (float)(high half of h)
-    float d;
-    asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(d) : "v"(h), "v"(x));
-    return d;
-}
 template <bool F16>
 __device__ __forceinline__ void split2(f32x2 v, uint32_t& hi, uint32_t& lo) {
     if constexpr (F16) {
