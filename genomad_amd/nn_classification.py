@@ -230,6 +230,16 @@ def _engine():
 
 
 F16_MODES = ("f16c8", "f16c6", "f16x3")     # their operands are f16: activations beyond 65504 overflow to inf -> NaN scores
+
+
+def configured_precision() -> str:
+    """GENOMAD_AMD_PRECISION if set (one of the library's arithmetic names), else the default; an unknown name is an error
+    before anything is read or written, not a KeyError in the middle of a run."""
+    from ._lib import PRECISIONS
+    name = os.environ.get("GENOMAD_AMD_PRECISION", DEFAULT_PRECISION)
+    if name not in PRECISIONS:
+        raise ValueError(f"GENOMAD_AMD_PRECISION={name!r}: expected one of {sorted(PRECISIONS)} (default {DEFAULT_PRECISION})")
+    return name
 _WARNED = set()
 
 
@@ -258,7 +268,7 @@ class GpuBackend:
     def __init__(self, batch_size: int):
         self.eng = _engine()
         self.chunk = max(int(batch_size), 4096)
-        self.precision = os.environ.get("GENOMAD_AMD_PRECISION", DEFAULT_PRECISION)
+        self.precision = configured_precision()
 
     def score(self, windows: np.ndarray) -> np.ndarray:
         out = []
@@ -299,6 +309,7 @@ def main(input_path, output_path, single_window, batch_size, restart, threads, v
     :class:`genomad_amd.rccl.RcclComm`, and fails without a GPU."""
     from . import rccl, sharding
     rccl.prepare_env()        # before ANY HIP call: drops the reference's CUDA_VISIBLE_DEVICES=-1 (:8)
+    configured_precision()    # a mistyped GENOMAD_AMD_PRECISION stops here
     input_path, output_path = Path(input_path), Path(output_path)
     if _comm is not None:
         comm = _comm
@@ -444,7 +455,7 @@ def main(input_path, output_path, single_window, batch_size, restart, threads, v
                 z = np.load(npz_path)
                 names, predictions = z[names_key], z["predictions"]
         else:
-            precision = os.environ.get("GENOMAD_AMD_PRECISION", DEFAULT_PRECISION)
+            precision = configured_precision()
             eng = _engine()
             parts = []
             if sequence.compression_of(fasta) == "uncompressed":

@@ -901,3 +901,20 @@ def test_bench_cli_self_launch_reaches_the_ranks(tmp_path):
     assert r.returncode != 0
     assert "needs a launch with" not in r.stderr
     assert "rank" in r.stderr and "exited with" in r.stderr          # the launcher's report of the first failing rank
+
+
+def test_unknown_precision_name_is_refused_up_front(tmp_path, monkeypatch):
+    """GENOMAD_AMD_PRECISION is the one knob a user of the drop-in sets by hand: a typo must stop main() before it creates the
+    output directory's contents, with the valid names in the message."""
+    monkeypatch.setenv("GENOMAD_AMD_PRECISION", "f16x4")
+    with pytest.raises(ValueError, match="f16x3"):
+        nnc.configured_precision()
+    fa = tmp_path / "a.fna"
+    fa.write_text(">c1\n" + "ACGT" * 800 + "\n")
+    with pytest.raises(ValueError, match="GENOMAD_AMD_PRECISION"):
+        nnc.main(fa, tmp_path / "out", False, 128, True, 1, False, False)
+    assert not (tmp_path / "out" / "a_nn_classification").exists()
+    monkeypatch.setenv("GENOMAD_AMD_PRECISION", "bf16x3")
+    assert nnc.configured_precision() == "bf16x3"
+    monkeypatch.delenv("GENOMAD_AMD_PRECISION")
+    assert nnc.configured_precision() == nnc.DEFAULT_PRECISION == "f16x3"
