@@ -226,9 +226,13 @@ def main():
     args.gpus = world                    # under a launcher the launcher's world is the truth
 
     weights = synthetic.synth_weights()
-    if args.share_devices:
-        n_dev = ctypes.c_int()
-        _lib.check(_lib.load().gnn_device_count(ctypes.byref(n_dev)))
+    n_dev = ctypes.c_int()
+    _lib.check(_lib.load().gnn_device_count(ctypes.byref(n_dev)))
+    if local_rank >= max(n_dev.value, 1):
+        # fewer visible GPUs than ranks (e.g. `--gpus 2` on a one-GPU box): the rank shares device r mod D, so that the launch
+        # runs as far as RCCL's own duplicate-device check instead of stopping at the device index
+        print(f"bench.py: rank {rank}: {n_dev.value} device(s) visible for {world} ranks, using device {local_rank % max(n_dev.value, 1)} "
+              f"(RCCL refuses two ranks on one device)", file=sys.stderr)
         local_rank %= max(n_dev.value, 1)
     eng = NNEngine(local_rank, weights, chunk=args.chunk)
     info = eng.device_info()
