@@ -13,6 +13,10 @@ What it restates (reference paths are relative to /root/reference):
   genomad/neural_network/igloo.py:30-83, :117-217 (forward pass only).
 * ``keras_shim`` / ``reference_harness`` – no restatement: they run the reference's files where
   they lie (numba / tensorflow / keras replaced by minimal stand-ins).
+* ``make_golden`` / ``make_golden_config2`` – generate the committed fixtures of ``tests/golden/`` from them (config 2: all
+  10 000 windows; config 3: every 512th of its 1 048 576 windows).
+* ``precision_study`` / ``precision_mixes`` – numpy emulation of MFMA operand formats (which arithmetic keeps the scores
+  inside the tolerance, and with what margin); design aids, not checkers.
 
 Pinning status
 --------------
