@@ -54,6 +54,10 @@ ENCODER_BYTES = {"u8": 6000 + 5997 * 257, "bf16": 6000 + 5997 * 257 * 2, "f32": 
 HBM_PEAK_GBS = 8000.0
 # matrix-pipe cost of one product in units of one bf16/f16 pass (f16c8: 1 f16 pass + 2 fp8 corrections at 2x rate)
 MFMA_PASSES = {"f16c6": 1.5, "f16c8": 2.0, "f16x3": 3.0, "bf16x3": 3.0, "bf16": 1.0}
+# the dominant kernel as rocprofv3's kernel trace names it (profiles/*/kernel_stats.csv)
+FRONT_KERNEL = {"f16x3": "gnn::x3::fused_front_x3_kernel<true, false>", "bf16x3": "gnn::x3::fused_front_x3_kernel<false, false>",
+                "f16c6": "gnn::c6::fused_front_c6_kernel", "f16c8": "gnn::c8::fused_front_c8_kernel",
+                "bf16": "gnn::fused_front_kernel<1, false, false>", "f32": "f32 front end (5 kernels)"}
 DTYPE_TEXT = {"f16c6": "f16 MFMA + MX-fp6 (e2m3, both operands block scaled) correction MFMAs, f32 accumulate (1.5 f16-pass equivalents)",
               "f16c8": "f16 MFMA + MX-fp8 (e4m3) correction MFMAs, f32 accumulate (2.0 bf16-pass equivalents)",
               "f16x3": "f16x3 (split-f16 MFMA, 3 passes, f32 accumulate; logits GEMM split-f16 x 3 as well, dense head exact f32)",
@@ -170,6 +174,26 @@ def spawn_ranks(n: int, cmd, env=None) -> int:
         shutil.rmtree(rdzv, ignore_errors=True)
 
 
+def make_engine(local_rank: int, weights, chunk: int):
+    """(engine, visible device count, local_rank used).  GENOMAD_AMD_BENCH_FAKE_ENGINE=1 swaps in tests/fake_engine.py — a CPU
+    stand-in that exists so that the multi-rank plumbing of this file (spawn, shards, gather, the line's fields) can be
+    exercised on a box without GPUs; its line says so ("fake_engine": true) and is not a measurement."""
+    if os.environ.get("GENOMAD_AMD_BENCH_FAKE_ENGINE") == "1":
+        from tests import fake_engine
+        return fake_engine.FakeEngine(local_rank, weights, chunk), 8, local_rank
+    from genomad_amd import _lib
+    from genomad_amd.engine import NNEngine
+    n_dev = ctypes.c_int()
+    _lib.check(_lib.load().gnn_device_count(ctypes.byref(n_dev)))
+    if local_rank >= max(n_dev.value, 1):
+        # fewer visible GPUs than ranks (e.g. `--gpus 2` on a one-GPU box): the rank shares device r mod D, so that the launch
+        # runs as far as RCCL's own duplicate-device check instead of stopping at the device index
+        print(f"bench.py: local rank {local_rank}: {n_dev.value} device(s) visible, using device {local_rank % max(n_dev.value, 1)} "
+              f"(RCCL refuses two ranks on one device)", file=sys.stderr)
+        local_rank %= max(n_dev.value, 1)
+    return NNEngine(local_rank, weights, chunk=chunk), n_dev.value, local_rank
+
+
 def main():
     from genomad_amd._lib import DEFAULT_PRECISION
     ap = argparse.ArgumentParser()
@@ -202,9 +226,10 @@ def main():
                     "steps x gbp-per-step per GPU); BASELINE configs[4] is 60")
     ap.add_argument("--gbp-per-step", type=float, default=0.6, help="metagenome: Gbp resident in HBM per step and GPU")
     ap.add_argument("--force-dist", action="store_true", help="(kept for old command lines: the communicator is always created now)")
-    ap.add_argument("--fast-mode-steps", type=int, default=4,
+    ap.add_argument("--fast-mode-steps", type=int, default=0,
                     help="after the timed region, time this many steps with the opt-in fast arithmetic f16c6 as well and report it "
-                         "beside the default's line (0 = skip); it never enters `value`")
+                         "beside the default's line (default 0 = skip: the mode cannot ship - it leaves the 1e-4 tolerance on 10^6 windows); it "
+                         "never enters `value`")
     ap.add_argument("--power", action="store_true",
                     help="sample `rocm-smi --showpower` of this rank's GPU on a helper thread during the timed region: mean watts and "
                          "joules per window in the line")
@@ -219,24 +244,23 @@ def main():
 
     import numpy as np
     from genomad_amd import _lib, rccl, sharding, synthetic
-    from genomad_amd.engine import NNEngine
 
     rccl.prepare_env()
     rank, world, local_rank = rccl.world_from_env()
     args.gpus = world                    # under a launcher the launcher's world is the truth
 
     weights = synthetic.synth_weights()
-    n_dev = ctypes.c_int()
-    _lib.check(_lib.load().gnn_device_count(ctypes.byref(n_dev)))
-    if local_rank >= max(n_dev.value, 1):
-        # fewer visible GPUs than ranks (e.g. `--gpus 2` on a one-GPU box): the rank shares device r mod D, so that the launch
-        # runs as far as RCCL's own duplicate-device check instead of stopping at the device index
-        print(f"bench.py: rank {rank}: {n_dev.value} device(s) visible for {world} ranks, using device {local_rank % max(n_dev.value, 1)} "
-              f"(RCCL refuses two ranks on one device)", file=sys.stderr)
-        local_rank %= max(n_dev.value, 1)
-    eng = NNEngine(local_rank, weights, chunk=args.chunk)
+    # The CPU baseline runs on rank 0 at EVERY N (north_star: "next to the reference CPU path timed on the same box's host cores in
+    # the same run"), before the engine and the communicator exist: the other ranks wait for rank 0's RCCL unique id meanwhile
+    # (RcclComm polls for up to 10 minutes), no GPU work is in flight and nothing timed has started.
+    cpu_base, cpu_scores = None, None
+    if rank == 0 and args.cpu_sample > 0 and args.kernel == "classify" and args.workload == "windows":
+        cpu_base, cpu_scores = cpu_baseline(weights, args.cpu_sample)
+    eng, _n_dev, local_rank = make_engine(local_rank, weights, args.chunk)
     info = eng.device_info()
-    comm = rccl.RcclComm(eng, rank, world)          # always: the N = 1 line takes the same RCCL path as N = 8
+    t_ci = time.perf_counter()
+    comm = rccl.RcclComm(eng, rank, world, timeout=600.0)   # always: the N = 1 line takes the same RCCL path as N = 8
+    comm_init_s = time.perf_counter() - t_ci
     rccl_ranks, rccl_rank = ctypes.c_int(), ctypes.c_int()
     _lib.check(eng.lib.gnn_comm_info(eng.ctx, ctypes.byref(rccl_ranks), ctypes.byref(rccl_rank)))
     assert rccl_ranks.value == world and rccl_rank.value == rank
@@ -379,18 +403,30 @@ def main():
     t_own = time.perf_counter() - t0             # this rank's own K steps (reported per rank; `value` uses the max below)
     watts = sampler.stop() if sampler is not None else []
     # ONE gather of every rank's (n_local, 3) f32 scores to rank 0 (ncclGather over xGMI; at N = 1 the same call) ...
+    t_g = time.perf_counter()
     comm.gather_dev(scores.ptr, gathered_dev.ptr if gathered_dev is not None else None, n_local * 12, 0)
     host_scores = None
     if rank == 0:                 # ... and on to the host of rank 0, still inside the timed region
         host_scores = gathered_dev.download((total, 3), np.float32)
+    else:
+        eng.sync()
+    gather_ms = (time.perf_counter() - t_g) * 1e3     # on rank 0: includes waiting for the slowest rank's last step
     barrier()
     dt = max_over_ranks(time.perf_counter() - t0)
     own_us = comm.allgather_i64([int(t_own * 1e6)])[:, 0]
+    # the same gather once more, untimed and between barriers (no rank is still computing): what the collective itself costs,
+    # so that a slow first RCCL call cannot be mistaken for poor scaling
+    barrier()
+    t_g2 = time.perf_counter()
+    comm.gather_dev(scores.ptr, gathered_dev.ptr if gathered_dev is not None else None, n_local * 12, 0)
+    eng.sync()
+    gather_ms_isolated = max_over_ranks((time.perf_counter() - t_g2) * 1e3)
 
     kid = _lib.K_F32_FRONT if args.precision == "f32" else _lib.K_FUSED
     front_ms, front_launches = eng.profile_get(kid)
     back_ms, _ = eng.profile_get(_lib.K_BACKEND)
     eng.profile_enable(False)
+    front_us_ranks = comm.allgather_i64([int(front_ms * 1e3), int(front_launches)])
 
     # ---- untimed: the opt-in fast arithmetic on the same steps, for the record (f16c6: 1.5 MFMA pass equivalents; it does NOT hold
     # the 1e-4 tolerance on 10^6 windows, which is why it is not the default and never enters `value`)
@@ -459,6 +495,10 @@ def main():
             "dtype": DTYPE_TEXT[args.precision], "data": "synthetic",
             "rccl_ranks": int(rccl_ranks.value),
             "per_rank_windows_per_s": [round(n_local / (u * 1e-6), 1) for u in own_us.tolist()],
+            "per_rank_steps_ms": [round(u * 1e-3, 2) for u in own_us.tolist()],
+            "per_rank_front_ms_total": [round(u * 1e-3, 2) for u in front_us_ranks[:, 0].tolist()],
+            "gather_ms": round(gather_ms, 3), "gather_ms_isolated": round(gather_ms_isolated, 3),
+            "comm_init_s": round(comm_init_s, 3),
             "config": {"workload": f"{total} synthetic 6 kbp windows ({K} steps x {wps}{' per GPU' if args.scaling == 'weak' else ''}), "
                                    f"{'sharded contiguously over' if args.scaling == 'strong' else 'on each of'} {world} GPU(s) "
                                    f"= {n_local} per GPU, synthetic weights of the reference shapes, HBM-resident input, "
@@ -487,7 +527,7 @@ def main():
             "bound": "mfma", "achieved": round(tflops, 2), "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
             "frac": round(tflops / MFMA_PEAK_TFLOPS, 4), "traffic": traffic, "traffic_source": traffic_source,
             "algorithmic_bytes_per_launch": int(6012 * win_per_launch),
-            "kernel": {"f16c6": "fused_front_c6_kernel", "f16c8": "fused_front_c8_kernel", "f32": "f32 front end (5 kernels)"}.get(args.precision, "fused_front_kernel"),
+            "kernel": FRONT_KERNEL[args.precision],
             "flop_per_launch": int(FLOP_PER_WINDOW * win_per_launch), "avg_launch_ms": round(avg_ms, 4),
             "launches": int(front_launches), "mfma_passes": passes,
             "note": "achieved counts ALGORITHMIC flops (2.763 GFLOP/window) against the dense 16-bit MFMA peak; the "
@@ -540,10 +580,13 @@ def main():
                 failed.append(f"max |dscore| {out['max_abs_dscore']:.3e} against the reference-graph golden exceeds 1e-4")
         out["steps_verified"] = {"windows_all_ranks": int(total), "mismatching_windows_all_ranks": mismatching,
                                  "against": "untimed re-run of every step through the synchronous gnn_classify_dev, bit for bit"}
-        if world == 1 and args.cpu_sample > 0:
-            base, cpu_scores = cpu_baseline(weights, args.cpu_sample)
-            out["cpu_baseline"] = base
-            out["max_abs_dscore_vs_cpu_baseline"] = float(np.abs(host_scores[:args.cpu_sample] - cpu_scores).max())
+        if cpu_base is not None:
+            out["cpu_baseline"] = cpu_base
+            if args.scaling == "strong" or world == 1:      # host_scores[:sample] are the job's first windows = the CPU sample
+                out["max_abs_dscore_vs_cpu_baseline"] = float(np.abs(host_scores[:args.cpu_sample] - cpu_scores).max())
+        if os.environ.get("GENOMAD_AMD_BENCH_FAKE_ENGINE") == "1":
+            out["fake_engine"] = True
+            out["data"] = "FAKE ENGINE on the CPU (tests/fake_engine.py): a test of this file's multi-rank plumbing, not a measurement"
         if failed:
             out["failed"] = failed
         print(json.dumps(out), flush=True)

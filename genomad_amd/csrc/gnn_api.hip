@@ -1,5 +1,8 @@
 // Host side of the C ABI declared in include/genomad_nn.h.
 #include <algorithm>
+#include <map>
+#include <mutex>
+#include <cstdio>
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
@@ -10,6 +13,22 @@ namespace gnn {
 
 static thread_local std::string g_last_error;
 void set_error(const std::string& msg) { g_last_error = msg; }
+
+// Debug / measurement switches read from the environment (GNN_ASYNC_EVENT_WAIT, GNN_NO_BACKEND_OVERLAP, GNN_DEBUG_POISON,
+// GNN_X3_ROUND1, GNN_NO_PAD_SKIP, GNN_LOGITS_F32): each is read ONCE per process, and a switch that is set says so on stderr -
+// a stray variable in a user's environment must not silently change ordering or arithmetic.
+bool debug_switch(const char* name) {
+    static std::mutex mu;
+    static std::map<std::string, bool> seen;
+    std::lock_guard<std::mutex> lock(mu);
+    auto it = seen.find(name);
+    if (it != seen.end()) return it->second;
+    const bool on = std::getenv(name) != nullptr;
+    if (on)
+        std::fprintf(stderr, "libgenomad_nn_hip: debug switch %s is set: NOT the production path (ordering or arithmetic may differ)\n", name);
+    seen[name] = on;
+    return on;
+}
 
 struct ProfScope {
     gnn_ctx* ctx;
@@ -169,7 +188,7 @@ static int check_ctx(gnn_ctx* ctx, bool flush = true) {
     GNN_HIP(hipSetDevice(ctx->device));
     if (!flush) return GNN_OK;
     // GNN_ASYNC_EVENT_WAIT=1 (scripts/async_hunt.py only): the ordering round 2 first shipped, an event wait on ctx->stream
-    static const bool event_wait = std::getenv("GNN_ASYNC_EVENT_WAIT") != nullptr;
+    static const bool event_wait = debug_switch("GNN_ASYNC_EVENT_WAIT");
     return event_wait ? flush_backend(ctx) : finish_pending(ctx);
 }
 
@@ -294,7 +313,7 @@ int classify_chunks(gnn_ctx* ctx, const uint8_t* bases_dev, int64_t n, int preci
     // HBM-bound kernels, 5 % of the time) is enqueued on a second stream and runs beside the front end of chunk i+1 (of this
     // call or of the next one), on whatever the power-bound fused kernel leaves idle between its workgroups; two workspaces
     // alternate.  GNN_NO_BACKEND_OVERLAP=1 disables it.
-    static const bool allow_overlap = std::getenv("GNN_NO_BACKEND_OVERLAP") == nullptr;
+    static const bool allow_overlap = !debug_switch("GNN_NO_BACKEND_OVERLAP");
     const bool pending = ctx->back_pending[0] || ctx->back_pending[1];
     if (pending && (f32 || !allow_overlap)) {
         if ((rc = flush_backend(ctx))) return rc;
@@ -326,15 +345,19 @@ int classify_chunks(gnn_ctx* ctx, const uint8_t* bases_dev, int64_t n, int preci
         // GNN_DEBUG_POISON=1 (debug aid): every workspace tensor is filled with NaN bit patterns before the front end runs,
         // so a kernel that reads something this launch has not written yet turns the scores into NaN instead of reading the
         // previous launch's values (which are the right ones whenever the same windows are classified again)
-        static const bool poison = std::getenv("GNN_DEBUG_POISON") != nullptr;
+        static const bool poison = debug_switch("GNN_DEBUG_POISON");
         if (poison) {
+            // ctx->ws is the workspace THIS chunk's front end writes (the swap happens after the launch); every tensor was sized
+            // for ws.chunk >= m windows by ensure_ws above, for the f32 path as for the fused ones
             const Workspace& ws = ctx->ws;
-            GNN_HIP(hipMemsetAsync(ws.mp, 0xFF, (size_t)m * 2 * NPAIR * sizeof(float), guard.main));
-            GNN_HIP(hipMemsetAsync(ws.m, 0xFF, (size_t)m * 2 * NP * sizeof(float), guard.main));
-            GNN_HIP(hipMemsetAsync(ws.yp, 0xFF, (size_t)m * 2 * POOLED * C * sizeof(float), guard.main));
-            GNN_HIP(hipMemsetAsync(ws.logits, 0xFF, (size_t)m * 2 * POOLED * sizeof(float), guard.main));
-            GNN_HIP(hipMemsetAsync(ws.alpha, 0xFF, (size_t)m * 2 * POOLED * sizeof(float), guard.main));
-            GNN_HIP(hipMemsetAsync(ws.feat, 0xFF, (size_t)m * FEAT * sizeof(float), guard.main));
+            const size_t mm = (size_t)std::min<int64_t>(m, ws.chunk);
+            auto fill = [&](float* p, size_t per_window) -> int {
+                if (p && mm) GNN_HIP(hipMemsetAsync(p, 0xFF, mm * per_window * sizeof(float), guard.main));
+                return GNN_OK;
+            };
+            if ((rc = fill(ws.mp, 2 * NPAIR)) || (rc = fill(ws.m, 2 * NP)) || (rc = fill(ws.yp, (size_t)2 * POOLED * C)) ||
+                (rc = fill(ws.logits, 2 * POOLED)) || (rc = fill(ws.alpha, 2 * POOLED)) || (rc = fill(ws.feat, FEAT)))
+                return rc;
         }
         if (f32) {
             ProfScope ps(ctx, GNN_K_F32_FRONT);
@@ -343,7 +366,7 @@ int classify_chunks(gnn_ctx* ctx, const uint8_t* bases_dev, int64_t n, int preci
             ProfScope ps(ctx, GNN_K_FUSED);
             // the three-pass modes run the streaming kernel of gnn_fused_x3.hip; the round-1 kernel (gnn_fused.hip) keeps the
             // single-pass bf16 mode, window buffers that are not 4-byte aligned, and GNN_X3_ROUND1=1 (A/B measurements)
-            static const bool x3_round1 = std::getenv("GNN_X3_ROUND1") != nullptr;
+            static const bool x3_round1 = debug_switch("GNN_X3_ROUND1");
             const bool x3 = (precision == GNN_PREC_F16X3 || precision == GNN_PREC_BF16X3) && !x3_round1 &&
                             !(reinterpret_cast<uintptr_t>(b) & 3u);
             rc = precision == GNN_PREC_F16C6   ? launch_front_c6(ctx, b, m)
@@ -483,7 +506,7 @@ int gnn_create(int device, gnn_ctx** out) {
     }
     gnn_ctx* ctx = new gnn_ctx();
     ctx->device = device;
-    ctx->c6_pad_skip = std::getenv("GNN_NO_PAD_SKIP") == nullptr;
+    ctx->c6_pad_skip = !debug_switch("GNN_NO_PAD_SKIP");
     ctx->cu_count = prop.multiProcessorCount;
     hipError_t e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking);
     if (e != hipSuccess) {

@@ -479,6 +479,7 @@ int launch_backend(gnn_ctx* ctx, int64_t n, int precision, float* scores_dev) {
     hipLaunchKernelGGL(m_kernel, dim3((unsigned)n, 2), dim3(256), 0, ctx->stream, ws.mp, d.w_bias[0], d.w_bias[1],
                        d.slot[0], d.slot[1], ws.m);
     static_assert(QK_KSTEPS % 2 == 0 && QK_NBLK % 8 == 0, "logits_mfma_kernel tiling");
+    static const bool logits_f32 = debug_switch("GNN_LOGITS_F32");      // A/B measurements only
     const dim3 qk_grid(QK_NBLK / 8, (unsigned)((n + 63) / 64), 2);
     const uint4* qf0 = reinterpret_cast<const uint4*>(d.wqk_frag[0]);
     const uint4* qf1 = reinterpret_cast<const uint4*>(d.wqk_frag[1]);
@@ -486,7 +487,7 @@ int launch_backend(gnn_ctx* ctx, int64_t n, int precision, float* scores_dev) {
         hipLaunchKernelGGL(logits_mfma_kernel<3>, qk_grid, dim3(256), 0, ctx->stream, ws.m, qf0, qf1, (int)n, ws.logits);
     else if (precision == GNN_PREC_BF16)
         hipLaunchKernelGGL(logits_mfma_kernel<1>, qk_grid, dim3(256), 0, ctx->stream, ws.m, qf0, qf1, (int)n, ws.logits);
-    else if (precision == GNN_PREC_F16X3 && std::getenv("GNN_LOGITS_F32") == nullptr)
+    else if (precision == GNN_PREC_F16X3 && !logits_f32)
         // the default arithmetic: split-f16 x 3 on the matrix pipe (22 significant bits, f32 accumulate: f32 class; 0.25 instead of
         // 0.64 ms per 4096 windows for the exact-f32 VALU kernel, which GNN_LOGITS_F32=1 selects for A/B runs)
         hipLaunchKernelGGL((logits_mfma_kernel<3, true>), qk_grid, dim3(256), 0, ctx->stream, ws.m,

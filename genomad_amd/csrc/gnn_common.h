@@ -34,6 +34,7 @@ constexpr int QK_KSTEPS = (NP + 15) / 16;        // 132
 constexpr int QK_NBLK = (POOLED + 31) / 32;      // 24
 
 void set_error(const std::string& msg);
+bool debug_switch(const char* name);   // gnn_api.hip: environment switch read once, announced on stderr when set
 
 #define GNN_HIP(call)                                                                          \
     do {                                                                                       \

@@ -8,7 +8,9 @@ bytes, tagged with a hash of what identifies THIS launch and a timestamp, in a f
 directory under the node-local temp directory (created exclusively, renamed into place; a leftover of a
 crashed run is removed first and is never accepted by the readers: wrong tag or too old); the other ranks
 poll for it; every rank then runs ``ncclCommInitRank`` on its own device.  (One node, as the bench contract
-says; a shared directory can be named with GENOMAD_AMD_RDZV_DIR otherwise.)
+says.  Several nodes need a launcher that exports, identically on every node, GENOMAD_AMD_RDZV_DIR (a shared directory owned
+by the user who runs the ranks) AND GENOMAD_AMD_RDZV_PARENT or GENOMAD_AMD_RDZV_NONCE: without one of those the launch tag
+falls back to the parent pid, which differs between nodes, and the ranks would wait for different file names.)
 """
 import contextlib
 import ctypes as C
@@ -155,7 +157,9 @@ class RcclComm:
         global _SEQ
         self.engine, self.lib, self.ctx = engine, engine.lib, engine.ctx
         self.rank, self.world = int(rank), int(world)
-        path, tag = _id_file(_SEQ), _run_tag(_SEQ)
+        # the rendezvous file exists only for world > 1: a single rank neither creates nor checks the per-user directory
+        tag = _run_tag(_SEQ)
+        path = _id_file(_SEQ) if self.world > 1 else None
         _SEQ += 1
         uid = (C.c_uint8 * ID_BYTES)()
         if self.rank == 0:

@@ -168,7 +168,13 @@ def test_errors_are_reported_not_swallowed(engine):
 # f16c6 = f16 MFMA + MX-fp6 correction MFMAs, both operands block scaled (gnn_fused_c6.hip), f16c8 = f16 MFMA + MX-fp8
 # correction MFMAs (gnn_fused_c8.hip), f16x3 / bf16x3 = split-f16 / split-bf16, three passes (gnn_fused.hip).
 # Per-stage tolerances are absolute, against the fp64 oracle.
-FUSED = ["f16c6", "f16c8", "f16x3", "bf16x3"]
+# The parametrised matrix covers the arithmetics that can ship: the default (f16x3), its f32-range fallback (bf16x3) and the one
+# opt-in fast mode (f16c6).  f16c8 and the round-1 kernel are frozen: one smoke test each
+# (test_frozen_f16c8_kernel_smoke, test_single_pass_bf16_is_outside_tolerance_but_sane).
+FUSED = ["f16c6", "f16x3", "bf16x3"]
+# the contig front end is exercised with the default arithmetic first (what main() runs), then the fallback
+from genomad_amd._lib import DEFAULT_PRECISION  # noqa: E402
+CONTIG_PRECS = [DEFAULT_PRECISION, "bf16x3"]
 
 
 @pytest.mark.parametrize("prec", FUSED)
@@ -216,6 +222,14 @@ def test_fused_edge_windows(engine, synth_weights, prec):
     want = igloo_oracle.classify_windows(bases, synth_weights, np.float64)
     assert np.abs(got - want).max() <= SCORE_TOL
     assert engine.classify(bases[:0], prec).shape == (0, 3)
+
+
+def test_frozen_f16c8_kernel_smoke(engine, synth_weights):
+    """f16c8 (gnn_fused_c8.hip) is frozen: kept buildable and inside the tolerance on a small batch, no longer in the matrix."""
+    bases = synthetic.synth_windows(0, 64)
+    got = engine.classify(bases, "f16c8")
+    assert np.abs(got - igloo_oracle.classify_windows(bases, synth_weights, np.float32)).max() <= SCORE_TOL
+    assert np.array_equal(got[11:19], engine.classify(bases[11:19], "f16c8"))
 
 
 def test_f16c8_large_activations_saturate_instead_of_nan(synth_weights):
@@ -517,7 +531,8 @@ def test_config3_1m_windows_sharding_determinism_and_accuracy(engine, golden_dir
 
 
 # ------------------------------------------------------------------ contig front end
-def test_contig_front_end_equals_window_path(engine, synth_weights, golden_dir):
+@pytest.mark.parametrize("prec", CONTIG_PRECS)
+def test_contig_front_end_equals_window_path(engine, synth_weights, golden_dir, prec):
     """classify_contigs (device-side upper-casing/padding/N rule/segment mean on spans of the packed
     buffer) == reference windowing rules (golden FASTA fixture) + classify + segment mean."""
     from genomad_amd import sequence
@@ -525,10 +540,10 @@ def test_contig_front_end_equals_window_path(engine, synth_weights, golden_dir):
     names, seq, offsets = sequence.read_fasta_packed(path)
     g = json.load(open(os.path.join(golden_dir, "fasta_golden.json")))
     for single, key in ((False, "all"), (True, "single")):
-        contig_scores, ids = engine.classify_contigs(seq, offsets, single, "bf16x3")
+        contig_scores, ids = engine.classify_contigs(seq, offsets, single, prec)
         assert list(ids) == g[key]["contig_ids"]                 # N rule evaluated on the device
         _, ids_h, wins = sequence.encode_fasta(path, single)
-        want = engine.segment_mean(engine.classify(wins, "bf16x3"), ids_h, len(names))
+        want = engine.segment_mean(engine.classify(wins, prec), ids_h, len(names))
         assert np.array_equal(contig_scores, want)               # same windows -> same bits
         oracle = sequence_oracle.segment_mean(igloo_oracle.classify_windows(wins, synth_weights, np.float32), ids_h)
         assert np.abs(contig_scores - oracle).max() <= SCORE_TOL
@@ -536,7 +551,8 @@ def test_contig_front_end_equals_window_path(engine, synth_weights, golden_dir):
     assert empty.shape == (0, 3) and len(ids) == 0
 
 
-def test_config5_metagenome_contigs_resident_in_hbm(engine):
+@pytest.mark.parametrize("prec", CONTIG_PRECS)
+def test_config5_metagenome_contigs_resident_in_hbm(engine, prec):
     """BASELINE config 5 at reduced size: a 48 Mbp synthetic metagenome (mixed 1-500 kbp contigs,
     log-uniform) generated IN HBM, through the contig front end (spans -> N rule -> upper-case/pad ->
     encode+IGLOO -> per-contig mean), against the same rules applied on the host + the window path;
@@ -550,7 +566,7 @@ def test_config5_metagenome_contigs_resident_in_hbm(engine):
     try:
         engine.synth_windows_dev(0, nwin, buf.ptr)
         engine.sync()
-        got, ids = engine.classify_contigs_dev(buf.ptr, offsets, False, "bf16x3")
+        got, ids = engine.classify_contigs_dev(buf.ptr, offsets, False, prec)
         # host restatement of nn_classification.py:66-73 on the same bytes
         seq = synthetic.synth_windows(0, nwin).reshape(-1)
         starts, lens, cids, wn = sequence.candidate_spans(offsets)
@@ -560,13 +576,13 @@ def test_config5_metagenome_contigs_resident_in_hbm(engine):
         wins = np.full((int(keep.sum()), 6000), ord("N"), np.uint8)
         for r, i in enumerate(np.flatnonzero(keep)):
             wins[r, :lens[i]] = seq[starts[i]:starts[i] + lens[i]]
-        want = engine.segment_mean(engine.classify(wins, "bf16x3"), cids[keep], n_contigs)
+        want = engine.segment_mean(engine.classify(wins, prec), cids[keep], n_contigs)
         assert np.array_equal(got, want)
         assert got.shape == (n_contigs, 3) and np.allclose(got.sum(1), 1.0, atol=1e-5)
         # contigs shard embarrassingly: the two halves, classified separately, give the same bits
         h = n_contigs // 2
-        a, _ = engine.classify_contigs_dev(buf.ptr, offsets[:h + 1], False, "bf16x3")
-        b, _ = engine.classify_contigs_dev(buf.ptr + int(offsets[h]), offsets[h:] - offsets[h], False, "bf16x3")
+        a, _ = engine.classify_contigs_dev(buf.ptr, offsets[:h + 1], False, prec)
+        b, _ = engine.classify_contigs_dev(buf.ptr + int(offsets[h]), offsets[h:] - offsets[h], False, prec)
         assert np.array_equal(np.concatenate([a, b]), got)
         # host-side edits: lower-case bases are upper-cased on the device; a run of literal 'N' makes
         # the skip rule fire (window_n > 0 and > 4000 'N'), a run of lower-case 'n' does not count
@@ -578,7 +594,7 @@ def test_config5_metagenome_contigs_resident_in_hbm(engine):
         assert offsets[c1 + 1] - offsets[c1] > 40000
         mod[offsets[c0] + 6000:offsets[c0] + 6000 + 15000] = ord("N")
         mod[offsets[c1] + 12000:offsets[c1] + 12000 + 15000] = ord("n")
-        got_mod, ids_mod = engine.classify_contigs(mod, offsets, False, "bf16x3")
+        got_mod, ids_mod = engine.classify_contigs(mod, offsets, False, prec)
         keep2 = np.array([wn[i] == 0 or np.count_nonzero(mod[starts[i]:starts[i] + lens[i]] == ord("N")) <= 4000
                           for i in range(len(starts))])
         assert np.count_nonzero(~keep2 & (cids == c0)) == 2 and not np.any(~keep2 & (cids == c1))
@@ -587,7 +603,7 @@ def test_config5_metagenome_contigs_resident_in_hbm(engine):
         for r, i in enumerate(np.flatnonzero(keep2)):
             w = mod[starts[i]:starts[i] + lens[i]]
             wins2[r, :lens[i]] = np.where((w >= ord("a")) & (w <= ord("z")), w - 32, w)
-        want2 = engine.segment_mean(engine.classify(wins2, "bf16x3"), cids[keep2], n_contigs)
+        want2 = engine.segment_mean(engine.classify(wins2, prec), cids[keep2], n_contigs)
         assert np.array_equal(got_mod, want2)
     finally:
         buf.free()
@@ -677,22 +693,22 @@ def test_classify_contigs_entry_point_equals_span_level_path(engine):
     try:
         buf.upload(seq)
         for single in (False, True):
-            for prec in ("f16c8", "f32"):
+            for prec in (DEFAULT_PRECISION, "f32"):
                 want, want_ids = engine.classify_contigs_spans(buf.ptr, offsets, single, prec)
                 got_dev, ids_dev = engine.classify_contigs_dev(buf.ptr, offsets, single, prec)
                 got_host, ids_host = engine.classify_contigs(seq, offsets, single, prec)
                 assert np.array_equal(ids_dev, want_ids) and np.array_equal(ids_host, want_ids)
                 assert np.array_equal(got_dev, want) and np.array_equal(got_host, want), (single, prec)
         assert len(want_ids) == len(lengths)                          # single window: one per contig
-        full, full_ids = engine.classify_contigs(seq, offsets, False, "f16c8")
+        full, full_ids = engine.classify_contigs(seq, offsets, False, DEFAULT_PRECISION)
         assert len(full_ids) == sum(len(sequence.window_spans(n)) for n in lengths) - 1      # one dropped
         # a sub-table that starts in the middle of the buffer, and the empty table
-        sub, sub_ids = engine.classify_contigs(seq, offsets[7:], False, "f16c8")
+        sub, sub_ids = engine.classify_contigs(seq, offsets[7:], False, DEFAULT_PRECISION)
         assert np.array_equal(sub, full[7:]) and np.array_equal(sub_ids, full_ids[full_ids >= 7] - 7)
-        empty, e_ids = engine.classify_contigs(seq, offsets[:1], False, "f16c8")
+        empty, e_ids = engine.classify_contigs(seq, offsets[:1], False, DEFAULT_PRECISION)
         assert empty.shape == (0, 3) and len(e_ids) == 0
         with pytest.raises(Exception, match="offsets"):
-            engine.classify_contigs(seq, np.array([0, 50, 40, 60]), False, "f16c8")
+            engine.classify_contigs(seq, np.array([0, 50, 40, 60]), False, DEFAULT_PRECISION)
     finally:
         buf.free()
 

@@ -918,3 +918,32 @@ def test_unknown_precision_name_is_refused_up_front(tmp_path, monkeypatch):
     assert nnc.configured_precision() == "bf16x3"
     monkeypatch.delenv("GENOMAD_AMD_PRECISION")
     assert nnc.configured_precision() == nnc.DEFAULT_PRECISION == "f16x3"
+
+
+def test_bench_n8_line_is_complete_over_the_fake_engine(tmp_path):
+    """The driver's own command, `python bench.py --gpus 8 --steps 20 --warmup 5`, end to end on the CPU over tests/fake_engine.py
+    (GENOMAD_AMD_BENCH_FAKE_ENGINE=1): bench.py spawns its 8 ranks, shards the job contiguously, gathers the scores on rank 0
+    and prints ONE line that carries what an 8-GPU measurement has to be read with - `roofline`, `cpu_baseline` (rank 0, before
+    the communicator exists), `rccl_ranks` 8, one `per_rank_*` entry per rank, the gather's own duration and the communicator's
+    start-up time - and that passes its own parity checks (the fake serves the committed reference-graph scores)."""
+    import subprocess
+    root = Path(__file__).resolve().parents[1]
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT")}
+    env["GENOMAD_AMD_BENCH_FAKE_ENGINE"] = "1"
+    env["OPENBLAS_NUM_THREADS"] = "2"
+    r = subprocess.run([sys.executable, str(root / "bench.py"), "--gpus", "8", "--steps", "20", "--warmup", "5",
+                        "--windows-per-step", "1024", "--cpu-sample", "2"], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [json.loads(x) for x in r.stdout.splitlines() if x.startswith("{")]
+    assert len(lines) == 1
+    o = lines[0]
+    assert o["fake_engine"] is True and o["data"].startswith("FAKE ENGINE")
+    assert o["n_gpus"] == 8 and o["rccl_ranks"] == 8 and o["steps"] == 20 and o["warmup"] == 5 and o["scaling"] == "strong"
+    assert len(o["per_rank_windows_per_s"]) == len(o["per_rank_steps_ms"]) == len(o["per_rank_front_ms_total"]) == 8
+    assert o["gather_ms"] > 0 and o["gather_ms_isolated"] > 0 and o["comm_init_s"] > 0
+    assert o["roofline"]["kernel"] == "gnn::x3::fused_front_x3_kernel<true, false>" and o["roofline"]["bound"] == "mfma"
+    assert o["cpu_baseline"]["kind"] == "port" and o["cpu_baseline"]["value"] > 0 and o["max_abs_dscore_vs_cpu_baseline"] < 1e-4
+    assert o["parity"]["ok"] and o["parity"]["windows"] == 20 * 1024
+    assert o["steps_verified"]["mismatching_windows_all_ranks"] == 0
+    assert o["max_abs_dscore"] == 0.0 and o["dscore_windows"] == 10000       # rank 0 holds ALL gathered windows, in job order
+    assert "failed" not in o
