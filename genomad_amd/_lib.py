@@ -88,6 +88,7 @@ SIGNATURES = {
     "gnn_mfma_probe_kind": (_int, [_vp, _int, _int, C.POINTER(C.c_double)]),
     "gnn_fused_rows_per_step": (_int, [_int]),
     "gnn_debug_set_pad_skip": (_int, [_vp, _int]),
+    "gnn_debug_set_time_split": (_int, [_vp, _int]),
     "gnn_debug_pack_c6": (_int, [_f32p, _int, _int, C.POINTER(C.c_uint32), _sz, C.POINTER(_sz)]),
     "gnn_crc32c": (C.c_uint32, [_vp, _sz]),
     "gnn_fasta_scan": (_int, [_vp, _i64, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_int)]),

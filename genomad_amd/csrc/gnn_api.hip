@@ -433,6 +433,13 @@ int gnn_debug_set_pad_skip(gnn_ctx* ctx, int on) {
     return GNN_OK;
 }
 
+int gnn_debug_set_time_split(gnn_ctx* ctx, int on) {
+    int rc = check_ctx(ctx);
+    if (rc) return rc;
+    ctx->time_split = on != 0;
+    return GNN_OK;
+}
+
 int gnn_fused_rows_per_step(int precision) {
     switch (precision) {
         case GNN_PREC_F32: return 0;
@@ -507,6 +514,7 @@ int gnn_create(int device, gnn_ctx** out) {
     gnn_ctx* ctx = new gnn_ctx();
     ctx->device = device;
     ctx->c6_pad_skip = !debug_switch("GNN_NO_PAD_SKIP");
+    ctx->time_split = !debug_switch("GNN_NO_TIME_SPLIT");
     ctx->cu_count = prop.multiProcessorCount;
     hipError_t e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking);
     if (e != hipSuccess) {

@@ -139,6 +139,7 @@ struct gnn_ctx {
     std::vector<hipEvent_t> event_pool;
     std::vector<void*> owned;   // device allocations to free at destroy
     int cu_count = 0;
+    bool time_split = true;                       // x3 kernel: several workgroups per window when a launch is smaller than the chip (gnn_debug_set_time_split)
     bool c6_pad_skip = true;                      // f16c6: copy the all-N tail of a window instead of computing it (gnn_debug_set_pad_skip)
     unsigned long long* phase_cycles = nullptr;   // non-null: fused kernel runs its instrumented build
     gnn::ContigWorkspace* contig_ws = nullptr;    // gnn_contigs.hip: persistent buffers of gnn_classify_contigs

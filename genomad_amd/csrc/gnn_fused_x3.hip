@@ -64,6 +64,7 @@ struct Args {
     const float* yp_c;                // outputs of an all-N window (padding skip), nullptr = compute everything
     const float* mp_c;
     unsigned long long* cycles;       // PROF builds: 16 phase counters, matrix wave 0 -> 0..7, helper wave 4 -> 8..15
+    int split;                        // workgroups per window (time split for launches smaller than the chip, see the kernel)
 };
 
 struct WU {
@@ -371,6 +372,14 @@ struct PairCompute {
 //            epilogue -> bufY (x3) | B4 | w_v B(s) [bufY]   -> straight into step s+1
 //   helpers: pair products B(s-1) [bufY] and A(s) [bufX], gather(s+1) table loads | B1 | x1 carry rows | B2 |
 //            x1(s+1) -> bufX (both halves), read x2 carry | B3 | x2 carry rows -> bufY, pair rows of step s+2 | B4
+//
+// Time split (a.split > 1; launches with fewer windows than the chip has CUs, e.g. the reference's own call shape of 128 windows
+// per predict, nn_classification.py:316-317): a window's steps are dealt to a.split workgroups in contiguous runs.  A workgroup
+// whose run starts at step s_lo > 0 first executes step s_lo - 1 as a WARM-UP: everything is computed, nothing is stored (no yp
+// rows, no pair products).  Its carry rows start as zeros, so the first 5 rows of x2 and the first 10 of x3 of the warm-up step
+// are wrong - and unused: what step s_lo reads from it are the LAST 5 rows of x1 (a function of the bases alone) and of x2 (a
+// function of x1 rows at least 118 rows into the warm-up step).  Every stored row goes through the same instruction sequence
+// with the same operands as in the one-workgroup launch: bit-identical, one extra step per additional workgroup.
 template <bool F16, bool PROF>
 __global__ __launch_bounds__(512, 2) void fused_front_x3_kernel(Args a) {
     __shared__ __attribute__((aligned(16))) unsigned char smem[SMEMX];
@@ -385,7 +394,8 @@ __global__ __launch_bounds__(512, 2) void fused_front_x3_kernel(Args a) {
     const bool helper = wave >= 4;
     const int hw = wave & 3;
     const int ht = tid & 255;
-    const int64_t wi = blockIdx.x;
+    const int64_t wi = blockIdx.x / a.split;
+    const int part = blockIdx.x % a.split;
     const uint8_t* bases = a.bases + wi * W;
     float* mp_w[2] = {a.mp + (wi * 2 + 0) * NPAIR, a.mp + (wi * 2 + 1) * NPAIR};
     const int woff = hw * WNBLK_B;                       // this wave's n-block inside every k16 unit
@@ -406,18 +416,23 @@ __global__ __launch_bounds__(512, 2) void fused_front_x3_kernel(Args a) {
             if (base_code_f(bases[i]) >= 0) last = i;
         if (last >= 0) atomicMax(s_last, last);
     }
-    // pair rows of steps 0 and 1: prow2(s & 1)[i] = pair row of positions (t0 - 5 + i, t0 - 4 + i), t0 = s * FTX
+    __syncthreads();
+    const int nsteps = a.yp_c ? max(1, min(STEPSX, (*s_last + 1 + 15 + FTX - 1) / FTX)) : STEPSX;
+    // this workgroup's run of steps [s_lo, s_hi) and the step it starts executing at (one warm-up step for every run but the first)
+    const int per = (nsteps + a.split - 1) / a.split;
+    const int s_lo = min(part * per, nsteps), s_hi = min(s_lo + per, nsteps);
+    const int s_begin = s_hi > s_lo ? (s_lo > 0 ? s_lo - 1 : 0) : s_hi;      // an empty run (short window, padding skip) executes nothing
+    // pair rows of the first two steps executed: prow2(s & 1)[i] = pair row of positions (t0 - 5 + i, t0 - 4 + i), t0 = s * FTX
     if (tid < PROW_N) {
 #pragma unroll
         for (int s01 = 0; s01 < 2; ++s01) {
             uint32_t lo, hi;
-            const int t = s01 * FTX - CARRY + tid;
+            const int t = (s_begin + s01) * FTX - CARRY + tid;
             prow_fetch(bases, t, lo, hi);
-            prow2(s01)[tid] = prow_make(lo, hi, t);
+            prow2((s_begin + s01) & 1)[tid] = prow_make(lo, hi, t);
         }
     }
     __syncthreads();
-    const int nsteps = a.yp_c ? max(1, min(STEPSX, (*s_last + 1 + 15 + FTX - 1) / FTX)) : STEPSX;
     unsigned long long cyc[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     unsigned long long tick_ = 0;
     const int gpq = ht & 7, gua = (ht >> 3) * 2;         // conv1 gather: 2 * block + channel half, first row of the lane pair (+ 64 for the second round)
@@ -433,8 +448,9 @@ __global__ __launch_bounds__(512, 2) void fused_front_x3_kernel(Args a) {
         __syncthreads();                                                         // x1 of step 0 is in bufX
         if constexpr (PROF) tick_ = __builtin_readcyclecounter();
 #pragma unroll 1
-        for (int step = 0; step < nsteps; ++step) {
+        for (int step = s_begin; step < s_hi; ++step) {
             const int t0 = step * FTX;
+            const bool store = step >= s_lo;                                     // false in the warm-up step of a time-split run
             GNN_TICK(7)
             f32x16 acc[NMB];
 #pragma unroll
@@ -442,7 +458,7 @@ __global__ __launch_bounds__(512, 2) void fused_front_x3_kernel(Args a) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[mb][r] = 0.f;
             gemm_tile<false, F16, 1, KS>(smem, CARRY * ROWX, vw[0], cw[0], woff, ring, acc, lane);
-            wv_pool_store(acc, yp_w[0], t0, hw, lane);
+            if (store) wv_pool_store(acc, yp_w[0], t0, hw, lane);
             GNN_TICK(0)
             acc_init_bias(acc, bias_s, hw, lane);
 #ifndef GNN_ABL_NOCONV2
@@ -469,31 +485,34 @@ __global__ __launch_bounds__(512, 2) void fused_front_x3_kernel(Args a) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[mb][r] = 0.f;
             gemm_tile<false, F16, 1, 1>(smem, BUFX_BYTES + CARRY * ROWX, vw[1], vw[0], woff, ring, acc, lane);
-            wv_pool_store(acc, yp_w[1], t0, hw, lane);
+            if (store) wv_pool_store(acc, yp_w[1], t0, hw, lane);
         }
     } else {
         {
             GatherUnit g;
 #pragma unroll
             for (int k = 0; k < 2; ++k) {
-                gather_issue(g, prow2(0), a.conv1_k, gua + 64 * k, gpq);
+                gather_issue(g, prow2(s_begin & 1), a.conv1_k, gua + 64 * k, gpq);
                 gather_finish<F16>(g, bufX, gua + 64 * k, gpq);
             }
         }
         uint32_t nlo = 0, nhi = 0;                       // bytes of this thread's pair row of the step AFTER next
-        if (ht < PROW_N) prow_fetch(bases, 2 * FTX - CARRY + ht, nlo, nhi);
+        if (ht < PROW_N) prow_fetch(bases, (s_begin + 2) * FTX - CARRY + ht, nlo, nhi);
         __syncthreads();
         if constexpr (PROF) tick_ = __builtin_readcyclecounter();
 #pragma unroll 1
-        for (int step = 0; step < nsteps; ++step) {
+        for (int step = s_begin; step < s_hi; ++step) {
             const int t0 = step * FTX;
             const uint16_t* prow = prow2((step + 1) & 1);                        // pair rows of the next step: written before B4 of the previous one
             GNN_TICK(10)
             {
-                const int sb = max(step - 1, 0);                                 // step 0: empty head-B range
+                // head B's entries of step s-1 belong to this run if s-1 is one of its steps (not the warm-up step, whose x3 rows
+                // are not valid everywhere: the previous run computes them after its last step); head A's if s is
+                const bool hb = step - 1 >= s_lo, ha = step >= s_lo;
+                const int sb = max(step - 1, 0);
                 const PairJob jb = {bufY, a.weff[1], a.pos_sorted[1], mp_w[1], t0 - FTX,
-                                    step > 0 ? a.bucket_ptr[1][sb] : 0, step > 0 ? a.bucket_ptr[1][sb + 1] : 0};
-                const PairJob ja = {bufX, a.weff[0], a.pos_sorted[0], mp_w[0], t0, a.bucket_ptr[0][step], a.bucket_ptr[0][step + 1]};
+                                    hb ? a.bucket_ptr[1][sb] : 0, hb ? a.bucket_ptr[1][sb + 1] : 0};
+                const PairJob ja = {bufX, a.weff[0], a.pos_sorted[0], mp_w[0], t0, ha ? a.bucket_ptr[0][step] : 0, ha ? a.bucket_ptr[0][step + 1] : 0};
 #ifndef GNN_ABL_NOHELP
                 m_partials2<PairCompute<F16>>(jb, ja, hw, lane);
 #endif
@@ -549,12 +568,13 @@ __global__ __launch_bounds__(512, 2) void fused_front_x3_kernel(Args a) {
             __syncthreads();                                                     // ---- B4
             if constexpr (PROF) tick_ = __builtin_readcyclecounter();
         }
-        const PairJob jb = {bufY, a.weff[1], a.pos_sorted[1], mp_w[1], (nsteps - 1) * FTX, a.bucket_ptr[1][nsteps - 1],
-                            a.bucket_ptr[1][nsteps]};
-        const PairJob none = {bufX, a.weff[0], a.pos_sorted[0], mp_w[0], 0, 0, 0};
-        m_partials2<PairCompute<F16>>(jb, none, hw, lane);
+        if (s_hi > s_lo) {                                  // head B's entries of this run's last step
+            const PairJob jb = {bufY, a.weff[1], a.pos_sorted[1], mp_w[1], (s_hi - 1) * FTX, a.bucket_ptr[1][s_hi - 1], a.bucket_ptr[1][s_hi]};
+            const PairJob none = {bufX, a.weff[0], a.pos_sorted[0], mp_w[0], 0, 0, 0};
+            m_partials2<PairCompute<F16>>(jb, none, hw, lane);
+        }
     }
-    if (nsteps < STEPSX) {            // the all-N tail: copy instead of compute (disjoint from what the steps above wrote)
+    if (nsteps < STEPSX && part == a.split - 1) {   // the all-N tail: copy instead of compute (disjoint from what the steps above wrote)
         const int q0 = nsteps * (FTX / GNN_POOL);
         const int nrow4 = (POOLED - q0) * (C / 4);
         for (int i = tid; i < 2 * nrow4; i += 512) {
@@ -587,9 +607,11 @@ static void fill_args(const gnn_ctx* ctx, Args& a, const uint8_t* bases, bool f1
         a.bucket_ptr[i] = d.bucket_ptr[i];
     }
     a.cycles = nullptr;
+    a.split = 1;
 }
 
-static void launch(const Args& a, bool f16, bool prof, unsigned n, hipStream_t stream) {
+static void launch(const Args& a, bool f16, bool prof, unsigned nwin, hipStream_t stream) {
+    const unsigned n = nwin * (unsigned)a.split;
     if (f16) {
         if (prof) hipLaunchKernelGGL((fused_front_x3_kernel<true, true>), dim3(n), dim3(512), 0, stream, a);
         else hipLaunchKernelGGL((fused_front_x3_kernel<true, false>), dim3(n), dim3(512), 0, stream, a);
@@ -646,6 +668,9 @@ int launch_front_x3(gnn_ctx* ctx, const uint8_t* bases, int64_t n, int precision
     a.yp_c = ctx->c6_pad_skip ? ctx->w.x3_yp_const[f16] : nullptr;
     a.mp_c = ctx->c6_pad_skip ? ctx->w.x3_mp_const[f16] : nullptr;
     a.cycles = ctx->phase_cycles;
+    // fewer windows than CUs (one workgroup owns a CU): deal every window's steps to several workgroups.  Capped at 4: each
+    // additional workgroup recomputes one step of 47, and below 12 steps per run the prologue starts to show
+    if (ctx->time_split && n > 0 && ctx->cu_count > 0) a.split = (int)std::max<int64_t>(1, std::min<int64_t>(4, ctx->cu_count / n));
     launch(a, f16, ctx->phase_cycles != nullptr, (unsigned)n, ctx->stream);
     GNN_HIP(hipGetLastError());
     return GNN_OK;

@@ -309,6 +309,12 @@ int gnn_fused_rows_per_step(int precision);
  * default is on (environment GNN_NO_PAD_SKIP=1 turns it off at gnn_create). */
 int gnn_debug_set_pad_skip(gnn_ctx* ctx, int on);
 
+/* test aid: launches of the default arithmetic with fewer windows than the device has CUs (the reference's own call shape, one
+ * predict per 128 windows: nn_classification.py:316-317) deal every window's steps to up to 4 workgroups, each with one
+ * warm-up step (gnn_fused_x3.hip) - bit-identical to the one-workgroup launch by construction.  on = 0 launches one workgroup per
+ * window whatever the batch size; the default is on (environment GNN_NO_TIME_SPLIT=1 turns it off at gnn_create). */
+int gnn_debug_set_time_split(gnn_ctx* ctx, int on);
+
 /* test aid, host only (no GPU, no ctx): the f16c6 weight stream of a row-major K x N matrix (K multiple of 128, N of 32) as
  * gnn_load_weights builds it — per (k32 step, 32-column block) 3584 B: the f16 fragments of the two k16 halves (2 x 1 KiB:
  * lane l holds column l & 31, k = 16 s + 8 (l >> 5) + 0..7), the fp6 (e2m3) fragment dwords 0-3 (1 KiB) and 4-5 (512 B) of

@@ -967,3 +967,47 @@ def test_fresh_process_call_mix_is_bit_identical_40_times():
         if r.returncode != 0 or not last.startswith("OK"):
             bad.append((i, prec, last[:600], r.stderr[-300:]))
     assert not bad, bad
+
+
+def test_time_split_small_batches_are_bit_identical(engine):
+    """Launches smaller than the chip (the reference's call shape: one predict per 128 windows, nn_classification.py:316-317) deal
+    every window's 47 steps to up to 4 workgroups with one warm-up step each (gnn_fused_x3.hip).  Scores AND the spilled
+    intermediates (pair products behind m, pooled y @ w_v rows) must equal the one-workgroup launch bit for bit, for every batch
+    size on both sides of the thresholds, for padded / N-run / all-N / empty windows (padding skip on and off), and for the
+    fallback arithmetic; and the split launch must actually be faster at 128 windows."""
+    import time
+    from genomad_amd import _lib
+    wins = synthetic.synth_windows(3000, 130)
+    wins[7] = _pad(b"")                                    # all N: the padding skip leaves one step
+    wins[8] = _pad(b"ACGT" * 40)                           # 160 bases: 2 steps
+    wins[9] = _pad(b"ACGT" * 700)                          # 2800 bases
+    wins[10, 3000:3300] = ord("N")
+    try:
+        for prec in ("f16x3", "bf16x3"):
+            for n in (1, 2, 40, 64, 65, 86, 128, 130):
+                for skip in (1, 0):
+                    _lib.check(engine.lib.gnn_debug_set_pad_skip(engine.ctx, skip))
+                    _lib.check(engine.lib.gnn_debug_set_time_split(engine.ctx, 0))
+                    want, wt = engine.debug_forward(wins[:n], prec, taps=("m_a", "m_b", "yp_a", "yp_b"))
+                    _lib.check(engine.lib.gnn_debug_set_time_split(engine.ctx, 1))
+                    got, gt = engine.debug_forward(wins[:n], prec, taps=("m_a", "m_b", "yp_a", "yp_b"))
+                    assert np.array_equal(got, want), (prec, n, skip)
+                    for k in wt:
+                        assert np.array_equal(gt[k], wt[k]), (prec, n, skip, k)
+                if n > 40 and prec == "bf16x3":
+                    break                                  # the fallback: the small sizes are enough
+        _lib.check(engine.lib.gnn_debug_set_pad_skip(engine.ctx, 1))
+        # the point of it: one call of 128 windows through the host-buffer entry point
+        ms = {}
+        for on in (0, 1):
+            _lib.check(engine.lib.gnn_debug_set_time_split(engine.ctx, on))
+            engine.classify(wins[:128])
+            t = time.perf_counter()
+            for _ in range(20):
+                engine.classify(wins[:128])
+            ms[on] = (time.perf_counter() - t) / 20 * 1e3
+        print(f"gnn_classify of 128 windows: {ms[0]:.3f} ms one workgroup per window, {ms[1]:.3f} ms time split")
+        assert ms[1] < 0.75 * ms[0]
+    finally:
+        _lib.check(engine.lib.gnn_debug_set_time_split(engine.ctx, 1))
+        _lib.check(engine.lib.gnn_debug_set_pad_skip(engine.ctx, 1))
