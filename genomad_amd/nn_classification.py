@@ -351,24 +351,29 @@ def main(input_path, output_path, single_window, batch_size, restart, threads, v
     # shared.  The device front end runs it on a helper thread while the GPU already classifies; nothing is
     # written (no outputs, no execution info) before ``gate()`` has seen the verdict, so an invalid input
     # leaves the same state behind as in the reference, which checks first.
-    check_pool = concurrent.futures.ThreadPoolExecutor(max_workers=1) if (device_front_end and rank0) else None
-    check_future = check_pool.submit(sequence.check_fasta, input_path) if check_pool else None
-    if not device_front_end:
-        fail_on_bad_fasta(everywhere(sequence.check_fasta(input_path) if rank0 else True)[0])
-
     skip, changed = False, False                                               # :175-197
     if rank0 and (outputs.nn_classification_execution_info.exists() and any(p.exists() for p in output_files)
                   and not restart):
         skip = compare_executions(input_path, parameter_dict, outputs.nn_classification_execution_info)
         changed = not skip
     skip, changed = everywhere(skip, changed)
+    # With several ranks the validation is sharded like the classification: every rank collects the accessions of the records
+    # of ITS share while it reads it (no second pass over the file), and one gather of 64-bit digests decides
+    # (sharding.fasta_verdict).  Only when the main stage really reads the file: a resumed run that finds the scores on disk
+    # validates as before, on rank 0.
+    (sharded_check,) = everywhere(device_front_end and world > 1 and rank0
+                                  and not (skip and outputs.nn_classification_npz_output.exists()))
+    check_pool = concurrent.futures.ThreadPoolExecutor(max_workers=1) if (device_front_end and rank0 and not sharded_check) else None
+    check_future = check_pool.submit(sequence.check_fasta, input_path) if check_pool else None
+    if not device_front_end:
+        fail_on_bad_fasta(everywhere(sequence.check_fasta(input_path) if rank0 else True)[0])
     if skip:
         console.log("Previous execution detected. Steps will be skipped unless their outputs are not found. "
                     "Use the --restart option to force the execution of all the steps again.")
     elif changed:
         console.log("The input file or the parameters changed since the last execution. "
                     "Previous outputs will be overwritten.")
-    state = {"info_writer": None, "gated": False}
+    state = {"info_writer": None, "gated": False, "verdict": None}
     start_time = datetime.now(timezone.utc).astimezone().isoformat()
 
     def gate():
@@ -378,7 +383,9 @@ def main(input_path, output_path, single_window, batch_size, restart, threads, v
         if state["gated"]:
             return
         state["gated"] = True
-        if device_front_end:
+        if device_front_end and sharded_check:
+            fail_on_bad_fasta(state["verdict"])                  # decided by all ranks together in the main stage
+        elif device_front_end:
             fail_on_bad_fasta(everywhere(check_future.result() if rank0 else True)[0])
         if rank0:
             outputs.nn_classification_dir.mkdir(exist_ok=True)
@@ -458,13 +465,21 @@ def main(input_path, output_path, single_window, batch_size, restart, threads, v
             precision = configured_precision()
             eng = _engine()
             parts = []
+            validate = sharded_check and fasta is input_path        # the provirus FASTA is geNomad's own output: never validated
+            seen = []                                               # accessions of ALL records of this rank's share (validate)
+
+            def pack(text):
+                if validate:
+                    seen.extend(sequence.index_accessions(text))    # before the in-place pack consumes the text
+                return sequence.pack_text(text, strip_n=True)
+
             if sequence.compression_of(fasta) == "uncompressed":
                 # this rank's record-aligned share of the file, in pieces of about 128 MB: piece k+1
                 # is read and packed on a helper thread while the GPU classifies piece k
                 share = Path(fasta).stat().st_size // world
                 pieces = int(min(64, max(1, -(-share // (128 << 20)))))
-                read = lambda k: sequence.read_fasta_packed(  # noqa: E731
-                    fasta, True, sequence.record_aligned_range(fasta, rank, world, k, pieces))
+                read = lambda k: pack(sequence._read_text_array(  # noqa: E731
+                    fasta, sequence.record_aligned_range(fasta, rank, world, k, pieces)))
                 with concurrent.futures.ThreadPoolExecutor(max_workers=1) as pool:
                     nxt = pool.submit(read, 0)
                     for k in range(pieces):
@@ -479,9 +494,11 @@ def main(input_path, output_path, single_window, batch_size, restart, threads, v
                 for i, chunk in enumerate(sequence.iter_text_chunks(fasta)):
                     if i % world != rank:
                         continue
-                    nm, sq, off = sequence.pack_text(chunk, strip_n=True)
+                    nm, sq, off = pack(chunk)
                     pr, wid = classify_contigs_safely(eng, sq, off, single_window, precision, console)
                     parts.append((i, nm, pr, wid))
+            if validate:
+                state["verdict"] = sharding.fasta_verdict(comm, seen, lambda: sequence.check_fasta(input_path))
             names, predictions, ids, n_windows = sharding.gather_contig_parts(comm, parts)
             gate()
             if not n_windows:                                                        # :297-299
@@ -513,10 +530,27 @@ def main(input_path, output_path, single_window, batch_size, restart, threads, v
         if check_pool is not None:
             check_pool.shutdown(wait=True)
         if state["info_writer"] is not None:
-            state["info_writer"].join()
+            if os.environ.get("GENOMAD_AMD_DEFER_EXECUTION_INFO") == "1" and sys.exc_info()[0] is None:
+                # opt-in: do not wait for the input's md5 (one sequential pass at ~1 GB/s, utils.py:216-223 - with 8 GPUs it is
+                # the longest thing main() does).  The scores are on disk; the execution-info JSON appears, with the same
+                # content, when the digest is ready (a non-daemon thread: the process does not exit before).  A caller that
+                # runs the next geNomad module in the same process right away (end-to-end: aggregated-classification requires
+                # the JSON, aggregated_classification.py:101) must call wait_execution_info() first - hence opt-in.
+                _DEFERRED.append(state["info_writer"])
+            else:
+                state["info_writer"].join()
     if comm is not None:
         comm.barrier()               # rank 0 has written everything before any rank returns
     console.log("geNomad nn-classification finished!")
+
+
+_DEFERRED = []
+
+
+def wait_execution_info():
+    """Block until every execution-info JSON deferred by GENOMAD_AMD_DEFER_EXECUTION_INFO=1 has been written."""
+    while _DEFERRED:
+        _DEFERRED.pop().join()
 
 
 def install():

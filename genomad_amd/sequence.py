@@ -291,6 +291,12 @@ def iter_text_chunks(path, chunk_bytes: int = 128 << 20):
             yield np.frombuffer(bytearray(b"".join(carry)), dtype=np.uint8)
 
 
+def index_accessions(text: np.ndarray):
+    """Accessions of ALL records of a text array (no N stripping: what check_fasta counts), without consuming it."""
+    acc, _, _ = _pack(text, strip_n=False, copy=False)
+    return acc
+
+
 def pack_text(text: np.ndarray, strip_n: bool = True):
     """(names, seq, offsets) of the records in a writable text array (consumed: packed in place)."""
     names, seq, offsets = _pack(text, strip_n)

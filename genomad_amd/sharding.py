@@ -167,3 +167,35 @@ def broadcast_flags(comm, flags, root: int = 0):
     """Small ints decided on ``root`` (e.g. "skip this stage") made known to every rank."""
     got = comm.allgather_i64([int(f) for f in flags])
     return [int(v) for v in got[root]]
+
+
+def accession_digests(accessions) -> np.ndarray:
+    """64-bit digests (blake2b) of record accessions, as a uint64 array: what travels instead of the strings."""
+    import hashlib
+    out = np.empty(len(accessions), dtype="<u8")
+    for i, a in enumerate(accessions):
+        out[i] = int.from_bytes(hashlib.blake2b(a.encode("utf-8", "surrogateescape"), digest_size=8).digest(), "little")
+    return out
+
+
+def fasta_verdict(comm, accessions, exact_check, root: int = 0) -> bool:
+    """check_fasta (genomad/sequence.py:124-131: False for a file without records or with two records of one accession) when
+    every rank has seen only ITS records: ``accessions`` = the accessions of all records of this rank's share of the file (no N
+    stripping: records that the classification pass drops count).  Duplicates inside a share are found locally; across shares
+    by ONE gather of 64-bit digests to ``root``.  Equal digests on different ranks are either a true duplicate or a collision
+    (about 1e-7 for a million records): ``exact_check()`` - the sequential whole-file check - decides, on ``root`` only.  Every
+    rank returns the same verdict."""
+    comm = comm or LocalComm()
+    acc = list(accessions)
+    local_dup = len(set(acc)) != len(acc)
+    meta = comm.allgather_i64([len(acc), int(local_dup)])
+    blobs = gather_bytes(comm, accession_digests(acc).tobytes() if not meta[:, 1].any() else b"", root)
+    ok = True
+    if comm.rank == root:
+        if int(meta[:, 0].sum()) == 0 or meta[:, 1].any():
+            ok = False
+        else:
+            d = np.sort(np.concatenate([np.frombuffer(b, dtype="<u8") for b in blobs]))
+            if len(d) > 1 and bool((d[1:] == d[:-1]).any()):
+                ok = bool(exact_check())
+    return bool(broadcast_flags(comm, [ok], root)[0])

@@ -136,9 +136,13 @@ __device__ __forceinline__ void xi_tc(const WU& wc, WU& wl, const XV& vc, XV& vl
         vl.l = *reinterpret_cast<const uint4*>(vb + VOFFN + 1024);
     }
     if constexpr (LW) load_wu(wl, wr, l16, wnext);
+#ifdef NOMMA      // measurement variant: the helpers' transform and the barriers alone - what the helper code takes with the SIMD to itself
+    acc[0] += __uint_as_float(wc.l.x ^ vc.h.x) + __uint_as_float(wc.h.y ^ vc.l.y);
+#else
     acc = mma(wc.l, vc.h, acc);
     acc = mma(wc.h, vc.h, acc);
     acc = mma(wc.h, vc.l, acc);
+#endif
     __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
     if (LX) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
     if (LW) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
@@ -152,19 +156,29 @@ __device__ __forceinline__ void xi_tc(const WU& wc, WU& wl, const XV& vc, XV& vl
 // stand-in for the helpers' input transform of ONE k16 unit's quarter (a helper wave = 32 tiles x 2 halves, 2 channels per
 // lane): 8 input rows x 2 channels (hi | lo planes) -> f32, the 8-point transform B^T of the points {0, +-1, +-2, +-1/2, inf}
 // (26 VALU per channel), split into f16 hi | lo, 16 ds_write_b32 into the ring slot.  Same instruction mix as the real thing.
-__device__ __forceinline__ void helper_transform(unsigned char* smem, int unit, int slot, int hw, int lane) {
-    const int tile = lane & 31, half = lane >> 5;
-    const unsigned char* xr = smem + (3 * tile) * ROWX + (unit * 16 + half * 8 + hw * 2) * 2;
+struct HRaw {
+    uint32_t h[8], l[8];
+};
+__device__ __forceinline__ void helper_load(HRaw& r, const unsigned char* smem, int unit, int hw, int lane) {
+    // lane -> (tile, k half, channel pair) so that both the row reads and the fragment stores are bank-conflict free: the 4 lanes
+    // of a (tile, half) cover its 8 channels = 16 consecutive bytes; a wave covers 16 (tile, half) combinations
+    const int pr = lane & 3, th = hw * 16 + (lane >> 2), tile = th & 31, half = th >> 5;
+    const unsigned char* xr = smem + (3 * tile) * ROWX + (unit * 16 + half * 8 + pr * 2) * 2;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        r.h[j] = *reinterpret_cast<const uint32_t*>(xr + j * ROWX);
+        r.l[j] = *reinterpret_cast<const uint32_t*>(xr + j * ROWX + 256);
+    }
+}
+__device__ __forceinline__ void helper_transform(const HRaw& r, unsigned char* smem, int slot, int hw, int lane) {
     float d[8][2];
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
-        const uint32_t h = *reinterpret_cast<const uint32_t*>(xr + j * ROWX);
-        const uint32_t l = *reinterpret_cast<const uint32_t*>(xr + j * ROWX + 256);
-        const f16x2 hh = __builtin_bit_cast(f16x2, h), ll = __builtin_bit_cast(f16x2, l);
+        const f16x2 hh = __builtin_bit_cast(f16x2, r.h[j]), ll = __builtin_bit_cast(f16x2, r.l[j]);
         d[j][0] = (float)hh[0] + (float)ll[0];
         d[j][1] = (float)hh[1] + (float)ll[1];
     }
-    unsigned char* vo = smem + VOFF + slot * VSLOT + lane * 16 + hw * 4;
+    unsigned char* vo = smem + VOFF + slot * VSLOT + (hw * 64 + lane) * 4;     // fragment lane th = hw * 16 + (lane >> 2), its dword lane & 3
 #pragma unroll
     for (int c = 0; c < 2; ++c) {
         float v[8];
@@ -209,7 +223,9 @@ __device__ __forceinline__ void conv_tc(unsigned char* smem, rsrc_t wr, int woff
         constexpr int k = decltype(kc)::value, kn = (k + 1) % 64;          // k = unit * 8 + xi
         constexpr int VOFFN = ((kn / 8) % VRING) * VSLOT + (kn % 8) * 2048;
         constexpr int kw = (k + RINGT - 1) % 64;
-        if constexpr (HELP && k % 8 == 0 && k > 0) __syncthreads();       // the V ring's hand-over: one barrier per k16 unit
+        // the V ring's hand-over: one barrier per k16 unit.  A bare s_barrier: __syncthreads() would also drain this wave's weight
+        // loads in flight (s_waitcnt vmcnt(0)) and expose an L2 round trip per unit; the matrix waves wait for nothing of their own
+        if constexpr (HELP && k % 8 == 0 && k > 0) __builtin_amdgcn_s_barrier();
         if constexpr (k % 2 == 0)
             xi_tc<LW, LX, VOFFN>(ring[k % RINGT], ring[(k + RINGT - 1) % RINGT], va, vc, vb, wr, woff + kw * 8192, l16, acc[k % 8]);
         else
@@ -269,7 +285,7 @@ __global__ __launch_bounds__(512, 2) void probe_kernel(const unsigned char* wts,
                     for (int xi = 0; xi < 8; ++xi)
 #pragma unroll
                         for (int r = 0; r < 16; ++r) acc[xi][r] = 0.f;
-                    if constexpr (HELP) __syncthreads();
+                    if constexpr (HELP) __builtin_amdgcn_s_barrier();
                     conv_tc<LW, LX, HELP>(smem, wr, woff + cv * 64 * 8192, ring, acc, lane);
 #pragma unroll
                     for (int xi = 0; xi < 8; ++xi) s += acc[xi][0] + acc[xi][7];
@@ -282,12 +298,23 @@ __global__ __launch_bounds__(512, 2) void probe_kernel(const unsigned char* wts,
         for (int step = 0; step < steps; ++step) {
 #pragma unroll 1
             for (int cv = 0; cv < 2; ++cv) {
-                __syncthreads();
+                HRaw ra, rb;
+                helper_load(ra, smem + cv * 48 * 1024, 1, hw, lane);
+                __builtin_amdgcn_s_barrier();
 #pragma unroll 1
-                for (int u = 0; u < 8; ++u) {
-                    // while the matrix waves consume unit u (slot u % 3) the helpers fill the slot of unit u + 1
-                    helper_transform(smem + cv * 48 * 1024, (u + 1) & 7, (u + 1) % VRING, hw, lane);
-                    if (u < 7) __syncthreads();
+                for (int u = 0; u < 8; u += 2) {
+                    // while the matrix waves consume unit u (slot u % 3) the helpers fill the slot of unit u + 1; the rows of the
+                    // unit after that are requested before the transform (software pipeline: no LDS round trip per barrier interval)
+                    helper_load(rb, smem + cv * 48 * 1024, (u + 2) & 7, hw, lane);
+                    helper_transform(ra, smem, (u + 1) % VRING, hw, lane);
+                    asm volatile("s_waitcnt lgkmcnt(8)" ::: "memory");      // the 16 stores are out; the 16 loads of the next unit may still fly
+                    __builtin_amdgcn_s_barrier();
+                    helper_load(ra, smem + cv * 48 * 1024, (u + 3) & 7, hw, lane);
+                    helper_transform(rb, smem, (u + 2) % VRING, hw, lane);
+                    if (u < 6) {
+                        asm volatile("s_waitcnt lgkmcnt(8)" ::: "memory");
+                        __builtin_amdgcn_s_barrier();
+                    }
                 }
             }
         }
@@ -345,13 +372,15 @@ int main(int argc, char** argv) {
     const int windows = argc > 1 ? atoi(argv[1]) : 4096;
     const int WD = 2 * 48 * 8192, WT = 2 * 64 * 8192;
     printf("conv2 + conv3 loops only (no w_v, no epilogues, no conv1 / pair products); weights %d KB direct, %d KB Toom-Cook per step\n", WD / 1024, WT / 1024);
-    run<0, true, true, false>("direct: weights + LDS reads + MFMAs", windows, 47, WD, 128);
-    run<0, false, true, false>("direct: no weight stream", windows, 47, WD, 128);
-    run<0, false, false, false>("direct: MFMAs only", windows, 47, WD, 128);
-    run<1, true, true, false>("tc F(3,6): weights + LDS reads + MFMAs", windows, 63, WT, 96);
-    run<1, false, true, false>("tc F(3,6): no weight stream", windows, 63, WT, 96);
-    run<1, true, false, false>("tc F(3,6): no LDS reads", windows, 63, WT, 96);
-    run<1, false, false, false>("tc F(3,6): MFMAs only", windows, 63, WT, 96);
+    if (argc <= 2) {
+        run<0, true, true, false>("direct: weights + LDS reads + MFMAs", windows, 47, WD, 128);
+        run<0, false, true, false>("direct: no weight stream", windows, 47, WD, 128);
+        run<0, false, false, false>("direct: MFMAs only", windows, 47, WD, 128);
+        run<1, true, true, false>("tc F(3,6): weights + LDS reads + MFMAs", windows, 63, WT, 96);
+        run<1, false, true, false>("tc F(3,6): no weight stream", windows, 63, WT, 96);
+        run<1, true, false, false>("tc F(3,6): no LDS reads", windows, 63, WT, 96);
+        run<1, false, false, false>("tc F(3,6): MFMAs only", windows, 63, WT, 96);
+    }
     run<1, true, true, true>("tc F(3,6): all + helper transform + barriers", windows, 63, WT, 96);
     run<1, false, true, true>("tc F(3,6): helpers + barriers, no weights", windows, 63, WT, 96);
     return 0;

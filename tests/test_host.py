@@ -947,3 +947,131 @@ def test_bench_n8_line_is_complete_over_the_fake_engine(tmp_path):
     assert o["steps_verified"]["mismatching_windows_all_ranks"] == 0
     assert o["max_abs_dscore"] == 0.0 and o["dscore_windows"] == 10000       # rank 0 holds ALL gathered windows, in job order
     assert "failed" not in o
+
+
+# ------------------------------------------------------------------ sharded FASTA validation
+class _FakeContigEngine:
+    """classify_contigs of the device front end with a fixed function of the contig bytes in place of the network."""
+
+    def classify_contigs(self, seq, offsets, single_window=False, precision=None):
+        offsets = np.asarray(offsets, np.int64)
+        _, _, ids, _ = sequence.candidate_spans(offsets, single_window)
+        sc = np.zeros((len(offsets) - 1, 3), np.float32)
+        for c in range(len(offsets) - 1):
+            v = float(np.asarray(seq[offsets[c]:offsets[c + 1]], np.int64).sum() % 997) / 997
+            sc[c] = (v, (1 - v) / 2, (1 - v) / 2)
+        return sc, ids
+
+
+def _sharded_check_worker(rank, world, port, fasta, out_dir, q, collide):
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    os.environ.pop("GENOMAD_AMD_FRONT_END", None)
+    from genomad_amd import sharding
+    from tests.gloo_comm import GlooComm
+    nnc._engine = lambda: _FakeContigEngine()
+    calls = []
+    real_check = sequence.check_fasta
+    sequence.check_fasta = lambda p, *a, **k: (calls.append(rank), real_check(p, *a, **k))[1]
+    if collide:                                      # every accession gets the same digest: the exact check has to decide
+        sharding.accession_digests = lambda acc: np.zeros(len(acc), dtype="<u8")
+    comm = GlooComm(rank, world, port)
+    code = 0
+    try:
+        nnc.main(fasta, out_dir, False, 128, False, 1, False, False, _comm=comm)
+    except SystemExit as e:
+        code = e.code
+    q.put((rank, code, calls))
+    comm.close()
+
+
+def _run_sharded_main(tmp_path, fasta, world, collide=False):
+    mp = pytest.importorskip("torch.multiprocessing")
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    out = tmp_path / f"out_{world}_{int(collide)}_{fasta.stem}"
+    procs = [ctx.Process(target=_sharded_check_worker, args=(r, world, port, str(fasta), str(out), q, collide)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = sorted(q.get(timeout=180) for _ in procs)
+    for p in procs:
+        p.join(timeout=180)
+        assert p.exitcode == 0
+    return out, got
+
+
+def test_fasta_validation_is_sharded_with_the_contigs(tmp_path, monkeypatch):
+    """With several ranks the device front end validates the FASTA where it reads it: every rank collects the accessions of ITS
+    records (all of them: a record the N strip drops still counts, as in the reference's check_fasta, sequence.py:124-131), one
+    gather of 64-bit digests finds duplicates across ranks, and the sequential whole-file check runs only if two digests are
+    equal.  Same verdicts, same files and same exit status as one process; nothing is written for an invalid input."""
+    rng = np.random.default_rng(5)
+    recs = [(f"c{i} note", "".join(rng.choice(list("ACGT"), int(L)))) for i, L in enumerate(rng.integers(3000, 20000, 14))]
+    recs.insert(5, ("alln", "N" * 7000))                                       # dropped by the classification pass
+    good = tmp_path / "good.fna"
+    _write_fasta(good, recs)
+    monkeypatch.setattr(nnc, "_engine", lambda: _FakeContigEngine())
+    monkeypatch.delenv("GENOMAD_AMD_FRONT_END", raising=False)
+    nnc.main(good, tmp_path / "single", False, 128, False, 1, False, False)
+    ref = np.load(tmp_path / "single" / "good_nn_classification" / "good_nn_classification.npz")
+    assert "alln" not in list(ref["contig_names"]) and len(ref["contig_names"]) == 14
+    for world in (2, 3):
+        out, got = _run_sharded_main(tmp_path, good, world)
+        assert [g[1] for g in got] == [0] * world
+        assert all(g[2] == [] for g in got)                                     # the sequential check never ran
+        z = np.load(out / "good_nn_classification" / "good_nn_classification.npz")
+        assert list(z["contig_names"]) == list(ref["contig_names"]) and np.array_equal(z["predictions"], ref["predictions"])
+        assert json.load(open(out / "good_nn_classification" / "good_nn_classification.json"))["input_md5"] == nnc._md5_of(good)
+    # equal digests (forced): the exact check decides, on rank 0 only, and the run still succeeds
+    out, got = _run_sharded_main(tmp_path, good, 2, collide=True)
+    assert [g[1] for g in got] == [0, 0] and got[0][2] == [0] and got[1][2] == []
+    # duplicates: across ranks (first and last record), inside one rank (neighbours), and of a record that is all N
+    for name, edit in (("across", lambda r: r + [("c0 again", "ACGT" * 900)]),
+                       ("inside", lambda r: r[:2] + [("c1", "GGCC" * 900)] + r[2:]),
+                       ("dropped", lambda r: r + [("alln x", "ACGT" * 900)])):
+        bad = tmp_path / f"{name}.fna"
+        _write_fasta(bad, edit(list(recs)))
+        assert not sequence.check_fasta(bad)
+        out, got = _run_sharded_main(tmp_path, bad, 3)
+        assert [g[1] for g in got] == [1, 1, 1], name                          # every rank leaves through sys.exit(1) (:164-170)
+        assert not (out / f"{name}_nn_classification").exists()
+    empty = tmp_path / "empty.fna"
+    empty.write_text("")
+    out, got = _run_sharded_main(tmp_path, empty, 2)
+    assert [g[1] for g in got] == [1, 1]
+
+
+def test_deferred_execution_info_is_opt_in_and_writes_the_same_file(tmp_path, monkeypatch):
+    """GENOMAD_AMD_DEFER_EXECUTION_INFO=1: main() returns once the scores are on disk without waiting for the input's md5 (the
+    reference's contract, utils.py:216-254, and the longest sequential thing left with 8 GPUs); the JSON is written by the
+    background thread when the digest is ready, byte for byte what the default path writes (start time aside)."""
+    import threading
+    import time
+    fa = tmp_path / "a.fna"
+    _write_fasta(fa, [("c1", "ACGT" * 2000), ("c2", "GGCA" * 900)])
+    release = threading.Event()
+    real = nnc._md5_of
+
+    def slow(path, size=1 << 22):
+        release.wait(30)
+        return real(path, size)
+    monkeypatch.setattr(nnc, "_md5_of", slow)
+    nnc._MD5_FUTURES.clear()
+    monkeypatch.setenv("GENOMAD_AMD_DEFER_EXECUTION_INFO", "1")
+    t = time.time()
+    nnc.main(fa, tmp_path / "o1", False, 128, True, 1, False, False, _backend=FakeBackend())
+    info = tmp_path / "o1" / "a_nn_classification" / "a_nn_classification.json"
+    assert time.time() - t < 20 and not info.exists()                      # returned although the digest is still pending
+    assert (tmp_path / "o1" / "a_nn_classification" / "a_nn_classification.tsv").exists()
+    release.set()
+    nnc.wait_execution_info()
+    got = json.load(open(info))
+    monkeypatch.delenv("GENOMAD_AMD_DEFER_EXECUTION_INFO")
+    nnc._MD5_FUTURES.clear()
+    nnc.main(fa, tmp_path / "o2", False, 128, True, 1, False, False, _backend=FakeBackend())
+    want = json.load(open(tmp_path / "o2" / "a_nn_classification" / "a_nn_classification.json"))
+    got.pop("start_time"), want.pop("start_time")
+    assert got == want and got["input_md5"] == real(fa)
