@@ -14,9 +14,9 @@ LIB_PATH = Path(os.environ.get("GENOMAD_AMD_LIB", _HERE / "csrc" / "libgenomad_n
 WINDOW, TOKENS, DEPTH, CH = 6000, 5997, 257, 128
 PATCHES, PATCH_SIZE, POOLED, FEAT, HIDDEN, CLASSES = 2100, 4, 749, 256, 512, 3
 
-PREC_F32, PREC_BF16X3, PREC_BF16, PREC_F16C8, PREC_F16X3, PREC_F16C6 = 0, 1, 2, 3, 4, 5
+PREC_F32, PREC_BF16X3, PREC_BF16, PREC_F16C8, PREC_F16X3, PREC_F16C6, PREC_F16X3TC = 0, 1, 2, 3, 4, 5, 6
 PRECISIONS = {"f32": PREC_F32, "bf16x3": PREC_BF16X3, "bf16": PREC_BF16, "f16c8": PREC_F16C8, "f16x3": PREC_F16X3,
-              "f16c6": PREC_F16C6}
+              "f16c6": PREC_F16C6, "f16x3tc": PREC_F16X3TC}
 # Arithmetic of the fused front end when the caller names none.  "f16x3" (split-f16, three MFMA passes, split-f16 logits GEMM and exact-f32
 # dense head) is the fastest mode whose class scores hold the 1e-4 tolerance WITH MARGIN on every workload measured (within
 # 2e-5 of the exact-f32 path on every one of 1 M windows).  "f16c6" / "f16c8" (f16 + 4-bit correction MFMAs) are 1.55x / 1.3x faster and stay

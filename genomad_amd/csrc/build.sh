@@ -6,12 +6,12 @@ HIPCC=${HIPCC:-/opt/rocm/bin/hipcc}
 FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wall -Wno-unused-result"
 mkdir -p obj
 pids=()
-for f in gnn_api gnn_encode gnn_front_f32 gnn_backend gnn_fused gnn_fused_c8 gnn_fused_c6 gnn_fused_x3 gnn_probe gnn_consumers gnn_fasta gnn_comm gnn_contigs; do
+for f in gnn_api gnn_encode gnn_front_f32 gnn_backend gnn_fused gnn_fused_c8 gnn_fused_c6 gnn_fused_x3 gnn_fused_tc gnn_probe gnn_consumers gnn_fasta gnn_comm gnn_contigs; do
   if [ ! -f obj/$f.o ] || [ $f.hip -nt obj/$f.o ] || [ gnn_common.h -nt obj/$f.o ] || [ gnn_fused_common.h -nt obj/$f.o ] || [ gnn_fused_helpers.h -nt obj/$f.o ] || [ ../../include/genomad_nn.h -nt obj/$f.o ]; then
     $HIPCC $FLAGS ${EXTRA_FLAGS:-} -c $f.hip -o obj/$f.o &
     pids+=($!)
   fi
 done
 for p in "${pids[@]:-}"; do [ -n "$p" ] && wait $p; done
-$HIPCC --offload-arch=gfx950 -shared -fPIC -o libgenomad_nn_hip.so obj/gnn_api.o obj/gnn_encode.o obj/gnn_front_f32.o obj/gnn_backend.o obj/gnn_fused.o obj/gnn_fused_c8.o obj/gnn_fused_c6.o obj/gnn_fused_x3.o obj/gnn_probe.o obj/gnn_consumers.o obj/gnn_fasta.o obj/gnn_comm.o obj/gnn_contigs.o -ldl
+$HIPCC --offload-arch=gfx950 -shared -fPIC -o libgenomad_nn_hip.so obj/gnn_api.o obj/gnn_encode.o obj/gnn_front_f32.o obj/gnn_backend.o obj/gnn_fused.o obj/gnn_fused_c8.o obj/gnn_fused_c6.o obj/gnn_fused_x3.o obj/gnn_fused_tc.o obj/gnn_probe.o obj/gnn_consumers.o obj/gnn_fasta.o obj/gnn_comm.o obj/gnn_contigs.o -ldl
 echo "built $(pwd)/libgenomad_nn_hip.so"

@@ -301,7 +301,7 @@ int classify_chunks(gnn_ctx* ctx, const uint8_t* bases_dev, int64_t n, int preci
         return GNN_ERR_STATE;
     }
     if (precision != GNN_PREC_F32 && precision != GNN_PREC_BF16X3 && precision != GNN_PREC_BF16 &&
-        precision != GNN_PREC_F16C8 && precision != GNN_PREC_F16X3 && precision != GNN_PREC_F16C6) {
+        precision != GNN_PREC_F16C8 && precision != GNN_PREC_F16X3 && precision != GNN_PREC_F16C6 && precision != GNN_PREC_F16X3TC) {
         set_error("unknown precision " + std::to_string(precision));
         return GNN_ERR_ARG;
     }
@@ -369,7 +369,8 @@ int classify_chunks(gnn_ctx* ctx, const uint8_t* bases_dev, int64_t n, int preci
             static const bool x3_round1 = debug_switch("GNN_X3_ROUND1");
             const bool x3 = (precision == GNN_PREC_F16X3 || precision == GNN_PREC_BF16X3) && !x3_round1 &&
                             !(reinterpret_cast<uintptr_t>(b) & 3u);
-            rc = precision == GNN_PREC_F16C6   ? launch_front_c6(ctx, b, m)
+            rc = precision == GNN_PREC_F16X3TC ? launch_front_tc(ctx, b, m)
+                 : precision == GNN_PREC_F16C6   ? launch_front_c6(ctx, b, m)
                  : precision == GNN_PREC_F16C8 ? launch_front_c8(ctx, b, m)
                  : x3                          ? launch_front_x3(ctx, b, m, precision)
                                                : launch_front_fused(ctx, b, m, precision);
@@ -382,7 +383,8 @@ int classify_chunks(gnn_ctx* ctx, const uint8_t* bases_dev, int64_t n, int preci
         }
         {
             ProfScope ps(ctx, GNN_K_BACKEND);
-            rc = launch_backend(ctx, m, precision, scores_dev + a * GNN_CLASSES);
+            // the Toom-Cook front end feeds the back end of the default arithmetic
+            rc = launch_backend(ctx, m, precision == GNN_PREC_F16X3TC ? GNN_PREC_F16X3 : precision, scores_dev + a * GNN_CLASSES);
         }
         if (overlap) {
             if (!rc) {
@@ -444,6 +446,7 @@ int gnn_fused_rows_per_step(int precision) {
     switch (precision) {
         case GNN_PREC_F32: return 0;
         case GNN_PREC_F16C6: return c6_rows_per_step();
+        case GNN_PREC_F16X3TC: return 96;
         case GNN_PREC_BF16X3: case GNN_PREC_BF16: case GNN_PREC_F16C8: case GNN_PREC_F16X3: return FT;
         default: return GNN_ERR_ARG;
     }
@@ -687,6 +690,7 @@ int gnn_load_weights(gnn_ctx* ctx, const gnn_weights* w) {
     if ((rc = pack_fused_c8_weights(ctx, w))) return rc;
     if ((rc = pack_fused_c6_weights(ctx, w))) return rc;
     if ((rc = pack_fused_x3_consts(ctx))) return rc;
+    if ((rc = pack_fused_tc_weights(ctx, w))) return rc;
     ctx->has_weights = true;
     return GNN_OK;
 }

@@ -93,6 +93,13 @@ struct DeviceWeights {
     int32_t* bucket_ptr6[2] = {nullptr, nullptr};
     float* c6_yp_const = nullptr;   // (2, 749, 128) / (2, 8400): the f16c6 kernel's yp and mp of an all-N window (padding skip)
     float* c6_mp_const = nullptr;
+    // Toom-Cook F(3,6) front end (gnn_fused_tc.hip): transformed conv weights [k16 unit 8][xi 8][nblk 4][hi | lo][lane 64][8] f16,
+    // the power of two the inverse transform multiplies by, IGLOO entry ranges per 96-row step, all-N window outputs
+    uint16_t* tc_frag[2] = {nullptr, nullptr};
+    float tc_inv_s[2] = {1.f, 1.f};
+    int32_t* bucket_ptr96[2] = {nullptr, nullptr};
+    float* tc_yp_const = nullptr;
+    float* tc_mp_const = nullptr;
     float* x3_yp_const[2] = {nullptr, nullptr};   // the same of gnn_fused_x3.hip: [0] bf16 limbs, [1] f16 limbs
     float* x3_mp_const[2] = {nullptr, nullptr};
 };
@@ -186,6 +193,8 @@ void free_stage(gnn_ctx* ctx);         // gnn_api.hip: staging of the host-buffe
 int launch_front_c8(gnn_ctx* ctx, const uint8_t* bases, int64_t n);             // GNN_PREC_F16C8 -> ws.mp, ws.yp
 int launch_front_c6(gnn_ctx* ctx, const uint8_t* bases, int64_t n);             // GNN_PREC_F16C6 -> ws.mp, ws.yp
 int launch_front_x3(gnn_ctx* ctx, const uint8_t* bases, int64_t n, int precision);   // GNN_PREC_F16X3 / BF16X3 (gnn_fused_x3.hip) -> ws.mp, ws.yp
+int launch_front_tc(gnn_ctx* ctx, const uint8_t* bases, int64_t n);             // GNN_PREC_F16X3TC (gnn_fused_tc.hip) -> ws.mp, ws.yp
+int pack_fused_tc_weights(gnn_ctx* ctx, const gnn_weights* w);                   // after pack_fused_c6_weights (shares its pair tables)
 int pack_fused_x3_consts(gnn_ctx* ctx);                                          // all-N window outputs of that kernel (after the other packs)
 
 // host-side packing for the fused paths (gnn_fused.hip, gnn_fused_c8.hip)

@@ -1,0 +1,840 @@
+// Fused front end, GNN_PREC_F16X3TC (opt-in, experimental): the f16x3 arithmetic of gnn_fused_x3.hip with conv2 and conv3
+// (igloo.py:65-67) evaluated by Toom-Cook minimal filtering F(3,6) over the time axis - VERDICT r03 item 1.
+//
+//   y[3t + i] = sum_xi AT[i][xi] * M_xi[t],   M_xi[t] = sum_c V_xi[t][c] * U_xi[c][n],   V_xi[t] = sum_j BT[xi][j] x[3t - 5 + j],
+//   U_xi = s * sum_k G[xi][k] w[k]            (oracle/toomcook.py: exact matrices; points 0, +-1, +-2, +-1/2, inf)
+//
+// so a step of 96 rows = 32 tiles = ONE 32-column MFMA block per transform point: 8 GEMMs of K = 128 instead of 6 taps x 3 row
+// blocks of K = 128: 192 MFMAs per wave, conv and step instead of 432 (0.444x).  U and V are split into f16 hi / lo limbs and
+// multiplied with the three products of the f16x3 arithmetic; transforms and accumulators are f32.
+//
+// What it costs (measured before it was built: scripts/probe_tc_loop.hip, profiles/r04/): a transformed weight fragment feeds 3
+// MFMAs (one tile block) where a direct one feeds 12 (four row blocks), so the L2 -> CU weight stream is 4x denser per MFMA
+// (the conv loops run at the chip's L2 ceiling, ~57 B/clk/CU), and the input transform is ~100 VALU instructions per (tile, 2
+// channels) on the helper waves.  DESIGN.md section 8 has the accounting.
+//
+// Structure: the streaming structure of gnn_fused_x3.hip (one workgroup = one window, both activation buffers in LDS with 5 carry
+// rows, 4 matrix waves + 4 helper waves) with steps of 96 rows and a ring of 3 x 16 KB in LDS through which the helper waves hand
+// the transformed activations of ONE k16 unit (8 points x hi | lo x 64 lanes x 16 B, MFMA B-fragment order) to the matrix waves:
+//
+//   matrix : [b0 it0 | b1 it1 | ... | b7 it7] conv2 -> inverse transform -> x2 (f32 rows) -> bufY | B1 | w_v A(s) [bufX] |
+//            [b0' .. b7'] conv3 -> inverse transform -> x3 (hi | lo rows) -> bufY | B0 | w_v B(s) [bufY]   -> step s+1
+//   helpers: during conv2 unit c: V2 chunk c+2 [bufX], pair products B(s-1) [bufY] and A(s) [bufX] | B1 | V3 chunks 0, 1 [bufY] |
+//            during conv3 unit c: V3 chunk c+2, conv1 gather of x1(s+1) -> bufX, carry rows, pair rows | B0 | V2(s+1) chunks 0, 1
+//
+// 18 workgroup barriers per step (bare s_barrier: a __syncthreads() would drain the matrix waves' weight loads in flight).  The
+// helpers run two chunks ahead of the matrix waves: before barrier b_c chunks <= c + 1 are complete, during unit c chunk c + 2
+// is written into slot (c + 2) % 3, which the matrix waves read last in unit c - 1.
+//
+// LDS: bufX 101 rows x 528 B (x1: hi | lo planes), bufY 101 x 528 (x2 as f32 rows, then x3 as hi | lo planes), ring 3 x 16 KB,
+// pair rows, biases: 157.3 KB.
+#include <algorithm>
+#include <cmath>
+#include <cstdlib>
+#include <cstring>
+
+#include "gnn_fused_helpers.h"
+
+namespace gnn {
+namespace tc {
+
+constexpr int NMB = 3;                       // 32-row blocks per step (w_v tiles); one 32-tile block per transform point
+constexpr int FTT = 32 * NMB;                // 96 rows per step
+constexpr int NTILE = 32;
+constexpr int STEPST = (T + FTT - 1) / FTT;  // 63
+constexpr int NXI = 8;
+constexpr int ROWX = 528, LOX = 256;
+constexpr int BUF_ROWS = CARRY + FTT;        // 101
+constexpr int BUF_BYTES = BUF_ROWS * ROWX;
+constexpr int VRING_OFF = 2 * BUF_BYTES;
+constexpr int VSLOT = NXI * 2 * 1024, VRING = 3;
+constexpr int PROW_OFF = VRING_OFF + VRING * VSLOT;
+constexpr int PROW_N = FTT + 4;
+constexpr int PROW_BYTES = ((PROW_N * 2 + 15) / 16) * 16;
+constexpr int BIAS_OFF = PROW_OFF + 2 * PROW_BYTES;
+constexpr int LAST_OFF = BIAS_OFF + 2 * C * 4;
+constexpr int SMEMT = LAST_OFF + 16;
+constexpr int ROW_U4 = ROWX / 16;
+constexpr int WNBLK_B = 2048;                // weight bytes per (unit, [xi,] n-block): hi fragment | lo fragment
+constexpr int WUNIT_B = 4 * WNBLK_B;         // per k16 unit (w_v) / per (k16 unit, xi) (convs)
+constexpr int RINGV = 4;                     // w_v tiles: weight ring slots
+constexpr int RINGT = 8;                     // convs: weight ring slots of one (unit, xi); 7 in flight ahead of the MFMAs
+static_assert(SMEMT <= 160 * 1024, "LDS budget");
+static_assert(T == 3 * 1999, "the tiles tile the window exactly");
+
+struct Args {
+    const uint8_t* bases;
+    const float* conv1_k;             // pair tables in the gather's lane order (DeviceWeights::conv1_pairs6)
+    const unsigned char* tcw[2];      // transformed conv weights: [k16 unit 8][xi 8][nblk 4][hi | lo] x 1 KiB, scaled by 1 / inv_s
+    float inv_s[2];                   // power of two that A^T absorbs
+    const float* conv_b[2];
+    const unsigned char* wv_w[2];     // [k16 unit 8][nblk 4][hi | lo] x 1 KiB (pack_frags, f16 limbs)
+    const float* weff[2];
+    const int32_t* pos_sorted[2];
+    const int32_t* bucket_ptr[2];     // (STEPST + 1,) entry ranges per 96-row step
+    float* mp;
+    float* yp;
+    const float* yp_c;                // outputs of an all-N window (padding skip), nullptr = compute everything
+    const float* mp_c;
+    unsigned long long* cycles;
+    int split;
+};
+
+struct WU {
+    uint4 h, l;
+};
+
+#define TC_BARRIER() asm volatile("s_barrier" ::: "memory")
+// this wave stored to LDS since the last barrier: the stores must have landed before the others are released
+#define TC_BARRIER_W() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
+
+__device__ __forceinline__ f32x16 mma(uint4 a, uint4 b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+}
+__device__ __forceinline__ void load_wu(WU& w, wrsrc_t r, uint32_t l16, int soff) {
+    const u32x4 a = __builtin_amdgcn_raw_buffer_load_b128(r, l16, soff, 0);
+    const u32x4 b = __builtin_amdgcn_raw_buffer_load_b128(r, l16 + 1024, soff, 0);
+    w.h = make_uint4(a[0], a[1], a[2], a[3]);
+    w.l = make_uint4(b[0], b[1], b[2], b[3]);
+}
+
+// ---------------------------------------------------------------- y @ w_v tiles (direct, 3 row blocks, as gnn_fused_x3.hip)
+struct XU {
+    uint4 h[NMB], l[NMB];
+};
+template <int OFF>
+__device__ __forceinline__ void load_xu(XU& f, const unsigned char* __restrict__ xh) {
+#pragma unroll
+    for (int mb = 0; mb < NMB; ++mb) {
+        f.h[mb] = *reinterpret_cast<const uint4*>(xh + OFF + mb * 32 * ROWX);
+        f.l[mb] = *reinterpret_cast<const uint4*>(xh + OFF + LOX + mb * 32 * ROWX);
+    }
+}
+template <bool LX, int OFFN>
+__device__ __forceinline__ void wv_unit(const WU& wc, WU& wl, bool lw, const XU& xc, XU& xl, const unsigned char* __restrict__ xh, wrsrc_t wr,
+                                        int wnext, uint32_t l16, f32x16 (&acc)[NMB]) {
+    if constexpr (LX) load_xu<OFFN>(xl, xh);
+    if (lw) load_wu(wl, wr, l16, wnext);
+#pragma unroll
+    for (int mb = 0; mb < NMB; ++mb) {
+        if (mb % 2 == 0) {
+            acc[mb] = mma(xc.h[mb], wc.l, acc[mb]);
+            acc[mb] = mma(xc.h[mb], wc.h, acc[mb]);
+            acc[mb] = mma(xc.l[mb], wc.h, acc[mb]);
+        } else {
+            acc[mb] = mma(xc.l[mb], wc.h, acc[mb]);
+            acc[mb] = mma(xc.h[mb], wc.h, acc[mb]);
+            acc[mb] = mma(xc.h[mb], wc.l, acc[mb]);
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 3 * NMB; ++i) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        if (LX && i < 2 * NMB) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+        if (i == 1 || i == 5) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+    }
+    GNN_REGION_END();
+}
+// D = X W over the 96 rows that start at buffer row CARRY of `xoff`: a lane ends up with 16 rows of one channel per row block.
+// The ring's first RINGV - 1 units were requested by prime_wv.
+__device__ __forceinline__ void wv_tile(const unsigned char* __restrict__ smem, int xoff, wrsrc_t wr, int woff, WU (&ring)[RINGT],
+                                        f32x16 (&acc)[NMB], int lane) {
+    uint32_t rowoff = (uint32_t)xoff + (uint32_t)(lane & 31) * ROWX + (uint32_t)(lane >> 5) * 16u;
+    asm volatile("" : "+v"(rowoff));
+    const unsigned char* xh = smem + rowoff;
+    const uint32_t l16 = (uint32_t)lane * 16u;
+    XU xa, xb;
+    load_xu<0>(xa, xh);
+    GNN_REGION_END();
+    static_for(std::make_integer_sequence<int, 8>{}, [&](auto kc) {
+        constexpr int k = decltype(kc)::value, kn = k + 1;
+        constexpr int OFFN = kn * 32;
+        constexpr bool LX = kn < 8, LW = k + RINGV - 1 < 8;
+        if constexpr (k % 2 == 0)
+            wv_unit<LX, OFFN>(ring[k % RINGV], ring[(k + RINGV - 1) % RINGV], LW, xa, xb, xh, wr, woff + (k + RINGV - 1) * WUNIT_B, l16, acc);
+        else
+            wv_unit<LX, OFFN>(ring[k % RINGV], ring[(k + RINGV - 1) % RINGV], LW, xb, xa, xh, wr, woff + (k + RINGV - 1) * WUNIT_B, l16, acc);
+    });
+}
+__device__ __forceinline__ void prime_wv(WU (&ring)[RINGT], wrsrc_t wr, int woff, int lane) {
+    const uint32_t l16 = (uint32_t)lane * 16u;
+#pragma unroll
+    for (int u = 0; u < RINGV - 1; ++u) load_wu(ring[u], wr, l16, woff + u * WUNIT_B);
+    asm volatile("" ::: "memory");
+}
+
+// MaxPool1D(8) of the y @ w_v tile -> yp rows (igloo.py:209-210); gnn_fused_x3.hip, wv_pool_store
+__device__ __forceinline__ void wv_pool_store(const f32x16 (&acc)[NMB], wrsrc_t yp_w, int t0, int wave, int lane) {
+    float m[4 * NMB];
+#pragma unroll
+    for (int i = 0; i < 4 * NMB; ++i) {
+        const int mb = i >> 2, rg = i & 3;
+        const float v = max_nan(max_nan(acc[mb][rg * 4], acc[mb][rg * 4 + 1]), max_nan(acc[mb][rg * 4 + 2], acc[mb][rg * 4 + 3]));
+        const unsigned bits = __float_as_uint(v);
+        const auto sw = __builtin_amdgcn_permlane32_swap(bits, bits, false, false);
+        m[i] = max_nan(__uint_as_float(sw[0]), __uint_as_float(sw[1]));
+    }
+    const int q0 = t0 / GNN_POOL;
+    const int nq = min(4 * NMB, POOLED - q0);
+    if (lane < 32) {
+        const uint32_t voff = (uint32_t)(wave * 32 + lane) * 4u;
+#pragma unroll
+        for (int i = 0; i < 4 * NMB; ++i)
+            if (i < nq) __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(m[i]), yp_w, voff, (q0 + i) * (C * 4), 0);
+    }
+}
+
+// ---------------------------------------------------------------- Toom-Cook conv: the matrix waves' side
+struct XV {
+    uint4 h, l;
+};
+template <int VOFFN>
+__device__ __forceinline__ void xi_mma(const WU& wc, WU& wl, const XV& vc, XV& vl, const unsigned char* __restrict__ vb, wrsrc_t wr, int wnext,
+                                       uint32_t l16, f32x16& acc) {
+    vl.h = *reinterpret_cast<const uint4*>(vb + VOFFN);
+    vl.l = *reinterpret_cast<const uint4*>(vb + VOFFN + 1024);
+    load_wu(wl, wr, l16, wnext);
+    acc = mma(wc.l, vc.h, acc);            // D = U^T V: a lane ends up with 16 channels of one tile
+    acc = mma(wc.h, vc.h, acc);
+    acc = mma(wc.h, vc.l, acc);
+    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+    __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+    __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+    GNN_REGION_END();
+}
+__device__ __forceinline__ void prime_tc(WU (&ring)[RINGT], wrsrc_t wr, int woff, int lane) {
+    const uint32_t l16 = (uint32_t)lane * 16u;
+#pragma unroll
+    for (int u = 0; u < RINGT - 1; ++u) load_wu(ring[u], wr, l16, woff + u * WUNIT_B);
+    asm volatile("" ::: "memory");
+}
+// 8 k16 units x 8 points; barrier b_c in front of unit c (the helpers' chunk c + 1 is complete, the slot of chunk c - 1 is free).
+// The weight requests of the last 7 (unit, xi) wrap onto the conv's first ones (in-bounds, unused).
+__device__ __forceinline__ void conv_tc(const unsigned char* __restrict__ smem, wrsrc_t wr, int woff, WU (&ring)[RINGT], f32x16 (&acc)[NXI],
+                                        int lane) {
+    const uint32_t l16 = (uint32_t)lane * 16u;
+    uint32_t voff = (uint32_t)VRING_OFF + l16;
+    asm volatile("" : "+v"(voff));
+    const unsigned char* vb = smem + voff;
+    XV va, vc;
+    TC_BARRIER();                                                            // b_0
+    va.h = *reinterpret_cast<const uint4*>(vb);
+    va.l = *reinterpret_cast<const uint4*>(vb + 1024);
+    vc = va;
+    GNN_REGION_END();
+    static_for(std::make_integer_sequence<int, 64>{}, [&](auto kc) {
+        constexpr int k = decltype(kc)::value, kn = (k + 1) % 64;             // k = unit * 8 + xi
+        constexpr int VOFFN = ((kn / 8) % VRING) * VSLOT + (kn % 8) * 2048;
+        constexpr int kw = (k + RINGT - 1) % 64;
+        if constexpr (k % 8 == 0 && k > 0) TC_BARRIER();                      // b_1 .. b_7
+        if constexpr (k % 2 == 0)
+            xi_mma<VOFFN>(ring[k % RINGT], ring[(k + RINGT - 1) % RINGT], va, vc, vb, wr, woff + kw * WUNIT_B, l16, acc[k % 8]);
+        else
+            xi_mma<VOFFN>(ring[k % RINGT], ring[(k + RINGT - 1) % RINGT], vc, va, vb, wr, woff + kw * WUNIT_B, l16, acc[k % 8]);
+    });
+}
+
+template <bool F16>
+__device__ __forceinline__ void split2(f32x2 v, uint32_t& hi, uint32_t& lo) {
+    hi = __builtin_bit_cast(uint32_t, __builtin_convertvector(v, f16x2));
+    lo = __builtin_bit_cast(uint32_t, __builtin_convertvector(f32x2{sub_f16_lo(v[0], hi), sub_f16_hi(v[1], hi)}, f16x2));
+}
+
+// A^T of F(3,6) (oracle/toomcook.py) on one accumulator register of the 8 points, then scale, bias, LeakyReLU:
+//   y0 = m0 + (m1 + m2) + (m3 + m4) + (m5 + m6);  y1 = (m1 - m2) + 2 (m3 - m4) + (m5 - m6) / 2;
+//   y2 = (m1 + m2) + 4 (m3 + m4) + (m5 + m6) / 4 + m7
+__device__ __forceinline__ void inverse3(const f32x16 (&acc)[NXI], int r, float inv_s, float bias, float (&y)[3]) {
+    const float s12 = acc[1][r] + acc[2][r], d12 = acc[1][r] - acc[2][r];
+    const float s34 = acc[3][r] + acc[4][r], d34 = acc[3][r] - acc[4][r];
+    const float s56 = acc[5][r] + acc[6][r], d56 = acc[5][r] - acc[6][r];
+    const float y0 = ((acc[0][r] + s12) + s34) + s56;
+    const float y1 = fmaf(d56, 0.5f, fmaf(d34, 2.f, d12));
+    const float y2 = fmaf(s56, 0.25f, fmaf(s34, 4.f, s12)) + acc[7][r];
+    const float v0 = fmaf(y0, inv_s, bias), v1 = fmaf(y1, inv_s, bias), v2 = fmaf(y2, inv_s, bias);
+    y[0] = vmax_raw(v0, v0 * LRELU);
+    y[1] = vmax_raw(v1, v1 * LRELU);
+    y[2] = vmax_raw(v2, v2 * LRELU);
+}
+// conv2 epilogue: x2 rows as f32 (only the input transform of conv3 reads them).  Register r of lane l = channel
+// 8 (r >> 2) + 4 (l >> 5) + (r & 3) of tile l & 31: one 16-B store per (row of the tile, register group)
+__device__ __forceinline__ void epilogue_f32(unsigned char* __restrict__ obuf, const f32x16 (&acc)[NXI], float inv_s,
+                                             const float* __restrict__ bias, int wave, int lane) {
+#pragma unroll
+    for (int rg = 0; rg < 4; ++rg) {
+        const int f0 = wave * 32 + rg * 8 + (lane >> 5) * 4;
+        const f32x4 b = *reinterpret_cast<const f32x4*>(bias + f0);
+        float y[4][3];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) inverse3(acc, rg * 4 + e, inv_s, b[e], y[e]);
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+            *reinterpret_cast<f32x4*>(obuf + (CARRY + 3 * (lane & 31) + i) * ROWX + f0 * 4) = f32x4{y[0][i], y[1][i], y[2][i], y[3][i]};
+    }
+}
+// conv3 epilogue: x3 rows as hi | lo planes (y @ w_v of head B and its pair products read them)
+__device__ __forceinline__ void epilogue_x3(unsigned char* __restrict__ obuf, const f32x16 (&acc)[NXI], float inv_s, const float* __restrict__ bias,
+                                            int wave, int lane) {
+#pragma unroll
+    for (int rg = 0; rg < 4; ++rg) {
+        const int f0 = wave * 32 + rg * 8 + (lane >> 5) * 4;
+        const f32x4 b = *reinterpret_cast<const f32x4*>(bias + f0);
+        float y[4][3];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) inverse3(acc, rg * 4 + e, inv_s, b[e], y[e]);
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            uint2 h, l;
+            split2<true>(f32x2{y[0][i], y[1][i]}, h.x, l.x);
+            split2<true>(f32x2{y[2][i], y[3][i]}, h.y, l.y);
+            unsigned char* o = obuf + (CARRY + 3 * (lane & 31) + i) * ROWX + f0 * 2;
+            *reinterpret_cast<uint2*>(o) = h;
+            *reinterpret_cast<uint2*>(o + LOX) = l;
+        }
+    }
+}
+
+// ---------------------------------------------------------------- Toom-Cook conv: the helper waves' side
+// One helper wave = 16 (tile, k half) combinations x 4 channel pairs of a k16 unit: the 4 lanes of a combination cover its 8
+// channels = the 16 bytes of one B-fragment lane, so the row reads (4 lanes = 16 consecutive bytes, tiles 1 584 B apart) and the
+// fragment stores (a wave = 256 consecutive bytes per point and limb) are bank-conflict free.
+struct HLane {
+    const unsigned char* rows;    // first input row of the lane's tile (buffer row 3 * tile), at the lane's channel pair
+    unsigned char* frag;          // the lane's dword of the ring slot's fragments
+};
+__device__ __forceinline__ HLane hlane(unsigned char* smem, int buf_off, int hw, int lane, int bytes_per_ch) {
+    const int pr = lane & 3, th = hw * 16 + (lane >> 2), tile = th & 31, half = th >> 5;
+    HLane h;
+    h.rows = smem + buf_off + (3 * tile) * ROWX + (half * 8 + pr * 2) * bytes_per_ch;
+    h.frag = smem + VRING_OFF + (hw * 64 + lane) * 4;
+    return h;
+}
+struct Raw16 {   // 8 rows x 2 channels as stored: f16 hi | lo words (x1) or f32 pairs (x2)
+    uint32_t a[8], b[8];
+};
+__device__ __forceinline__ void load_x1(Raw16& r, const HLane& h, int unit) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        r.a[j] = *reinterpret_cast<const uint32_t*>(h.rows + j * ROWX + unit * 32);
+        r.b[j] = *reinterpret_cast<const uint32_t*>(h.rows + j * ROWX + unit * 32 + LOX);
+    }
+}
+__device__ __forceinline__ void load_x2(Raw16& r, const HLane& h, int unit) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const uint2 v = *reinterpret_cast<const uint2*>(h.rows + j * ROWX + unit * 64);
+        r.a[j] = v.x;
+        r.b[j] = v.y;
+    }
+}
+// B^T of F(3,6) on the 8 rows of one channel (oracle/toomcook.py: rows of B^T in this order)
+__device__ __forceinline__ void bt8(const float (&d)[8], float (&v)[8]) {
+    v[0] = fmaf(d[2] - d[4], 5.25f, d[6] - d[0]);
+    const float t1 = fmaf(d[4], -4.25f, d[2] + d[6]), t2 = fmaf(d[3], -4.25f, d[1] + d[5]);
+    v[1] = t1 + t2;
+    v[2] = t1 - t2;
+    const float t3 = fmaf(d[4], -1.25f, fmaf(d[2], 0.25f, d[6])), t4 = fmaf(d[5], 2.f, fmaf(d[3], -2.5f, d[1] * 0.5f));
+    v[3] = t3 + t4;
+    v[4] = t3 - t4;
+    const float t5 = fmaf(d[4], -5.f, fmaf(d[2], 4.f, d[6])), t6 = fmaf(d[5], 0.5f, fmaf(d[3], -2.5f, d[1] * 2.f));
+    v[5] = t5 + t6;
+    v[6] = t5 - t6;
+    v[7] = fmaf(d[3] - d[5], 5.25f, d[7] - d[1]);
+}
+template <bool X1>
+__device__ __forceinline__ void transform_store(const Raw16& r, const HLane& h, int slot) {
+    float d0[8], d1[8], v0[8], v1[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        if constexpr (X1) {
+            const f16x2 hh = __builtin_bit_cast(f16x2, r.a[j]), ll = __builtin_bit_cast(f16x2, r.b[j]);
+            d0[j] = (float)hh[0] + (float)ll[0];
+            d1[j] = (float)hh[1] + (float)ll[1];
+        } else {
+            d0[j] = __uint_as_float(r.a[j]);
+            d1[j] = __uint_as_float(r.b[j]);
+        }
+    }
+    bt8(d0, v0);
+    bt8(d1, v1);
+    unsigned char* o = h.frag + slot * VSLOT;
+#pragma unroll
+    for (int xi = 0; xi < NXI; ++xi) {
+        uint32_t hi, lo;
+        split2<true>(f32x2{v0[xi], v1[xi]}, hi, lo);
+        *reinterpret_cast<uint32_t*>(o + xi * 2048) = hi;
+        *reinterpret_cast<uint32_t*>(o + xi * 2048 + 1024) = lo;
+    }
+}
+
+// conv1 + LeakyReLU of one (row, 32-channel block) unit -> both planes of the row (gnn_fused_x3.hip)
+__device__ __forceinline__ void store_block32(unsigned char* __restrict__ buf, int buf_row, int blk, const float (&x)[32]) {
+    unsigned char* row = buf + buf_row * ROWX + blk * 64;
+    uint32_t hi[16], lo[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) split2<true>(f32x2{x[2 * i], x[2 * i + 1]}, hi[i], lo[i]);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        *reinterpret_cast<uint4*>(row + i * 16) = make_uint4(hi[4 * i], hi[4 * i + 1], hi[4 * i + 2], hi[4 * i + 3]);
+        *reinterpret_cast<uint4*>(row + LOX + i * 16) = make_uint4(lo[4 * i], lo[4 * i + 1], lo[4 * i + 2], lo[4 * i + 3]);
+    }
+}
+__device__ __forceinline__ void gather_store(const GatherSum& g, unsigned char* __restrict__ xbuf, int ua, int pq) {
+    const bool odd = pq & 1;
+    float x[32];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const f32x4 sa = g.sa[i], sb = g.sb[i];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const float got = dpp_xor1(odd ? sa[k] : sb[k]);
+            const float c0 = odd ? got : sa[k], c1 = odd ? sb[k] : got;
+            x[4 * i + k] = vmax_raw(c0, c0 * LRELU);
+            x[16 + 4 * i + k] = vmax_raw(c1, c1 * LRELU);
+        }
+    }
+    store_block32(xbuf, CARRY + ua + (odd ? 1 : 0), pq >> 1, x);
+}
+__device__ __forceinline__ void gather_finish(const GatherUnit& g, unsigned char* __restrict__ xbuf, int ua, int pq) {
+    GatherSum t;
+    gather_sum(t, g);
+    gather_store(t, xbuf, ua, pq);
+}
+
+// dot product of an entry's 32 folded weights with block p of row u (x = hi + lo), summed over the entry's 4 lanes (gnn_fused_x3.hip)
+struct PairCompute {
+    static __device__ __forceinline__ void run(const PairW& w, const PairJob& jb, int e, int u, int p) {
+        const unsigned char* xr = jb.xbuf + (CARRY + u - jb.t0) * ROWX + p * 64;
+        uint4 hx[4], lx[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            hx[i] = *reinterpret_cast<const uint4*>(xr + i * 16);
+            lx[i] = *reinterpret_cast<const uint4*>(xr + LOX + i * 16);
+        }
+        float s = 0.f;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const uint32_t hv[4] = {hx[i].x, hx[i].y, hx[i].z, hx[i].w}, lv[4] = {lx[i].x, lx[i].y, lx[i].z, lx[i].w};
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const f16x2 hh = __builtin_bit_cast(f16x2, hv[k]), ll = __builtin_bit_cast(f16x2, lv[k]);
+                const float x0 = (float)hh[0] + (float)ll[0], x1 = (float)hh[1] + (float)ll[1];
+                const float4 w0 = w.w[2 * i + (k >> 1)];
+                s = fmaf(x0, (k & 1) ? w0.z : w0.x, s);
+                s = fmaf(x1, (k & 1) ? w0.w : w0.y, s);
+            }
+        }
+        s += dpp_xor1(s);
+        s += dpp_xor2(s);
+        if (p == 0) jb.mp[e] = s;
+    }
+};
+
+template <bool PROF>
+__global__ __launch_bounds__(512, 2) void fused_front_tc_kernel(Args a) {
+    __shared__ __attribute__((aligned(16))) unsigned char smem[SMEMT];
+    unsigned char* bufX = smem;
+    unsigned char* bufY = smem + BUF_BYTES;
+    auto prow2 = [&](int parity) { return reinterpret_cast<uint16_t*>(smem + PROW_OFF + parity * PROW_BYTES); };
+    float* bias_s = reinterpret_cast<float*>(smem + BIAS_OFF);
+    int* s_last = reinterpret_cast<int*>(smem + LAST_OFF);
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const bool helper = wave >= 4;
+    const int hw = wave & 3;
+    const int ht = tid & 255;
+    const int64_t wi = blockIdx.x / a.split;
+    const int part = blockIdx.x % a.split;
+    const uint8_t* bases = a.bases + wi * W;
+    float* mp_w[2] = {a.mp + (wi * 2 + 0) * NPAIR, a.mp + (wi * 2 + 1) * NPAIR};
+    const int woff = hw * WNBLK_B;
+
+    for (int i = tid; i < CARRY * ROW_U4; i += 512) {            // carry rows of the first step = the causal zero padding
+        reinterpret_cast<uint4*>(bufX)[i] = make_uint4(0, 0, 0, 0);
+        reinterpret_cast<uint4*>(bufY)[i] = make_uint4(0, 0, 0, 0);
+    }
+    if (tid >= 256) bias_s[tid - 256] = a.conv_b[(tid - 256) >> 7][tid & 127];
+    if (tid == 0) *s_last = -1;
+    __syncthreads();
+    if (a.yp_c) {
+        int last = -1;
+        for (int i = tid * 12; i < tid * 12 + 12 && i < W; ++i)
+            if (base_code_f(bases[i]) >= 0) last = i;
+        if (last >= 0) atomicMax(s_last, last);
+    }
+    __syncthreads();
+    const int nsteps = a.yp_c ? max(1, min(STEPST, (*s_last + 1 + 15 + FTT - 1) / FTT)) : STEPST;
+    const int per = (nsteps + a.split - 1) / a.split;
+    const int s_lo = min(part * per, nsteps), s_hi = min(s_lo + per, nsteps);
+    const int s_begin = s_hi > s_lo ? (s_lo > 0 ? s_lo - 1 : 0) : s_hi;       // one warm-up step per run but the first (gnn_fused_x3.hip)
+    if (tid < PROW_N) {
+#pragma unroll
+        for (int s01 = 0; s01 < 2; ++s01) {
+            uint32_t lo, hi;
+            const int t = (s_begin + s01) * FTT - CARRY + tid;
+            prow_fetch(bases, t, lo, hi);
+            prow2((s_begin + s01) & 1)[tid] = prow_make(lo, hi, t);
+        }
+    }
+    __syncthreads();
+    unsigned long long cyc[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long tick_ = 0;
+    // conv1 gather: a lane pair owns one 32-channel block of two neighbouring rows; 256 threads = 64 rows per round, 96 rows =
+    // round 0 (all threads) + round 1 (threads 0..127)
+    const int gpq = ht & 7, gua = (ht >> 3) * 2;
+    const bool g1_on = gua + 64 < FTT;
+
+    if (!helper) {
+        __builtin_amdgcn_s_setprio(2);
+        const wrsrc_t cw[2] = {make_wrsrc(a.tcw[0], 64 * WUNIT_B), make_wrsrc(a.tcw[1], 64 * WUNIT_B)};
+        const wrsrc_t vw[2] = {make_wrsrc(a.wv_w[0], 8 * WUNIT_B), make_wrsrc(a.wv_w[1], 8 * WUNIT_B)};
+        const wrsrc_t yp_w[2] = {make_wrsrc(reinterpret_cast<const unsigned char*>(a.yp + (wi * 2 + 0) * (size_t)POOLED * C), POOLED * C * 4),
+                                 make_wrsrc(reinterpret_cast<const unsigned char*>(a.yp + (wi * 2 + 1) * (size_t)POOLED * C), POOLED * C * 4)};
+        WU ring[RINGT];
+        prime_tc(ring, cw[0], woff, lane);
+        __syncthreads();                                                         // x1 of the first step is in bufX
+        if constexpr (PROF) tick_ = __builtin_readcyclecounter();
+#pragma unroll 1
+        for (int step = s_begin; step < s_hi; ++step) {
+            const int t0 = step * FTT;
+            const bool store = step >= s_lo;
+            f32x16 acc[NXI];
+#pragma unroll
+            for (int xi = 0; xi < NXI; ++xi)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[xi][r] = 0.f;
+            GNN_TICK(7)
+            conv_tc(smem, cw[0], woff, ring, acc, lane);                         // b_0 .. b_7, conv2
+            GNN_TICK(0)
+            prime_wv(ring, vw[0], woff, lane);
+            epilogue_f32(bufY, acc, a.inv_s[0], bias_s, hw, lane);
+            GNN_TICK(1)
+            TC_BARRIER_W();                                                      // ---- B1: x2 is in bufY
+            GNN_TICK(2)
+            {
+                f32x16 ac[NMB];
+#pragma unroll
+                for (int mb = 0; mb < NMB; ++mb)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) ac[mb][r] = 0.f;
+                wv_tile(smem, CARRY * ROWX, vw[0], woff, ring, ac, lane);
+                prime_tc(ring, cw[1], woff, lane);
+                if (store) wv_pool_store(ac, yp_w[0], t0, hw, lane);
+            }
+            GNN_TICK(3)
+#pragma unroll
+            for (int xi = 0; xi < NXI; ++xi)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[xi][r] = 0.f;
+            conv_tc(smem, cw[1], woff, ring, acc, lane);                         // b'_0 .. b'_7, conv3
+            GNN_TICK(4)
+            prime_wv(ring, vw[1], woff, lane);
+            epilogue_x3(bufY, acc, a.inv_s[1], bias_s + C, hw, lane);
+            GNN_TICK(5)
+            TC_BARRIER_W();                                                      // ---- B0: x3 is in bufY
+            GNN_TICK(6)
+            {
+                f32x16 ac[NMB];
+#pragma unroll
+                for (int mb = 0; mb < NMB; ++mb)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) ac[mb][r] = 0.f;
+                wv_tile(smem, BUF_BYTES + CARRY * ROWX, vw[1], woff, ring, ac, lane);
+                prime_tc(ring, cw[0], woff, lane);
+                if (store) wv_pool_store(ac, yp_w[1], t0, hw, lane);
+            }
+        }
+    } else {
+        {
+            GatherUnit g;
+            gather_issue(g, prow2(s_begin & 1), a.conv1_k, gua, gpq);
+            gather_finish(g, bufX, gua, gpq);
+            if (g1_on) {
+                gather_issue(g, prow2(s_begin & 1), a.conv1_k, gua + 64, gpq);
+                gather_finish(g, bufX, gua + 64, gpq);
+            }
+        }
+        uint32_t nlo = 0, nhi = 0;                       // bytes of this thread's pair row of the step AFTER next
+        if (ht < PROW_N) prow_fetch(bases, (s_begin + 2) * FTT - CARRY + ht, nlo, nhi);
+        const HLane h1 = hlane(smem, 0, hw, lane, 2), h2 = hlane(smem, BUF_BYTES, hw, lane, 4);
+        const int cr = ht / ROW_U4, cc = ht - cr * ROW_U4;   // carry rows: 5 rows x 33 chunks of 16 B
+        __syncthreads();
+        if constexpr (PROF) tick_ = __builtin_readcyclecounter();
+        Raw16 ra, rb;
+        // V2 chunks 0 and 1 of the first step
+        load_x1(ra, h1, 0);
+        load_x1(rb, h1, 1);
+        transform_store<true>(ra, h1, 0);
+        load_x1(ra, h1, 2);
+        transform_store<true>(rb, h1, 1);
+#pragma unroll 1
+        for (int step = s_begin; step < s_hi; ++step) {
+            const int t0 = step * FTT;
+            const uint16_t* prow = prow2((step + 1) & 1);
+            const bool hb = step - 1 >= s_lo, ha = step >= s_lo;
+            const int sb = max(step - 1, 0);
+            GNN_TICK(10)
+            // ---- conv2 phase: chunks 2 .. 7 (ra holds the rows of chunk 2), then the pair products
+            TC_BARRIER_W();                                                      // b_0
+            load_x1(rb, h1, 3);
+            transform_store<true>(ra, h1, 2);
+            TC_BARRIER_W();                                                      // b_1
+            load_x1(ra, h1, 4);
+            transform_store<true>(rb, h1, 0);
+            TC_BARRIER_W();                                                      // b_2
+            load_x1(rb, h1, 5);
+            transform_store<true>(ra, h1, 1);
+            TC_BARRIER_W();                                                      // b_3
+            load_x1(ra, h1, 6);
+            transform_store<true>(rb, h1, 2);
+            TC_BARRIER_W();                                                      // b_4
+            load_x1(rb, h1, 7);
+            transform_store<true>(ra, h1, 0);
+            TC_BARRIER_W();                                                      // b_5
+            transform_store<true>(rb, h1, 1);
+            GNN_TICK(8)
+            TC_BARRIER_W();                                                      // b_6
+            {
+                // head B's entries of step s-1 (x3 in bufY, overwritten by the conv2 epilogue behind b_7) and head A's of step s
+                const PairJob jb = {bufY, a.weff[1], a.pos_sorted[1], mp_w[1], t0 - FTT, hb ? a.bucket_ptr[1][sb] : 0, hb ? a.bucket_ptr[1][sb + 1] : 0};
+                const PairJob none = {bufX, a.weff[0], a.pos_sorted[0], mp_w[0], 0, 0, 0};
+                m_partials2<PairCompute>(jb, none, hw, lane);
+            }
+            GNN_TICK(9)
+            TC_BARRIER();                                                        // b_7
+            uint4 carry = make_uint4(0, 0, 0, 0);
+            if (ht < CARRY * ROW_U4) carry = *reinterpret_cast<const uint4*>(bufX + (FTT + cr) * ROWX + cc * 16);
+            GNN_TICK(11)
+            TC_BARRIER();                                                        // ---- B1: x2 is in bufY
+            // V3 chunks 0, 1 beside the matrix waves' w_v A, then head A's pair products (bufX stays x1(s) until the gather)
+            load_x2(ra, h2, 0);
+            load_x2(rb, h2, 1);
+            transform_store<false>(ra, h2, 0);
+            load_x2(ra, h2, 2);
+            transform_store<false>(rb, h2, 1);
+            {
+                const PairJob ja = {bufX, a.weff[0], a.pos_sorted[0], mp_w[0], t0, ha ? a.bucket_ptr[0][step] : 0, ha ? a.bucket_ptr[0][step + 1] : 0};
+                const PairJob none = {bufY, a.weff[1], a.pos_sorted[1], mp_w[1], 0, 0, 0};
+                m_partials2<PairCompute>(none, ja, hw, lane);
+            }
+            GNN_TICK(12)
+            // ---- conv3 phase: chunks 2 .. 7, the conv1 gather of the next step, carry rows, pair rows
+            TC_BARRIER_W();                                                      // b'_0: nobody reads bufX any more
+            if (ht < CARRY * ROW_U4) *reinterpret_cast<uint4*>(bufX + cr * ROWX + cc * 16) = carry;
+            load_x2(rb, h2, 3);
+            transform_store<false>(ra, h2, 2);
+            TC_BARRIER_W();                                                      // b'_1
+            load_x2(ra, h2, 4);
+            transform_store<false>(rb, h2, 0);
+            TC_BARRIER_W();                                                      // b'_2
+            load_x2(rb, h2, 5);
+            transform_store<false>(ra, h2, 1);
+            TC_BARRIER_W();                                                      // b'_3
+            load_x2(ra, h2, 6);
+            transform_store<false>(rb, h2, 2);
+            TC_BARRIER_W();                                                      // b'_4
+            load_x2(rb, h2, 7);
+            transform_store<false>(ra, h2, 0);
+            TC_BARRIER_W();                                                      // b'_5
+            transform_store<false>(rb, h2, 1);
+            GNN_TICK(13)
+            {
+                GatherUnit g;
+                gather_issue(g, prow, a.conv1_k, gua, gpq);
+                TC_BARRIER_W();                                                  // b'_6: V3 is complete
+                // x2 carry rows: nobody reads rows 0..4 of bufY any more, the conv3 epilogue (behind b'_7) overwrites rows 96..100
+                if (ht < CARRY * ROW_U4) {
+                    const uint4 c2 = *reinterpret_cast<const uint4*>(bufY + (FTT + cr) * ROWX + cc * 16);
+                    *reinterpret_cast<uint4*>(bufY + cr * ROWX + cc * 16) = c2;
+                }
+                gather_finish(g, bufX, gua, gpq);
+                if (g1_on) gather_issue(g, prow, a.conv1_k, gua + 64, gpq);
+                TC_BARRIER_W();                                                  // b'_7
+                if (g1_on) gather_finish(g, bufX, gua + 64, gpq);
+            }
+            if (ht < PROW_N) {                                                   // pair rows of step s+2 (parity buffer of step s: read last before b'_6)
+                const int t = t0 + 2 * FTT - CARRY + ht;
+                prow2(step & 1)[ht] = prow_make(nlo, nhi, t);
+                prow_fetch(bases, t + FTT, nlo, nhi);
+            }
+            GNN_TICK(14)
+            TC_BARRIER_W();                                                      // ---- B0: x3 is in bufY, x1(s+1) in bufX
+            // V2 chunks 0, 1 of the next step beside the matrix waves' w_v B
+            load_x1(ra, h1, 0);
+            load_x1(rb, h1, 1);
+            transform_store<true>(ra, h1, 0);
+            load_x1(ra, h1, 2);
+            transform_store<true>(rb, h1, 1);
+            GNN_TICK(15)
+        }
+        if (s_hi > s_lo) {                                  // head B's entries of this run's last step
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            const PairJob jb = {bufY, a.weff[1], a.pos_sorted[1], mp_w[1], (s_hi - 1) * FTT, a.bucket_ptr[1][s_hi - 1], a.bucket_ptr[1][s_hi]};
+            const PairJob none = {bufX, a.weff[0], a.pos_sorted[0], mp_w[0], 0, 0, 0};
+            m_partials2<PairCompute>(jb, none, hw, lane);
+        }
+    }
+    if (nsteps < STEPST && part == a.split - 1) {   // the all-N tail: copy instead of compute
+        const int q0 = nsteps * (FTT / GNN_POOL);
+        const int nrow4 = (POOLED - q0) * (C / 4);
+        for (int i = tid; i < 2 * nrow4; i += 512) {
+            const int h = i >= nrow4, j = i - h * nrow4;
+            const size_t off = (size_t)h * POOLED * C + (size_t)q0 * C + (size_t)j * 4;
+            *reinterpret_cast<float4*>(a.yp + wi * 2 * (size_t)POOLED * C + off) = *reinterpret_cast<const float4*>(a.yp_c + off);
+        }
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+            for (int e = a.bucket_ptr[h][nsteps] + tid; e < NPAIR; e += 512) mp_w[h][e] = a.mp_c[h * NPAIR + e];
+    }
+    if constexpr (PROF) {
+        if (tid == 0)
+            for (int i = 0; i < 8; ++i) atomicAdd(a.cycles + i, cyc[i]);
+        if (tid == 256)
+            for (int i = 8; i < 16; ++i) atomicAdd(a.cycles + i, cyc[i]);
+    }
+}
+
+static void fill_args(const gnn_ctx* ctx, Args& a, const uint8_t* bases) {
+    const DeviceWeights& d = ctx->w;
+    a.bases = bases;
+    a.conv1_k = d.conv1_pairs6;
+    for (int i = 0; i < 2; ++i) {
+        a.tcw[i] = reinterpret_cast<const unsigned char*>(d.tc_frag[i]);
+        a.inv_s[i] = d.tc_inv_s[i];
+        a.conv_b[i] = d.conv_b[i];
+        a.wv_w[i] = reinterpret_cast<const unsigned char*>(d.wv_frag_h[i]);
+        a.weff[i] = d.weff6[i];
+        a.pos_sorted[i] = d.pos_sorted[i];
+        a.bucket_ptr[i] = d.bucket_ptr96[i];
+    }
+    a.cycles = nullptr;
+    a.split = 1;
+}
+
+static void launch(const Args& a, bool prof, unsigned nwin, hipStream_t stream) {
+    const unsigned n = nwin * (unsigned)a.split;
+    if (prof) hipLaunchKernelGGL((fused_front_tc_kernel<true>), dim3(n), dim3(512), 0, stream, a);
+    else hipLaunchKernelGGL((fused_front_tc_kernel<false>), dim3(n), dim3(512), 0, stream, a);
+}
+
+// f32 -> f16 bits (round to nearest even) on the host, via the compiler's _Float16
+static uint16_t f16_bits_of(double v) {
+    const _Float16 h = (_Float16)v;
+    uint16_t b;
+    std::memcpy(&b, &h, 2);
+    return b;
+}
+static double f16_value_of(uint16_t b) {
+    _Float16 h;
+    std::memcpy(&h, &b, 2);
+    return (double)h;
+}
+
+}  // namespace tc
+
+// Transformed conv weights U_xi = s * sum_k G[xi][k] w[k] in f64 (G of F(3,6), oracle/toomcook.py), split into f16 hi | lo limbs in
+// MFMA fragment order [k16 unit][xi][n-block][hi | lo][lane 64][8]; s = the power of two that puts max |U| into [512, 1024) (the
+// low limbs leave the f16 subnormal range; 1 / s goes into the inverse transform).  And the IGLOO entry ranges per 96-row step.
+int pack_fused_tc_weights(gnn_ctx* ctx, const gnn_weights* w) {
+    using namespace tc;
+    DeviceWeights& d = ctx->w;
+    static const double G[NXI][KS] = {{-1, 0, 0, 0, 0, 0},
+                                      {-2. / 9, -2. / 9, -2. / 9, -2. / 9, -2. / 9, -2. / 9},
+                                      {-2. / 9, 2. / 9, -2. / 9, 2. / 9, -2. / 9, 2. / 9},
+                                      {1. / 90, 1. / 45, 2. / 45, 4. / 45, 8. / 45, 16. / 45},
+                                      {1. / 90, -1. / 45, 2. / 45, -4. / 45, 8. / 45, -16. / 45},
+                                      {32. / 45, 16. / 45, 8. / 45, 4. / 45, 2. / 45, 1. / 45},
+                                      {32. / 45, -16. / 45, 8. / 45, -4. / 45, 2. / 45, -1. / 45},
+                                      {0, 0, 0, 0, 0, 1}};
+    const float* ck[2] = {w->conv2_kernel, w->conv3_kernel};
+    for (int cv = 0; cv < 2; ++cv) {
+        std::vector<double> U((size_t)NXI * C * C);
+        double amax = 0.0;
+        for (int xi = 0; xi < NXI; ++xi)
+            for (int c = 0; c < C; ++c)
+                for (int n = 0; n < C; ++n) {
+                    double s = 0.0;
+                    for (int k = 0; k < KS; ++k) s += G[xi][k] * (double)ck[cv][((size_t)k * C + c) * C + n];
+                    U[((size_t)xi * C + c) * C + n] = s;
+                    amax = std::max(amax, std::fabs(s));
+                }
+        const double scale = amax > 0 ? std::exp2(std::floor(std::log2(1024.0 / amax))) : 1.0;
+        std::vector<uint16_t> frag((size_t)8 * NXI * 4 * 2 * 64 * 8);
+        for (int u = 0; u < 8; ++u)
+            for (int xi = 0; xi < NXI; ++xi)
+                for (int nb = 0; nb < 4; ++nb)
+                    for (int l = 0; l < 64; ++l)
+                        for (int e = 0; e < 8; ++e) {
+                            const int k = u * 16 + (l >> 5) * 8 + e, n = nb * 32 + (l & 31);
+                            const double v = U[((size_t)xi * C + k) * C + n] * scale;
+                            const uint16_t hi = f16_bits_of(v), lo = f16_bits_of(v - f16_value_of(hi));
+                            const size_t base = ((((size_t)u * NXI + xi) * 4 + nb) * 2) * 64 * 8;
+                            frag[base + (size_t)l * 8 + e] = hi;
+                            frag[base + 64 * 8 + (size_t)l * 8 + e] = lo;
+                        }
+        void* p = nullptr;
+        GNN_HIP(hipMalloc(&p, frag.size() * 2));
+        ctx->owned.push_back(p);
+        GNN_HIP(hipMemcpy(p, frag.data(), frag.size() * 2, hipMemcpyHostToDevice));
+        d.tc_frag[cv] = static_cast<uint16_t*>(p);
+        d.tc_inv_s[cv] = (float)(1.0 / scale);
+    }
+    const gnn_igloo_weights* ig[2] = {&w->igloo_a, &w->igloo_b};
+    for (int h = 0; h < 2; ++h) {
+        std::vector<int32_t> ptr(STEPST + 1, 0);
+        for (int i = 0; i < NPAIR; ++i) ptr[ig[h]->patches[i] / FTT + 1] += 1;      // range-checked by gnn_load_weights before
+        for (int s = 0; s < STEPST; ++s) ptr[s + 1] += ptr[s];
+        void* p = nullptr;
+        GNN_HIP(hipMalloc(&p, ptr.size() * 4));
+        ctx->owned.push_back(p);
+        GNN_HIP(hipMemcpy(p, ptr.data(), ptr.size() * 4, hipMemcpyHostToDevice));
+        d.bucket_ptr96[h] = static_cast<int32_t*>(p);
+    }
+    // the all-N window's outputs, computed once by the kernel itself (padding skip)
+    void* bn = nullptr;
+    GNN_HIP(hipMalloc(&bn, W));
+    ctx->owned.push_back(bn);
+    GNN_HIP(hipMemsetAsync(bn, 'N', W, ctx->stream));
+    void *yc = nullptr, *mc = nullptr;
+    GNN_HIP(hipMalloc(&yc, (size_t)2 * POOLED * C * sizeof(float)));
+    ctx->owned.push_back(yc);
+    GNN_HIP(hipMalloc(&mc, (size_t)2 * NPAIR * sizeof(float)));
+    ctx->owned.push_back(mc);
+    Args a;
+    fill_args(ctx, a, static_cast<const uint8_t*>(bn));
+    a.mp = static_cast<float*>(mc);
+    a.yp = static_cast<float*>(yc);
+    a.yp_c = nullptr;
+    a.mp_c = nullptr;
+    launch(a, false, 1, ctx->stream);
+    GNN_HIP(hipGetLastError());
+    GNN_HIP(hipStreamSynchronize(ctx->stream));
+    d.tc_yp_const = static_cast<float*>(yc);
+    d.tc_mp_const = static_cast<float*>(mc);
+    return GNN_OK;
+}
+
+int launch_front_tc(gnn_ctx* ctx, const uint8_t* bases, int64_t n) {
+    using namespace tc;
+    if (reinterpret_cast<uintptr_t>(bases) & 3u) {
+        set_error("f16x3tc: the window buffer must be 4-byte aligned");
+        return GNN_ERR_ARG;
+    }
+    Args a;
+    fill_args(ctx, a, bases);
+    a.mp = ctx->ws.mp;
+    a.yp = ctx->ws.yp;
+    a.yp_c = ctx->c6_pad_skip ? ctx->w.tc_yp_const : nullptr;
+    a.mp_c = ctx->c6_pad_skip ? ctx->w.tc_mp_const : nullptr;
+    a.cycles = ctx->phase_cycles;
+    if (ctx->time_split && n > 0 && ctx->cu_count > 0) a.split = (int)std::max<int64_t>(1, std::min<int64_t>(4, ctx->cu_count / n));
+    launch(a, ctx->phase_cycles != nullptr, (unsigned)n, ctx->stream);
+    GNN_HIP(hipGetLastError());
+    return GNN_OK;
+}
+
+}  // namespace gnn

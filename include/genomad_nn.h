@@ -64,6 +64,9 @@ typedef enum gnn_precision {
                                 no head-room under the tolerance (1.2e-4 on a few of 10^6 windows: bench.py exits non-zero
                                 with it); needs |activation| < 65504 (f16 range) and a 4-byte aligned window buffer (any
                                 gnn_dev_alloc / host staging buffer is)                                                 */
+    GNN_PREC_F16X3TC = 6,    /* EXPERIMENTAL, opt-in (gnn_fused_tc.hip): the F16X3 arithmetic with conv2 / conv3 by Toom-Cook minimal
+                                filtering F(3,6) over time: 0.444x the conv MFMAs, f32 transforms (error 2-4x F16X3's in emulation,
+                                oracle/toomcook.py); back end as F16X3; same range and alignment requirements               */
     GNN_PREC_F16X3 = 4       /* THE DEFAULT of main(), NNEngine and bench.py.  Fused path (gnn_fused_x3.hip): split-f16 (hi+lo,
                                 11+11 significant bits), 3 MFMA passes, logits GEMM split-f16 x 3 on the matrix pipe, dense head exact f32: f32-class
                                 accuracy (within 2e-5 of the exact-f32 path on every one of 10^6 windows, 25x below bf16x3 in emulation); needs

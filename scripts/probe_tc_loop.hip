@@ -171,6 +171,17 @@ __device__ __forceinline__ void helper_load(HRaw& r, const unsigned char* smem, 
     }
 }
 __device__ __forceinline__ void helper_transform(const HRaw& r, unsigned char* smem, int slot, int hw, int lane) {
+#ifdef HELP_NOVALU       // measurement variant: the 16 loads and 16 stores without the arithmetic between them
+    {
+        unsigned char* vo = smem + VOFF + slot * VSLOT + (hw * 64 + lane) * 4;
+#pragma unroll
+        for (int xi = 0; xi < 8; ++xi) {
+            *reinterpret_cast<uint32_t*>(vo + xi * 2048) = r.h[xi];
+            *reinterpret_cast<uint32_t*>(vo + xi * 2048 + 1024) = r.l[xi];
+        }
+        return;
+    }
+#endif
     float d[8][2];
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
@@ -203,8 +214,12 @@ __device__ __forceinline__ void helper_transform(const HRaw& r, unsigned char* s
         const f16x2 hi = __builtin_convertvector(v, f16x2);
         const f32x2 back = {(float)hi[0], (float)hi[1]};
         const f16x2 lo = __builtin_convertvector(v - back, f16x2);
+#ifdef HELP_NOSTORE      // measurement variant: the transform's VALU work without its 16 LDS stores
+        asm volatile("" ::"v"(__builtin_bit_cast(uint32_t, hi)), "v"(__builtin_bit_cast(uint32_t, lo)));
+#else
         *reinterpret_cast<uint32_t*>(vo + xi * 2048) = __builtin_bit_cast(uint32_t, hi);
         *reinterpret_cast<uint32_t*>(vo + xi * 2048 + 1024) = __builtin_bit_cast(uint32_t, lo);
+#endif
     }
 }
 
