@@ -8,7 +8,10 @@ mkdir -p obj
 pids=()
 for f in gnn_api gnn_encode gnn_front_f32 gnn_backend gnn_fused gnn_fused_c8 gnn_fused_c6 gnn_fused_x3 gnn_fused_tc gnn_probe gnn_consumers gnn_fasta gnn_comm gnn_contigs; do
   if [ ! -f obj/$f.o ] || [ $f.hip -nt obj/$f.o ] || [ gnn_common.h -nt obj/$f.o ] || [ gnn_fused_common.h -nt obj/$f.o ] || [ gnn_fused_helpers.h -nt obj/$f.o ] || [ ../../include/genomad_nn.h -nt obj/$f.o ]; then
-    $HIPCC $FLAGS ${EXTRA_FLAGS:-} -c $f.hip -o obj/$f.o &
+    # gnn_fused_tc: no SLP vectorisation - the helpers' transform runs beside the MFMA stream, where v_pk_*_f32 issue worse than
+    # two scalar ops (MI355X_MICROARCH.md, "price of one filler beside MFMAs"; 23.5 vs 24.1 ms per 4096 windows)
+    PERFILE=""; [ $f = gnn_fused_tc ] && PERFILE="-fno-slp-vectorize"
+    $HIPCC $FLAGS $PERFILE ${EXTRA_FLAGS:-} -c $f.hip -o obj/$f.o &
     pids+=($!)
   fi
 done

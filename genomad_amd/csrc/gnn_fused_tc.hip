@@ -40,7 +40,6 @@ namespace tc {
 
 constexpr int NMB = 3;                       // 32-row blocks per step (w_v tiles); one 32-tile block per transform point
 constexpr int FTT = 32 * NMB;                // 96 rows per step
-constexpr int NTILE = 32;
 constexpr int STEPST = (T + FTT - 1) / FTT;  // 63
 constexpr int NXI = 8;
 constexpr int ROWX = 528, LOX = 256;
@@ -85,6 +84,9 @@ struct WU {
 };
 
 #define TC_BARRIER() asm volatile("s_barrier" ::: "memory")
+// helper-side barrier with the PROF counters around it: `work` collects the time since the last tick, `wait` the time in the barrier
+#define HBAR_W(work, wait) GNN_TICK(work) TC_BARRIER_W(); GNN_TICK(wait)
+#define HBAR(work, wait) GNN_TICK(work) TC_BARRIER(); GNN_TICK(wait)
 // this wave stored to LDS since the last barrier: the stores must have landed before the others are released
 #define TC_BARRIER_W() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
 
@@ -349,10 +351,9 @@ __device__ __forceinline__ void transform_store(const Raw16& r, const HLane& h, 
     float d0[8], d1[8], v0[8], v1[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
-        if constexpr (X1) {
-            const f16x2 hh = __builtin_bit_cast(f16x2, r.a[j]), ll = __builtin_bit_cast(f16x2, r.b[j]);
-            d0[j] = (float)hh[0] + (float)ll[0];
-            d1[j] = (float)hh[1] + (float)ll[1];
+        if constexpr (X1) {            // x = hi + lo in ONE v_fma_mix_f32 per value (hi * 1.0 + lo, both read as f16 halves)
+            asm("v_fma_mix_f32 %0, %1, 1.0, %2 op_sel:[0,0,0] op_sel_hi:[1,0,1]" : "=v"(d0[j]) : "v"(r.a[j]), "v"(r.b[j]));
+            asm("v_fma_mix_f32 %0, %1, 1.0, %2 op_sel:[1,0,1] op_sel_hi:[1,0,1]" : "=v"(d1[j]) : "v"(r.a[j]), "v"(r.b[j]));
         } else {
             d0[j] = __uint_as_float(r.a[j]);
             d1[j] = __uint_as_float(r.b[j]);
@@ -414,17 +415,20 @@ struct PairCompute {
             hx[i] = *reinterpret_cast<const uint4*>(xr + i * 16);
             lx[i] = *reinterpret_cast<const uint4*>(xr + LOX + i * 16);
         }
+        // s += (hi + lo) * w as two v_fma_mix_f32 per value (the f16 halves are read in place: no conversion, no addition); the
+        // products hi * w and lo * w are exact in f32 up to one rounding each, like (hi + lo) * w
         float s = 0.f;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const uint32_t hv[4] = {hx[i].x, hx[i].y, hx[i].z, hx[i].w}, lv[4] = {lx[i].x, lx[i].y, lx[i].z, lx[i].w};
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
-                const f16x2 hh = __builtin_bit_cast(f16x2, hv[k]), ll = __builtin_bit_cast(f16x2, lv[k]);
-                const float x0 = (float)hh[0] + (float)ll[0], x1 = (float)hh[1] + (float)ll[1];
                 const float4 w0 = w.w[2 * i + (k >> 1)];
-                s = fmaf(x0, (k & 1) ? w0.z : w0.x, s);
-                s = fmaf(x1, (k & 1) ? w0.w : w0.y, s);
+                const float wa = (k & 1) ? w0.z : w0.x, wb = (k & 1) ? w0.w : w0.y;
+                asm("v_fma_mix_f32 %0, %1, %2, %0 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "+v"(s) : "v"(hv[k]), "v"(wa));
+                asm("v_fma_mix_f32 %0, %1, %2, %0 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "+v"(s) : "v"(lv[k]), "v"(wa));
+                asm("v_fma_mix_f32 %0, %1, %2, %0 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(s) : "v"(hv[k]), "v"(wb));
+                asm("v_fma_mix_f32 %0, %1, %2, %0 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(s) : "v"(lv[k]), "v"(wb));
             }
         }
         s += dpp_xor1(s);
@@ -432,6 +436,33 @@ struct PairCompute {
         if (p == 0) jb.mp[e] = s;
     }
 };
+
+// Pair products of one head and step, one PASS (64 entries: 4 lanes per entry, 16 entries per wave) at a time, the loads of a pass
+// requested long before they are used: a step holds ~134 entries per head = 3 passes, and the pass loop of gnn_fused_helpers.h
+// (weights one pass ahead) would expose an L2 round trip per head and step here, where the helpers are the critical path.
+struct PairPass {
+    PairW w;
+    int u;
+};
+__device__ __forceinline__ void pass_issue(PairPass& pp, const PairJob& jb, int k, int wave, int lane) {
+    const int e = jb.e + wave * 16 + (lane >> 2) + 64 * k;
+    pp.u = jb.t0;
+    if (e < jb.e_end) {
+        pp.u = jb.pos[e];
+        pair_load_w(pp.w, jb, e, lane & 3);
+    }
+}
+__device__ __forceinline__ void pass_compute(const PairPass& pp, const PairJob& jb, int k, int wave, int lane) {
+    const int e = jb.e + wave * 16 + (lane >> 2) + 64 * k;
+    if (e < jb.e_end) PairCompute::run(pp.w, jb, e, pp.u, lane & 3);
+}
+// a crowded step (more than 3 passes; rare): the remaining passes one by one, loads not hidden
+__device__ __forceinline__ void pass_rest(PairPass& pp, const PairJob& jb, int k0, int wave, int lane) {
+    for (int e = jb.e + wave * 16 + (lane >> 2) + 64 * k0; e < jb.e_end; e += 64) {
+        pair_load_w(pp.w, jb, e, lane & 3);
+        PairCompute::run(pp.w, jb, e, jb.pos[e], lane & 3);
+    }
+}
 
 template <bool PROF>
 __global__ __launch_bounds__(512, 2) void fused_front_tc_kernel(Args a) {
@@ -558,6 +589,9 @@ __global__ __launch_bounds__(512, 2) void fused_front_tc_kernel(Args a) {
                 gather_finish(g, bufX, gua + 64, gpq);
             }
         }
+        // the helpers are this kernel's critical path (the matrix waves wait for their chunks): they outrank the matrix waves, whose
+        // one MFMA per 32 cycles needs few issue slots (43.5 k vs 46.1 k cycles per step, profiles/r04/tc_ab_prio_slp.txt)
+        __builtin_amdgcn_s_setprio(3);
         uint32_t nlo = 0, nhi = 0;                       // bytes of this thread's pair row of the step AFTER next
         if (ht < PROW_N) prow_fetch(bases, (s_begin + 2) * FTT - CARRY + ht, nlo, nhi);
         const HLane h1 = hlane(smem, 0, hw, lane, 2), h2 = hlane(smem, BUF_BYTES, hw, lane, 4);
@@ -565,6 +599,8 @@ __global__ __launch_bounds__(512, 2) void fused_front_tc_kernel(Args a) {
         __syncthreads();
         if constexpr (PROF) tick_ = __builtin_readcyclecounter();
         Raw16 ra, rb;
+        PairPass p0, p1;
+        p0.u = p1.u = 0;
         // V2 chunks 0 and 1 of the first step
         load_x1(ra, h1, 0);
         load_x1(rb, h1, 1);
@@ -575,95 +611,104 @@ __global__ __launch_bounds__(512, 2) void fused_front_tc_kernel(Args a) {
         for (int step = s_begin; step < s_hi; ++step) {
             const int t0 = step * FTT;
             const uint16_t* prow = prow2((step + 1) & 1);
-            const bool hb = step - 1 >= s_lo, ha = step >= s_lo;
+            const bool hb = step - 1 >= s_lo, ha = step >= s_lo;                 // a warm-up step of a time-split run stores nothing
             const int sb = max(step - 1, 0);
             GNN_TICK(10)
-            // ---- conv2 phase: chunks 2 .. 7 (ra holds the rows of chunk 2), then the pair products
-            TC_BARRIER_W();                                                      // b_0
+            // Pair products: head B's entries of step s-1 (x3 in bufY until the conv2 epilogue behind b_7) and head A's of step s (x1 in
+            // bufX until the gather behind b'_0), as a stream of 3 + 3 passes through two register sets: a pass is computed two or more
+            // units after its loads were requested, and the set is re-used for the pass after next.  A warm-up step (time split)
+            // stores nothing: hb / ha.
+            const PairJob jb = {bufY, a.weff[1], a.pos_sorted[1], mp_w[1], t0 - FTT, hb ? a.bucket_ptr[1][sb] : 0, hb ? a.bucket_ptr[1][sb + 1] : 0};
+            const PairJob ja = {bufX, a.weff[0], a.pos_sorted[0], mp_w[0], t0, ha ? a.bucket_ptr[0][step] : 0, ha ? a.bucket_ptr[0][step + 1] : 0};
+            // ---- conv2 phase: chunks 2 .. 7 (ra holds the rows of chunk 2; p0 / p1 the B passes 0 / 1, requested behind B0)
+            HBAR_W(8, 9);                                                        // b_0
             load_x1(rb, h1, 3);
             transform_store<true>(ra, h1, 2);
-            TC_BARRIER_W();                                                      // b_1
+            HBAR_W(8, 9);                                                        // b_1
+            pass_compute(p0, jb, 0, hw, lane);
+            pass_issue(p0, jb, 2, hw, lane);
             load_x1(ra, h1, 4);
             transform_store<true>(rb, h1, 0);
-            TC_BARRIER_W();                                                      // b_2
+            HBAR_W(8, 9);                                                        // b_2
+            pass_compute(p1, jb, 1, hw, lane);
+            pass_issue(p1, ja, 0, hw, lane);
             load_x1(rb, h1, 5);
             transform_store<true>(ra, h1, 1);
-            TC_BARRIER_W();                                                      // b_3
+            HBAR_W(8, 9);                                                        // b_3
             load_x1(ra, h1, 6);
             transform_store<true>(rb, h1, 2);
-            TC_BARRIER_W();                                                      // b_4
+            HBAR_W(8, 9);                                                        // b_4
+            pass_compute(p0, jb, 2, hw, lane);
+            pass_rest(p0, jb, 3, hw, lane);
+            pass_issue(p0, ja, 1, hw, lane);
             load_x1(rb, h1, 7);
             transform_store<true>(ra, h1, 0);
-            TC_BARRIER_W();                                                      // b_5
+            HBAR_W(8, 9);                                                        // b_5
             transform_store<true>(rb, h1, 1);
-            GNN_TICK(8)
-            TC_BARRIER_W();                                                      // b_6
-            {
-                // head B's entries of step s-1 (x3 in bufY, overwritten by the conv2 epilogue behind b_7) and head A's of step s
-                const PairJob jb = {bufY, a.weff[1], a.pos_sorted[1], mp_w[1], t0 - FTT, hb ? a.bucket_ptr[1][sb] : 0, hb ? a.bucket_ptr[1][sb + 1] : 0};
-                const PairJob none = {bufX, a.weff[0], a.pos_sorted[0], mp_w[0], 0, 0, 0};
-                m_partials2<PairCompute>(jb, none, hw, lane);
-            }
-            GNN_TICK(9)
-            TC_BARRIER();                                                        // b_7
+            HBAR_W(8, 9);                                                        // b_6
+            pass_compute(p1, ja, 0, hw, lane);
+            pass_issue(p1, ja, 2, hw, lane);
+            HBAR(8, 9);                                                          // b_7
+            pass_compute(p0, ja, 1, hw, lane);
             uint4 carry = make_uint4(0, 0, 0, 0);
             if (ht < CARRY * ROW_U4) carry = *reinterpret_cast<const uint4*>(bufX + (FTT + cr) * ROWX + cc * 16);
-            GNN_TICK(11)
-            TC_BARRIER();                                                        // ---- B1: x2 is in bufY
-            // V3 chunks 0, 1 beside the matrix waves' w_v A, then head A's pair products (bufX stays x1(s) until the gather)
+            HBAR(8, 10);                                                         // ---- B1: x2 is in bufY
+            // the last pass of head A, then V3 chunks 0, 1, beside the matrix waves' w_v A
             load_x2(ra, h2, 0);
             load_x2(rb, h2, 1);
+            pass_compute(p1, ja, 2, hw, lane);
+            pass_rest(p1, ja, 3, hw, lane);
             transform_store<false>(ra, h2, 0);
             load_x2(ra, h2, 2);
             transform_store<false>(rb, h2, 1);
-            {
-                const PairJob ja = {bufX, a.weff[0], a.pos_sorted[0], mp_w[0], t0, ha ? a.bucket_ptr[0][step] : 0, ha ? a.bucket_ptr[0][step + 1] : 0};
-                const PairJob none = {bufY, a.weff[1], a.pos_sorted[1], mp_w[1], 0, 0, 0};
-                m_partials2<PairCompute>(none, ja, hw, lane);
-            }
             GNN_TICK(12)
-            // ---- conv3 phase: chunks 2 .. 7, the conv1 gather of the next step, carry rows, pair rows
-            TC_BARRIER_W();                                                      // b'_0: nobody reads bufX any more
-            if (ht < CARRY * ROW_U4) *reinterpret_cast<uint4*>(bufX + cr * ROWX + cc * 16) = carry;
-            load_x2(rb, h2, 3);
-            transform_store<false>(ra, h2, 2);
-            TC_BARRIER_W();                                                      // b'_1
-            load_x2(ra, h2, 4);
-            transform_store<false>(rb, h2, 0);
-            TC_BARRIER_W();                                                      // b'_2
-            load_x2(rb, h2, 5);
-            transform_store<false>(ra, h2, 1);
-            TC_BARRIER_W();                                                      // b'_3
-            load_x2(ra, h2, 6);
-            transform_store<false>(rb, h2, 2);
-            TC_BARRIER_W();                                                      // b'_4
-            load_x2(rb, h2, 7);
-            transform_store<false>(ra, h2, 0);
-            TC_BARRIER_W();                                                      // b'_5
-            transform_store<false>(rb, h2, 1);
-            GNN_TICK(13)
+            // ---- conv3 phase: chunks 2 .. 7, the conv1 gather of the next step (table loads two units ahead of their use),
+            // carry rows, pair rows
             {
                 GatherUnit g;
+                HBAR_W(13, 14);                                                  // b'_0: nobody reads bufX any more
+                if (ht < CARRY * ROW_U4) *reinterpret_cast<uint4*>(bufX + cr * ROWX + cc * 16) = carry;
                 gather_issue(g, prow, a.conv1_k, gua, gpq);
-                TC_BARRIER_W();                                                  // b'_6: V3 is complete
-                // x2 carry rows: nobody reads rows 0..4 of bufY any more, the conv3 epilogue (behind b'_7) overwrites rows 96..100
-                if (ht < CARRY * ROW_U4) {
-                    const uint4 c2 = *reinterpret_cast<const uint4*>(bufY + (FTT + cr) * ROWX + cc * 16);
-                    *reinterpret_cast<uint4*>(bufY + cr * ROWX + cc * 16) = c2;
-                }
+                load_x2(rb, h2, 3);
+                transform_store<false>(ra, h2, 2);
+                HBAR_W(13, 14);                                                  // b'_1
+                load_x2(ra, h2, 4);
+                transform_store<false>(rb, h2, 0);
+                HBAR_W(13, 14);                                                  // b'_2
                 gather_finish(g, bufX, gua, gpq);
                 if (g1_on) gather_issue(g, prow, a.conv1_k, gua + 64, gpq);
-                TC_BARRIER_W();                                                  // b'_7
+                load_x2(rb, h2, 5);
+                transform_store<false>(ra, h2, 1);
+                HBAR_W(13, 14);                                                  // b'_3
+                load_x2(ra, h2, 6);
+                transform_store<false>(rb, h2, 2);
+                HBAR_W(13, 14);                                                  // b'_4
+                load_x2(rb, h2, 7);
+                transform_store<false>(ra, h2, 0);
+                HBAR_W(13, 14);                                                  // b'_5
+                transform_store<false>(rb, h2, 1);
+                HBAR_W(13, 14);                                                  // b'_6: V3 is complete
                 if (g1_on) gather_finish(g, bufX, gua + 64, gpq);
             }
-            if (ht < PROW_N) {                                                   // pair rows of step s+2 (parity buffer of step s: read last before b'_6)
+            // x2 carry rows: nobody reads rows 0..4 of bufY any more, the conv3 epilogue (behind b'_7) overwrites rows 96..100
+            if (ht < CARRY * ROW_U4) {
+                const uint4 c2 = *reinterpret_cast<const uint4*>(bufY + (FTT + cr) * ROWX + cc * 16);
+                *reinterpret_cast<uint4*>(bufY + cr * ROWX + cc * 16) = c2;
+            }
+            if (ht < PROW_N) {                                                   // pair rows of step s+2 (parity buffer of step s: read last before b'_2)
                 const int t = t0 + 2 * FTT - CARRY + ht;
                 prow2(step & 1)[ht] = prow_make(nlo, nhi, t);
                 prow_fetch(bases, t + FTT, nlo, nhi);
             }
-            GNN_TICK(14)
-            TC_BARRIER_W();                                                      // ---- B0: x3 is in bufY, x1(s+1) in bufX
-            // V2 chunks 0, 1 of the next step beside the matrix waves' w_v B
+            HBAR_W(13, 14);                                                      // b'_7
+            HBAR(13, 11);                                                        // ---- B0: x3 is in bufY, x1(s+1) in bufX
+            // V2 chunks 0, 1 of the next step beside the matrix waves' w_v B; head B's first two passes of THIS step are requested
+            // for the next iteration (or the tail below)
+            {
+                const PairJob jn = {bufY, a.weff[1], a.pos_sorted[1], mp_w[1], t0, ha ? a.bucket_ptr[1][step] : 0, ha ? a.bucket_ptr[1][step + 1] : 0};
+                pass_issue(p0, jn, 0, hw, lane);
+                pass_issue(p1, jn, 1, hw, lane);
+            }
             load_x1(ra, h1, 0);
             load_x1(rb, h1, 1);
             transform_store<true>(ra, h1, 0);
@@ -672,10 +717,10 @@ __global__ __launch_bounds__(512, 2) void fused_front_tc_kernel(Args a) {
             GNN_TICK(15)
         }
         if (s_hi > s_lo) {                                  // head B's entries of this run's last step
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             const PairJob jb = {bufY, a.weff[1], a.pos_sorted[1], mp_w[1], (s_hi - 1) * FTT, a.bucket_ptr[1][s_hi - 1], a.bucket_ptr[1][s_hi]};
-            const PairJob none = {bufX, a.weff[0], a.pos_sorted[0], mp_w[0], 0, 0, 0};
-            m_partials2<PairCompute>(jb, none, hw, lane);
+            pass_compute(p0, jb, 0, hw, lane);
+            pass_compute(p1, jb, 1, hw, lane);
+            pass_rest(p0, jb, 2, hw, lane);
         }
     }
     if (nsteps < STEPST && part == a.split - 1) {   // the all-N tail: copy instead of compute

@@ -36,3 +36,17 @@ if len(sys.argv) > 2:
     eng.classify_dev(b.ptr, N, s.ptr, "f32")
     eng.sync()
     print(f"f16x3tc vs exact f32 over {N} windows: max |dscore| {np.abs(a - s.download((N, 3), np.float32)).max():.3e}")
+if len(sys.argv) > 2:
+    import ctypes as C
+    names = ["conv2 loop (b0..b7)", "conv2 epilogue", "wait B1", "w_v A + pool", "conv3 loop", "conv3 epilogue", "wait B0", "w_v B + pool (+loop top)",
+             "h conv2 phase: own work between barriers", "h conv2 phase: waiting at b0..b7", "h waiting at B1", "h waiting at B0",
+             "h V3 chunks 0,1 (beside w_v A)", "h conv3 phase: own work between barriers", "h conv3 phase: waiting at b'0..b'7", "h V2 chunks 0,1 (beside w_v B)"]
+    _lib.check(eng.lib.gnn_phase_cycles(eng.ctx, 1, None))
+    eng.classify_dev(b.ptr, 4096, s.ptr, "f16x3tc")
+    eng.sync()
+    out = (C.c_uint64 * 16)()
+    _lib.check(eng.lib.gnn_phase_cycles(eng.ctx, 0, out))
+    per = [v / (4096 * 63) for v in out]
+    print(f"f16x3tc cycles per 96-row step (instrumented build): matrix wave total {sum(per[:8]):.0f}, helper total {sum(per[8:]):.0f}")
+    for nm, v in zip(names, per):
+        print(f"    {nm:50s} {v:8.0f}")
