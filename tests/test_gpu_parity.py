@@ -171,7 +171,7 @@ def test_errors_are_reported_not_swallowed(engine):
 # The parametrised matrix covers the arithmetics that can ship: the default (f16x3), its f32-range fallback (bf16x3) and the one
 # opt-in fast mode (f16c6).  f16c8 and the round-1 kernel are frozen: one smoke test each
 # (test_frozen_f16c8_kernel_smoke, test_single_pass_bf16_is_outside_tolerance_but_sane).
-FUSED = ["f16c6", "f16x3", "bf16x3"]
+FUSED = ["f16c6", "f16x3", "f16x3tc", "bf16x3"]
 # the contig front end is exercised with the default arithmetic first (what main() runs), then the fallback
 from genomad_amd._lib import DEFAULT_PRECISION  # noqa: E402
 CONTIG_PRECS = [DEFAULT_PRECISION, "bf16x3"]
@@ -182,7 +182,7 @@ def test_fused_intermediates(engine, oracle16, prec):
     """Fused kernels (activations in LDS, low-precision MFMA operands) against the fp64 oracle, per stage."""
     bases, scores64, t64 = oracle16
     scores, taps = engine.debug_forward(bases, prec)
-    loose = {"f16c6": 2.5, "f16c8": 2.5, "f16x3": 0.25}.get(prec, 1.0)   # 4-bit correction terms / 11+11-bit limbs vs bf16's 8+8
+    loose = {"f16c6": 2.5, "f16c8": 2.5, "f16x3": 0.25, "f16x3tc": 0.25}.get(prec, 1.0)   # 4-bit correction terms / 11+11-bit limbs vs bf16's 8+8
     checks = [("m_a", "mA", 1e-4), ("m_b", "mB", 1e-3), ("yp_a", "ypA", 1e-4), ("yp_b", "ypB", 1e-3),
               ("alpha_a", "alphaA", 1e-5), ("alpha_b", "alphaB", 2e-4), ("feat", "f", 5e-4)]
     for mine, ref, tol in checks:
@@ -483,7 +483,7 @@ def test_config2_10k_windows_vs_reference_graph_golden(engine, golden_dir):
     n = len(ref32)
     assert n == 10_000
     worst = {}
-    for prec, tol64 in (("f32", 2e-5), ("f16x3", 2e-5), ("bf16x3", SCORE_TOL), ("f16c8", SCORE_TOL), ("f16c6", SCORE_TOL)):
+    for prec, tol64 in (("f32", 2e-5), ("f16x3", 2e-5), ("f16x3tc", 2e-5), ("bf16x3", SCORE_TOL), ("f16c8", SCORE_TOL), ("f16c6", SCORE_TOL)):
         got = _classify_resident(engine, 0, n, prec)
         assert np.isfinite(got).all() and np.allclose(got.sum(1), 1.0, atol=1e-5)
         e32, e64 = np.abs(got - ref32).max(), np.abs(got - truth).max()
@@ -790,7 +790,7 @@ def test_second_weight_set_and_engine(synth_weights):
     assert err["f16c8"] <= 2 * SCORE_TOL and err["f16c6"] <= 2 * SCORE_TOL
 
 
-@pytest.mark.parametrize("prec", ["f16c6", "f16x3", "bf16x3"])
+@pytest.mark.parametrize("prec", ["f16c6", "f16x3", "f16x3tc", "bf16x3"])
 def test_padding_skip_is_bit_identical(engine, prec):
     """The streaming kernels (f16c6; f16x3 / bf16x3 of gnn_fused_x3.hip) copy the yp rows and pair products of a window's all-N tail from an all-N window instead of
     computing them (the padding of a contig's last window, nn_classification.py:72).  With the skip switched off the
@@ -983,7 +983,7 @@ def test_time_split_small_batches_are_bit_identical(engine):
     wins[9] = _pad(b"ACGT" * 700)                          # 2800 bases
     wins[10, 3000:3300] = ord("N")
     try:
-        for prec in ("f16x3", "bf16x3"):
+        for prec in ("f16x3", "f16x3tc", "bf16x3"):
             for n in (1, 2, 40, 64, 65, 86, 128, 130):
                 for skip in (1, 0):
                     _lib.check(engine.lib.gnn_debug_set_pad_skip(engine.ctx, skip))
@@ -994,7 +994,7 @@ def test_time_split_small_batches_are_bit_identical(engine):
                     assert np.array_equal(got, want), (prec, n, skip)
                     for k in wt:
                         assert np.array_equal(gt[k], wt[k]), (prec, n, skip, k)
-                if n > 40 and prec == "bf16x3":
+                if n > 40 and prec != "f16x3":
                     break                                  # the fallback: the small sizes are enough
         _lib.check(engine.lib.gnn_debug_set_pad_skip(engine.ctx, 1))
         # the point of it: one call of 128 windows through the host-buffer entry point
