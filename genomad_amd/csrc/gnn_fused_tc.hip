@@ -620,37 +620,39 @@ __global__ __launch_bounds__(512, 2) void fused_front_tc_kernel(Args a) {
             // stores nothing: hb / ha.
             const PairJob jb = {bufY, a.weff[1], a.pos_sorted[1], mp_w[1], t0 - FTT, hb ? a.bucket_ptr[1][sb] : 0, hb ? a.bucket_ptr[1][sb + 1] : 0};
             const PairJob ja = {bufX, a.weff[0], a.pos_sorted[0], mp_w[0], t0, ha ? a.bucket_ptr[0][step] : 0, ha ? a.bucket_ptr[0][step + 1] : 0};
-            // ---- conv2 phase: chunks 2 .. 7 (ra holds the rows of chunk 2; p0 / p1 the B passes 0 / 1, requested behind B0)
+            // ---- conv2 phase: chunks 2 .. 7 (ra holds the rows of chunk 2; p0 / p1 the B passes 0 / 1, requested behind B0).  Only
+            // the chunk transforms run beside the conv loop; the pair products sit in the intervals in which the matrix waves finish
+            // the loop and run their epilogue without needing anything from the helpers.
             HBAR_W(8, 9);                                                        // b_0
             load_x1(rb, h1, 3);
             transform_store<true>(ra, h1, 2);
             HBAR_W(8, 9);                                                        // b_1
-            pass_compute(p0, jb, 0, hw, lane);
-            pass_issue(p0, jb, 2, hw, lane);
             load_x1(ra, h1, 4);
             transform_store<true>(rb, h1, 0);
             HBAR_W(8, 9);                                                        // b_2
-            pass_compute(p1, jb, 1, hw, lane);
-            pass_issue(p1, ja, 0, hw, lane);
             load_x1(rb, h1, 5);
             transform_store<true>(ra, h1, 1);
             HBAR_W(8, 9);                                                        // b_3
             load_x1(ra, h1, 6);
             transform_store<true>(rb, h1, 2);
             HBAR_W(8, 9);                                                        // b_4
-            pass_compute(p0, jb, 2, hw, lane);
-            pass_rest(p0, jb, 3, hw, lane);
-            pass_issue(p0, ja, 1, hw, lane);
             load_x1(rb, h1, 7);
             transform_store<true>(ra, h1, 0);
             HBAR_W(8, 9);                                                        // b_5
             transform_store<true>(rb, h1, 1);
+            uint4 carry = make_uint4(0, 0, 0, 0);
+            pass_compute(p0, jb, 0, hw, lane);
+            pass_compute(p1, jb, 1, hw, lane);
+            pass_issue(p0, jb, 2, hw, lane);
+            pass_issue(p1, ja, 0, hw, lane);
             HBAR_W(8, 9);                                                        // b_6
+            pass_compute(p0, jb, 2, hw, lane);                                   // head B reads bufY: before b_7, behind which the conv2
+            pass_rest(p0, jb, 3, hw, lane);                                      // epilogue overwrites it
+            pass_issue(p0, ja, 1, hw, lane);
+            HBAR(8, 9);                                                          // b_7
             pass_compute(p1, ja, 0, hw, lane);
             pass_issue(p1, ja, 2, hw, lane);
-            HBAR(8, 9);                                                          // b_7
             pass_compute(p0, ja, 1, hw, lane);
-            uint4 carry = make_uint4(0, 0, 0, 0);
             if (ht < CARRY * ROW_U4) carry = *reinterpret_cast<const uint4*>(bufX + (FTT + cr) * ROWX + cc * 16);
             HBAR(8, 10);                                                         // ---- B1: x2 is in bufY
             // the last pass of head A, then V3 chunks 0, 1, beside the matrix waves' w_v A
@@ -662,45 +664,47 @@ __global__ __launch_bounds__(512, 2) void fused_front_tc_kernel(Args a) {
             load_x2(ra, h2, 2);
             transform_store<false>(rb, h2, 1);
             GNN_TICK(12)
-            // ---- conv3 phase: chunks 2 .. 7, the conv1 gather of the next step (table loads two units ahead of their use),
-            // carry rows, pair rows
+            // ---- conv3 phase: chunks 2 .. 7; the conv1 gather of the next step towards its end (round 0 finished beside unit 6,
+            // round 1 beside the conv3 epilogue), carry rows, pair rows
             {
                 GatherUnit g;
                 HBAR_W(13, 14);                                                  // b'_0: nobody reads bufX any more
                 if (ht < CARRY * ROW_U4) *reinterpret_cast<uint4*>(bufX + cr * ROWX + cc * 16) = carry;
-                gather_issue(g, prow, a.conv1_k, gua, gpq);
                 load_x2(rb, h2, 3);
                 transform_store<false>(ra, h2, 2);
                 HBAR_W(13, 14);                                                  // b'_1
                 load_x2(ra, h2, 4);
                 transform_store<false>(rb, h2, 0);
                 HBAR_W(13, 14);                                                  // b'_2
-                gather_finish(g, bufX, gua, gpq);
-                if (g1_on) gather_issue(g, prow, a.conv1_k, gua + 64, gpq);
                 load_x2(rb, h2, 5);
                 transform_store<false>(ra, h2, 1);
                 HBAR_W(13, 14);                                                  // b'_3
                 load_x2(ra, h2, 6);
                 transform_store<false>(rb, h2, 2);
                 HBAR_W(13, 14);                                                  // b'_4
+                gather_issue(g, prow, a.conv1_k, gua, gpq);
                 load_x2(rb, h2, 7);
                 transform_store<false>(ra, h2, 0);
                 HBAR_W(13, 14);                                                  // b'_5
                 transform_store<false>(rb, h2, 1);
                 HBAR_W(13, 14);                                                  // b'_6: V3 is complete
+                gather_finish(g, bufX, gua, gpq);
+                if (g1_on) gather_issue(g, prow, a.conv1_k, gua + 64, gpq);
+                // x2 carry rows: nobody reads rows 0..4 of bufY any more, the conv3 epilogue (behind b'_7) overwrites rows 96..100
+                if (ht < CARRY * ROW_U4) {
+                    const uint4 c2 = *reinterpret_cast<const uint4*>(bufY + (FTT + cr) * ROWX + cc * 16);
+                    *reinterpret_cast<uint4*>(bufY + cr * ROWX + cc * 16) = c2;
+                }
+                HBAR_W(13, 14);                                                  // b'_7
                 if (g1_on) gather_finish(g, bufX, gua + 64, gpq);
             }
-            // x2 carry rows: nobody reads rows 0..4 of bufY any more, the conv3 epilogue (behind b'_7) overwrites rows 96..100
-            if (ht < CARRY * ROW_U4) {
-                const uint4 c2 = *reinterpret_cast<const uint4*>(bufY + (FTT + cr) * ROWX + cc * 16);
-                *reinterpret_cast<uint4*>(bufY + cr * ROWX + cc * 16) = c2;
-            }
-            if (ht < PROW_N) {                                                   // pair rows of step s+2 (parity buffer of step s: read last before b'_2)
+            if (ht < PROW_N) {                                                   // pair rows of step s+2 (parity buffer of step s: read last before b'_7)
                 const int t = t0 + 2 * FTT - CARRY + ht;
                 prow2(step & 1)[ht] = prow_make(nlo, nhi, t);
                 prow_fetch(bases, t + FTT, nlo, nhi);
             }
-            HBAR_W(13, 14);                                                      // b'_7
+            GNN_TICK(13)
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             HBAR(13, 11);                                                        // ---- B0: x3 is in bufY, x1(s+1) in bufX
             // V2 chunks 0, 1 of the next step beside the matrix waves' w_v B; head B's first two passes of THIS step are requested
             // for the next iteration (or the tail below)
