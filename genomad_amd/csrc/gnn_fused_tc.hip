@@ -84,6 +84,15 @@ struct WU {
 };
 
 #define TC_BARRIER() asm volatile("s_barrier" ::: "memory")
+// The helpers outrank the matrix waves (priority 2) while the conv loops wait for their chunks, and yield beside the w_v tiles,
+// where the matrix waves are the critical path and the helpers have time to spare.  -DTC_HPRIO_STATIC keeps them at 3 throughout.
+#ifdef TC_HPRIO_STATIC
+#define TC_HPRIO_LOW()
+#define TC_HPRIO_HIGH()
+#else
+#define TC_HPRIO_LOW() __builtin_amdgcn_s_setprio(1)
+#define TC_HPRIO_HIGH() __builtin_amdgcn_s_setprio(3)
+#endif
 // helper-side barrier with the PROF counters around it: `work` collects the time since the last tick, `wait` the time in the barrier
 #define HBAR_W(work, wait) GNN_TICK(work) TC_BARRIER_W(); GNN_TICK(wait)
 #define HBAR(work, wait) GNN_TICK(work) TC_BARRIER(); GNN_TICK(wait)
@@ -623,6 +632,7 @@ __global__ __launch_bounds__(512, 2) void fused_front_tc_kernel(Args a) {
             // ---- conv2 phase: chunks 2 .. 7 (ra holds the rows of chunk 2; p0 / p1 the B passes 0 / 1, requested behind B0).  Only
             // the chunk transforms run beside the conv loop; the pair products sit in the intervals in which the matrix waves finish
             // the loop and run their epilogue without needing anything from the helpers.
+            TC_HPRIO_HIGH();
             HBAR_W(8, 9);                                                        // b_0
             load_x1(rb, h1, 3);
             transform_store<true>(ra, h1, 2);
@@ -655,6 +665,7 @@ __global__ __launch_bounds__(512, 2) void fused_front_tc_kernel(Args a) {
             pass_compute(p0, ja, 1, hw, lane);
             if (ht < CARRY * ROW_U4) carry = *reinterpret_cast<const uint4*>(bufX + (FTT + cr) * ROWX + cc * 16);
             HBAR(8, 10);                                                         // ---- B1: x2 is in bufY
+            TC_HPRIO_LOW();
             // the last pass of head A, then V3 chunks 0, 1, beside the matrix waves' w_v A
             load_x2(ra, h2, 0);
             load_x2(rb, h2, 1);
@@ -668,6 +679,7 @@ __global__ __launch_bounds__(512, 2) void fused_front_tc_kernel(Args a) {
             // round 1 beside the conv3 epilogue), carry rows, pair rows
             {
                 GatherUnit g;
+                TC_HPRIO_HIGH();
                 HBAR_W(13, 14);                                                  // b'_0: nobody reads bufX any more
                 if (ht < CARRY * ROW_U4) *reinterpret_cast<uint4*>(bufX + cr * ROWX + cc * 16) = carry;
                 load_x2(rb, h2, 3);
@@ -706,6 +718,7 @@ __global__ __launch_bounds__(512, 2) void fused_front_tc_kernel(Args a) {
             GNN_TICK(13)
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             HBAR(13, 11);                                                        // ---- B0: x3 is in bufY, x1(s+1) in bufX
+            TC_HPRIO_LOW();
             // V2 chunks 0, 1 of the next step beside the matrix waves' w_v B; head B's first two passes of THIS step are requested
             // for the next iteration (or the tail below)
             {
