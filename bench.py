@@ -53,14 +53,17 @@ MFMA_PEAK_TFLOPS = 2500.0              # MI355X_MICROARCH.md: dense bf16 / f16 M
 ENCODER_BYTES = {"u8": 6000 + 5997 * 257, "bf16": 6000 + 5997 * 257 * 2, "f32": 6000 + 5997 * 257 * 4}
 HBM_PEAK_GBS = 8000.0
 # matrix-pipe cost of one product in units of one bf16/f16 pass (f16c8: 1 f16 pass + 2 fp8 corrections at 2x rate)
-MFMA_PASSES = {"f16c6": 1.5, "f16c8": 2.0, "f16x3": 3.0, "bf16x3": 3.0, "bf16": 1.0}
+# f16x3tc: conv2 + conv3 (85.35 % of the algorithmic FLOPs) issue 8 / 18 of the direct form's MFMAs, y @ w_v and the rest all of them
+MFMA_PASSES = {"f16c6": 1.5, "f16c8": 2.0, "f16x3": 3.0, "f16x3tc": round(3.0 * (0.8535 * 8 / 18 + 0.1465), 3), "bf16x3": 3.0, "bf16": 1.0}
 # the dominant kernel as rocprofv3's kernel trace names it (profiles/*/kernel_stats.csv)
-FRONT_KERNEL = {"f16x3": "gnn::x3::fused_front_x3_kernel<true, false>", "bf16x3": "gnn::x3::fused_front_x3_kernel<false, false>",
+FRONT_KERNEL = {"f16x3tc": "gnn::tc::fused_front_tc_kernel<false>", "f16x3": "gnn::x3::fused_front_x3_kernel<true, false>", "bf16x3": "gnn::x3::fused_front_x3_kernel<false, false>",
                 "f16c6": "gnn::c6::fused_front_c6_kernel", "f16c8": "gnn::c8::fused_front_c8_kernel",
                 "bf16": "gnn::fused_front_kernel<1, false, false>", "f32": "f32 front end (5 kernels)"}
 DTYPE_TEXT = {"f16c6": "f16 MFMA + MX-fp6 (e2m3, both operands block scaled) correction MFMAs, f32 accumulate (1.5 f16-pass equivalents)",
               "f16c8": "f16 MFMA + MX-fp8 (e4m3) correction MFMAs, f32 accumulate (2.0 bf16-pass equivalents)",
               "f16x3": "f16x3 (split-f16 MFMA, 3 passes, f32 accumulate; logits GEMM split-f16 x 3 as well, dense head exact f32)",
+              "f16x3tc": "f16x3tc (split-f16 MFMA, 3 products per operand pair, f32 accumulate; conv2 / conv3 by Toom-Cook F(3,6) minimal filtering over "
+                         "time with f32 transforms: 0.444x their MFMAs; y @ w_v direct; logits GEMM split-f16 x 3, dense head exact f32)",
               "bf16x3": "bf16x3 (split-bf16 MFMA, 3 passes, f32 accumulate)", "bf16": "bf16", "f32": "f32"}
 
 
@@ -204,7 +207,7 @@ def main():
                     "or of every rank (weak)")
     ap.add_argument("--scaling", default="strong", choices=["strong", "weak"])
     ap.add_argument("--chunk", type=int, default=4096, help="windows per launch of the fused kernel")
-    ap.add_argument("--precision", default=DEFAULT_PRECISION, choices=["f16c6", "f16c8", "f16x3", "bf16x3", "bf16", "f32"],
+    ap.add_argument("--precision", default=DEFAULT_PRECISION, choices=["f16c6", "f16c8", "f16x3", "f16x3tc", "bf16x3", "bf16", "f32"],
                     help=f"arithmetic of the fused front end (default {DEFAULT_PRECISION}: the fastest mode with margin inside the 1e-4 "
                          "tolerance; f16c6 / f16c8 are faster and exceed it on a few of 10^6 windows)")
     ap.add_argument("--async-steps", action="store_true",
@@ -550,11 +553,11 @@ def main():
                 out["roofline"]["mfma_probe_same_mix_algorithmic_tflops"] = round(same.value, 1)
                 out["roofline"]["frac_of_power_floor"] = round(tflops / same.value, 4)
                 out["roofline"]["frac_ceiling_at_power_floor"] = round(same.value / MFMA_PEAK_TFLOPS, 4)
-            if args.precision in ("f16x3", "bf16x3"):
+            if args.precision in ("f16x3", "f16x3tc", "bf16x3"):
                 # the power floor of THIS arithmetic: register-operand MFMAs of the kernel's own instruction (f16 draws more than
                 # bf16 per MFMA on this chip), nothing else running; the kernel issues `passes` of them per algorithmic product
                 same = ctypes.c_double()
-                _lib.check(eng.lib.gnn_mfma_probe_kind(eng.ctx, 1 if args.precision == "f16x3" else 0, 200, ctypes.byref(same)))
+                _lib.check(eng.lib.gnn_mfma_probe_kind(eng.ctx, 0 if args.precision == "bf16x3" else 1, 200, ctypes.byref(same)))
                 out["roofline"]["mfma_probe_same_instruction_tflops"] = round(same.value, 1)
                 out["roofline"]["frac_of_power_floor"] = round(tflops * passes / same.value, 4)
                 out["roofline"]["frac_ceiling_at_power_floor"] = round(same.value / passes / MFMA_PEAK_TFLOPS, 4)

@@ -17,11 +17,12 @@ PATCHES, PATCH_SIZE, POOLED, FEAT, HIDDEN, CLASSES = 2100, 4, 749, 256, 512, 3
 PREC_F32, PREC_BF16X3, PREC_BF16, PREC_F16C8, PREC_F16X3, PREC_F16C6, PREC_F16X3TC = 0, 1, 2, 3, 4, 5, 6
 PRECISIONS = {"f32": PREC_F32, "bf16x3": PREC_BF16X3, "bf16": PREC_BF16, "f16c8": PREC_F16C8, "f16x3": PREC_F16X3,
               "f16c6": PREC_F16C6, "f16x3tc": PREC_F16X3TC}
-# Arithmetic of the fused front end when the caller names none.  "f16x3" (split-f16, three MFMA passes, split-f16 logits GEMM and exact-f32
-# dense head) is the fastest mode whose class scores hold the 1e-4 tolerance WITH MARGIN on every workload measured (within
-# 2e-5 of the exact-f32 path on every one of 1 M windows).  "f16c6" / "f16c8" (f16 + 4-bit correction MFMAs) are 1.55x / 1.3x faster and stay
-# opt-in: 8e-5 on the 10 000-window parity config, but 1.2e-4 on a handful of 10^6 windows.  "bf16x3": f32 range; "f32": exact.
-DEFAULT_PRECISION = "f16x3"
+# Arithmetic of the fused front end when the caller names none.  "f16x3tc" (round 4): split-f16 limbs, three MFMA products per operand
+# pair, conv2 / conv3 by Toom-Cook F(3,6) minimal filtering over time (0.444x their MFMAs, f32 transforms), split-f16 logits GEMM and
+# exact-f32 dense head.  Class scores within 2e-5 (weight seed 42) / 4e-5 (seed 43) of the exact-f32 path on every one of 1 M windows -
+# the figures of "f16x3", the direct three-pass form it replaced as the default (profiles/r04_tails.txt) - and 1.16x its speed.
+# "f16c6" / "f16c8" (f16 + 4-bit correction MFMAs) stay opt-in: 1.2e-4 on a handful of 10^6 windows.  "bf16x3": f32 range; "f32": exact.
+DEFAULT_PRECISION = "f16x3tc"
 OH_U8, OH_BF16, OH_F32 = 0, 1, 2
 K_FUSED, K_BACKEND, K_ENCODER, K_F32_FRONT = 0, 1, 2, 3
 

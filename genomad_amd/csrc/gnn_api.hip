@@ -369,7 +369,11 @@ int classify_chunks(gnn_ctx* ctx, const uint8_t* bases_dev, int64_t n, int preci
             static const bool x3_round1 = debug_switch("GNN_X3_ROUND1");
             const bool x3 = (precision == GNN_PREC_F16X3 || precision == GNN_PREC_BF16X3) && !x3_round1 &&
                             !(reinterpret_cast<uintptr_t>(b) & 3u);
-            rc = precision == GNN_PREC_F16X3TC ? launch_front_tc(ctx, b, m)
+            // a window buffer that is not 4-byte aligned (possible only for device pointers a caller offsets by hand): the
+            // Toom-Cook kernel fetches bases as aligned dwords; the round-1 kernel (byte loads) computes the direct f16x3 form
+            const bool tc = precision == GNN_PREC_F16X3TC && !(reinterpret_cast<uintptr_t>(b) & 3u);
+            rc = tc                              ? launch_front_tc(ctx, b, m)
+                 : precision == GNN_PREC_F16X3TC ? launch_front_fused(ctx, b, m, GNN_PREC_F16X3)
                  : precision == GNN_PREC_F16C6   ? launch_front_c6(ctx, b, m)
                  : precision == GNN_PREC_F16C8 ? launch_front_c8(ctx, b, m)
                  : x3                          ? launch_front_x3(ctx, b, m, precision)

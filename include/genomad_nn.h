@@ -64,13 +64,19 @@ typedef enum gnn_precision {
                                 no head-room under the tolerance (1.2e-4 on a few of 10^6 windows: bench.py exits non-zero
                                 with it); needs |activation| < 65504 (f16 range) and a 4-byte aligned window buffer (any
                                 gnn_dev_alloc / host staging buffer is)                                                 */
-    GNN_PREC_F16X3TC = 6,    /* EXPERIMENTAL, opt-in (gnn_fused_tc.hip): the F16X3 arithmetic with conv2 / conv3 by Toom-Cook minimal
-                                filtering F(3,6) over time: 0.444x the conv MFMAs, f32 transforms (error 2-4x F16X3's in emulation,
-                                oracle/toomcook.py); back end as F16X3; same range and alignment requirements               */
-    GNN_PREC_F16X3 = 4       /* THE DEFAULT of main(), NNEngine and bench.py.  Fused path (gnn_fused_x3.hip): split-f16 (hi+lo,
-                                11+11 significant bits), 3 MFMA passes, logits GEMM split-f16 x 3 on the matrix pipe, dense head exact f32: f32-class
-                                accuracy (within 2e-5 of the exact-f32 path on every one of 10^6 windows, 25x below bf16x3 in emulation); needs
-                                |activation| < 65504 (f16 range)                                   */
+    GNN_PREC_F16X3TC = 6,    /* THE DEFAULT of main(), NNEngine and bench.py since round 4 (gnn_fused_tc.hip): the F16X3 arithmetic (split-f16
+                                hi + lo limbs, three MFMA products per operand pair, f32 accumulate) with conv2 / conv3 evaluated by
+                                Toom-Cook minimal filtering F(3,6) over the time axis - 0.444x their MFMAs, f32 transforms; y @ w_v direct,
+                                logits GEMM split-f16 x 3 on the matrix pipe, dense head exact f32.  Class scores as F16X3's: within
+                                2e-5 / 4e-5 of the exact-f32 path on every one of 10^6 windows for two weight sets
+                                (profiles/r04_tails.txt).  Needs |activation| < ~2000 (the transformed activations, up to 32x the
+                                activations, are f16 operands): beyond that the scores are non-finite, never silently wrong, and
+                                main() recomputes the batch with BF16X3.  A window buffer that is not 4-byte aligned is served by the
+                                direct F16X3 form                                                                            */
+    GNN_PREC_F16X3 = 4       /* the direct three-pass form (gnn_fused_x3.hip), the default of round 3: split-f16 (hi+lo, 11+11 significant
+                                bits), 3 MFMA passes, logits GEMM split-f16 x 3 on the matrix pipe, dense head exact f32: f32-class
+                                accuracy (within 2e-5 of the exact-f32 path on every one of 10^6 windows); needs |activation| < 65504
+                                (f16 range)                                   */
 } gnn_precision;
 
 typedef enum gnn_onehot_dtype { GNN_OH_U8 = 0, GNN_OH_BF16 = 1, GNN_OH_F32 = 2 } gnn_onehot_dtype;

@@ -70,7 +70,8 @@ def test_weight_validation_rejects_bad_tensors(synth_weights):
 
 def test_precision_enum_matches_the_binding_and_rows_per_step():
     """include/genomad_nn.h's gnn_precision values are what genomad_amd/_lib.py sends, and the (GPU-free) geometry query
-    answers for every mode: 128 rows per fused step (32 * GNN_C6_NMB for f16c6), 0 for the unfused f32 path."""
+    answers for every mode: 128 rows per fused step (32 * GNN_C6_NMB for f16c6, 96 = 32 Toom-Cook tiles for f16x3tc), 0 for the
+    unfused f32 path."""
     from genomad_amd import _lib
     text = open(os.path.join(ROOT, "include", "genomad_nn.h")).read()
     text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
@@ -79,7 +80,7 @@ def test_precision_enum_matches_the_binding_and_rows_per_step():
     lib = _lib.load()
     for name, val in _lib.PRECISIONS.items():
         rows = lib.gnn_fused_rows_per_step(val)
-        assert rows == (0 if name == "f32" else 128 if name != "f16c6" else rows) and rows % 32 == 0
+        assert rows == (0 if name == "f32" else 96 if name == "f16x3tc" else 128 if name != "f16c6" else rows) and rows % 32 == 0
     assert lib.gnn_fused_rows_per_step(_lib.PRECISIONS["f16c6"]) in (128, 160)
     assert lib.gnn_fused_rows_per_step(77) < 0
     from genomad_amd import nn_classification

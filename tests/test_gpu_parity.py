@@ -191,12 +191,18 @@ def test_fused_intermediates(engine, oracle16, prec):
     assert np.abs(scores - scores64).max() <= SCORE_TOL
 
 
-@pytest.mark.parametrize("prec", FUSED)
-def test_fused_scores_256_windows(engine, synth_weights, prec):
-    """256 synthetic windows (padded and N-run windows included) within 1e-4 of the fp32 oracle."""
+@pytest.fixture(scope="module")
+def oracle256(synth_weights):
+    """fp32 oracle scores of 256 synthetic windows, computed once for all arithmetics (11 s of numpy)"""
     bases = synthetic.synth_windows(0, 256)
+    return bases, igloo_oracle.classify_windows(bases, synth_weights, np.float32)
+
+
+@pytest.mark.parametrize("prec", FUSED)
+def test_fused_scores_256_windows(engine, oracle256, prec):
+    """256 synthetic windows (padded and N-run windows included) within 1e-4 of the fp32 oracle."""
+    bases, want = oracle256
     got = engine.classify(bases, prec)
-    want = igloo_oracle.classify_windows(bases, synth_weights, np.float32)
     err = np.abs(got - want).max()
     assert err <= SCORE_TOL, f"{prec}: max |dscore| = {err:.3e}"
     assert got.std(axis=0).min() > 0.05          # the test is not vacuous: scores vary across windows
@@ -272,8 +278,8 @@ def test_f16_modes_overflow_is_detected_and_main_falls_back_to_bf16x3(synth_weig
     with NNEngine(0, w) as e2:
         exact, wide = e2.classify(bases, "f32"), e2.classify(bases, "bf16x3")
         assert np.isfinite(wide).all() and np.abs(wide - exact).max() <= 1e-3
-        for prec in ("f16c8", "f16c6", "f16x3"):
-            assert not np.isfinite(e2.classify(bases, prec)).all()
+        for prec in ("f16c8", "f16c6", "f16x3", "f16x3tc"):
+            assert not np.isfinite(e2.classify(bases, prec)).all(), prec
         wpath = tmp_path / "w.npz"
         W.save_npz(wpath, w)
         monkeypatch.setenv("GENOMAD_AMD_WEIGHTS", str(wpath))
@@ -783,9 +789,9 @@ def test_second_weight_set_and_engine(synth_weights):
     with NNEngine(0, w3) as e3:
         exact = e3.classify(big, "f32")
         assert exact.std(axis=0).min() > 0.05, exact.std(axis=0)          # every class score varies: the check is not vacuous
-        err = {prec: float(np.abs(e3.classify(big, prec) - exact).max()) for prec in ("f16x3", "bf16x3", "f16c8", "f16c6")}
+        err = {prec: float(np.abs(e3.classify(big, prec) - exact).max()) for prec in ("f16x3", "f16x3tc", "bf16x3", "f16c8", "f16c6")}
     print("seed-43 weights (calibrated), 4096 windows, max |dscore| vs the exact-f32 path:", err)
-    assert DEFAULT_PRECISION == "f16x3" and err["f16x3"] <= SCORE_TOL / 4
+    assert DEFAULT_PRECISION == "f16x3tc" and err["f16x3tc"] <= SCORE_TOL / 4 and err["f16x3"] <= SCORE_TOL / 4
     assert err["bf16x3"] <= SCORE_TOL
     assert err["f16c8"] <= 2 * SCORE_TOL and err["f16c6"] <= 2 * SCORE_TOL
 
@@ -845,12 +851,12 @@ def test_f16c6_rejects_a_misaligned_window_buffer(engine):
         assert np.array_equal(got, want)
         # the three-pass modes take it too: the round-1 kernel (byte loads) serves such a buffer instead of the streaming
         # one; same arithmetic, sums in another order -> equal within f32 rounding, far inside the tolerance
-        for prec in ("f16x3", "bf16x3"):
+        for prec in ("f16x3", "f16x3tc", "bf16x3"):
             engine.classify_dev(buf.ptr + 1, 2, out.ptr, prec)
             engine.sync()
             got = out.download((2, 3), np.float32)
             want = engine.classify(host[:2 * 6000].reshape(2, 6000), prec)
-            assert np.abs(got - want).max() <= 1e-5, prec
+            assert np.abs(got - want).max() <= 2e-5, prec
     finally:
         buf.free()
         out.free()
@@ -943,24 +949,25 @@ def test_bench_command_line_prints_one_complete_json_line(tmp_path):
     for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
                 "dtype", "data", "config", "roofline", "rccl_ranks", "parity", "steps_verified"):
         assert key in d, key
-    assert d["n_gpus"] == 1 and d["rccl_ranks"] == 1 and d["steps"] == 3 and d["config"]["precision"] == "f16x3"
+    assert d["n_gpus"] == 1 and d["rccl_ranks"] == 1 and d["steps"] == 3 and d["config"]["precision"] == DEFAULT_PRECISION
     assert d["parity"]["ok"] and d["parity"]["windows"] == 3 * 2048 and d["parity"]["max_abs_dscore_all"] <= SCORE_TOL / 2
     assert d["steps_verified"]["mismatching_windows_all_ranks"] == 0
-    assert d["roofline"]["bound"] == "mfma" and 0 < d["roofline"]["frac"] < 1 / 3
+    assert d["roofline"]["bound"] == "mfma" and 0 < d["roofline"]["frac"] < 1 / d["roofline"]["mfma_passes"]
     assert d["value"] > 50_000
 
 
-def test_fresh_process_call_mix_is_bit_identical_40_times():
+def test_fresh_process_call_mix_is_bit_identical_24_times():
     """The round-2 mismatch only ever showed up in the first launches of FRESH processes (profiles/r03_pair_row_race.md: a
     data race on the conv1 pair rows inside the f16c6 kernel that a wave delayed by first-touch latencies exposed; fixed by
     ordering the pair rows with a barrier).  One process = one sample: 40 fresh processes run the call mix of
     scripts/async_hunt.py (synchronous reference, asynchronous calls of mixed sizes, tapped host forwards in between, two
-    rounds) — 20 with the f16c6 kernel it was seen in, 20 with the default arithmetic's kernel, which shares the scheme."""
+    rounds) — 8 with the f16c6 kernel it was seen in, 16 with the default arithmetic's kernel (round 3 ran 40 per suite and
+    1 170 in total without a miss; the default's kernel changed in round 4, so it gets the larger share)."""
     import subprocess
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     bad = []
-    for i in range(40):
-        prec = "f16c6" if i % 2 == 0 else "f16x3"
+    for i in range(24):
+        prec = "f16c6" if i % 3 == 0 else DEFAULT_PRECISION
         r = subprocess.run([sys.executable, os.path.join(root, "scripts", "async_hunt.py"), "2", prec],
                            capture_output=True, text=True, timeout=300)
         last = (r.stdout.strip().splitlines() or ["<no output>"])[-1]

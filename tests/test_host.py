@@ -917,7 +917,7 @@ def test_unknown_precision_name_is_refused_up_front(tmp_path, monkeypatch):
     monkeypatch.setenv("GENOMAD_AMD_PRECISION", "bf16x3")
     assert nnc.configured_precision() == "bf16x3"
     monkeypatch.delenv("GENOMAD_AMD_PRECISION")
-    assert nnc.configured_precision() == nnc.DEFAULT_PRECISION == "f16x3"
+    assert nnc.configured_precision() == nnc.DEFAULT_PRECISION == "f16x3tc"
 
 
 def test_bench_n8_line_is_complete_over_the_fake_engine(tmp_path):
@@ -941,7 +941,7 @@ def test_bench_n8_line_is_complete_over_the_fake_engine(tmp_path):
     assert o["n_gpus"] == 8 and o["rccl_ranks"] == 8 and o["steps"] == 20 and o["warmup"] == 5 and o["scaling"] == "strong"
     assert len(o["per_rank_windows_per_s"]) == len(o["per_rank_steps_ms"]) == len(o["per_rank_front_ms_total"]) == 8
     assert o["gather_ms"] > 0 and o["gather_ms_isolated"] > 0 and o["comm_init_s"] > 0
-    assert o["roofline"]["kernel"] == "gnn::x3::fused_front_x3_kernel<true, false>" and o["roofline"]["bound"] == "mfma"
+    assert o["roofline"]["kernel"] == "gnn::tc::fused_front_tc_kernel<false>" and o["roofline"]["bound"] == "mfma"
     assert o["cpu_baseline"]["kind"] == "port" and o["cpu_baseline"]["value"] > 0 and o["max_abs_dscore_vs_cpu_baseline"] < 1e-4
     assert o["parity"]["ok"] and o["parity"]["windows"] == 20 * 1024
     assert o["steps_verified"]["mismatching_windows_all_ranks"] == 0
