@@ -534,7 +534,7 @@ def main():
             "flop_per_launch": int(FLOP_PER_WINDOW * win_per_launch), "avg_launch_ms": round(avg_ms, 4),
             "launches": int(front_launches), "mfma_passes": passes,
             "note": "achieved counts ALGORITHMIC flops (2.763 GFLOP/window) against the dense 16-bit MFMA peak; the "
-                    "1e-4 tolerance needs more than one 16-bit pass per product (profiles/r02_precision_study.json): "
+                    "1e-4 tolerance needs more than one 16-bit pass per product (profiles/history/r02_precision_study.json): "
                     "mfma_passes bf16-pass equivalents are issued, which caps frac at 1/mfma_passes",
             "backend_ms_total": round(back_ms, 2), "front_ms_total": round(front_ms, 2)}
         if args.precision != "f32":

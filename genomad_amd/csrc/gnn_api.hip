@@ -179,7 +179,7 @@ int finish_pending(gnn_ctx* ctx) {
 // finished before this call does anything.  A host-side wait, not an event wait on ctx->stream: these entry points copy
 // between host and device, allocate and free, and read the workspaces - none of them is on a path where the few hundred
 // microseconds matter, and nothing they do can then depend on how a cross-stream dependency is resolved
-// (profiles/r02c6_async_flake.md).  Callers that never use the asynchronous entry point never have anything pending here.
+// (profiles/history/r02c6_async_flake.md).  Callers that never use the asynchronous entry point never have anything pending here.
 static int check_ctx(gnn_ctx* ctx, bool flush = true) {
     if (!ctx) {
         set_error("ctx is NULL");

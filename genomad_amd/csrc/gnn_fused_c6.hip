@@ -18,7 +18,7 @@
 // v_permlane32_swap, the conv1 gather works on lane pairs (each lane fetches half a block of two neighbouring rows, the
 // halves are swapped with DPP moves) and the IGLOO pair products are mapped 4 lanes per row.
 //
-// Operand layout facts (scripts/probe_mx.hip -> profiles/r02_probe_mx.txt): an fp6 operand of 32x32x64 is 6 dwords
+// Operand layout facts (scripts/probe_mx.hip -> profiles/history/r02_probe_mx.txt): an fp6 operand of 32x32x64 is 6 dwords
 // per lane: lane l = row (or column) l & 31, K block l >> 5, element i of the block in bits [6i, 6i+6); the scale of
 // block 0 is read from lanes 0-31, that of block 1 from lanes 32-63, byte OPSEL of the scale VGPR.
 //
@@ -335,7 +335,7 @@ __device__ __forceinline__ uint32_t f16_exp(float amax) {
 // operand images: h = f16(x) (RNE), x6 = e2m3(h / 2^(E-2)) with E = exponent of the block's largest |h|, and
 // xl6 = e2m3 of the f16 rounding residual x - h, block scaled by the exponent of its own largest element
 // (v_cvt_scalef32_2xpk16_fp6_f32 takes the f32 residuals directly: output slot 2i = first source [i], slot 2i+1 = second
-// source [i], profiles/r02_probe_cvt6.txt).  The scale bytes are what the MFMA multiplies the fragments with
+// source [i], profiles/history/r02_probe_cvt6.txt).  The scale bytes are what the MFMA multiplies the fragments with
 // (2^(byte - 127)).  Instruction count matters here: the helper waves issue beside the matrix waves' MFMA stream, at a
 // fraction of the nominal VALU rate (profiles/README.md), so the maxima are three-operand and nothing is converted twice.
 __device__ __forceinline__ void store_block32(unsigned char* __restrict__ buf, int buf_row, int blk, const float (&x)[32]) {
@@ -452,7 +452,7 @@ __device__ __forceinline__ void wv_pool_store(const f32x16 (&acc)[NMB], wrsrc_t 
 // and the two lanes then swap halves (16 DPP moves) so that each holds all 32 channels of ONE row for the conversion.
 // (Assigning the loads by role instead — each lane fetching the lower half of the row it keeps and the upper half of its
 // partner's — removes the 44 lane-parity selects of gather_store but makes every load touch 16 half lines again: measured
-// 18.64 vs 18.30 ms per 4096 windows, profiles/r02c6_ab_gather_roles.txt.)
+// 18.64 vs 18.30 ms per 4096 windows, profiles/history/r02c6_ab_gather_roles.txt.)
 // (GatherUnit, gather_issue, gather_sum: gnn_fused_helpers.h)
 __device__ __forceinline__ void gather_store(const GatherSum& g, unsigned char* __restrict__ xbuf, int ua, int pq) {
     const bool odd = pq & 1;

@@ -11,12 +11,12 @@
 // scales of the instruction (one E8M0 byte per lane and 32-element K block) put each term at its
 // place: activations use 2^0 (block 0) and 2^-11 (block 1, the residual is stored times 2^11),
 // weights use per-(32 k, column) block exponents chosen at packing time.  Measured in emulation
-// (oracle/precision_study.py, profiles/r02_precision_study.json): max |dscore| 4e-5 vs the fp64 oracle,
+// (oracle/precision_study.py, profiles/history/r02_precision_study.json): max |dscore| 4e-5 vs the fp64 oracle,
 // against 1.6e-5 for split-bf16 x 3 and a tolerance of 1e-4.  The fp8 MFMA runs at twice the f16 rate
 // (64 cycles for K = 64 against 32 cycles for K = 16), so a 32-channel slice of K costs 2 x 32 + 64 = 128
 // matrix-pipe cycles per 32x32 tile instead of 6 x 32 = 192.
 //
-// Operand layout facts established on the hardware by scripts/probe_mx.hip (profiles/r02_probe_mx.txt):
+// Operand layout facts established on the hardware by scripts/probe_mx.hip (profiles/history/r02_probe_mx.txt):
 //  * fp8 operands of 32x32x64: lane l = row (or column) l & 31; its bytes 0-15 are elements
 //    16*(l>>5) .. +15 of K block 0 and its bytes 16-31 the same elements of K block 1; the scale of
 //    block 0 comes from lanes 0-31, the scale of block 1 from lanes 32-63 (byte OPSEL of the scale VGPR).

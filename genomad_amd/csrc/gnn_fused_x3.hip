@@ -143,7 +143,7 @@ __device__ __forceinline__ void unit(const WU& wcur, WU& wload, const XU& xcur, 
     // every MFMA shares one operand register with its predecessor (w_l x_h0, w_h x_h0, w_h x_l0 | w_h x_l1, w_h x_h1, w_l x_h1 |
     // ...): the matrix pipe draws a little less when one operand does not change - 27.80 vs 28.01 ms per 4096 windows against
     // the term-major order (all w_l x_h, then all w_h x_l, then all w_h x_h; GNN_X3_TERM_MAJOR), the loop cycles are the same
-    // (three dependent MFMAs per accumulator in a row do not stall): profiles/r03_x3_operand_chain_ab.txt
+    // (three dependent MFMAs per accumulator in a row do not stall): profiles/history/r03_x3_operand_chain_ab.txt
 #define GNN_MM(W_, X_, mb) acc[mb] = SWAP ? mma16<F16>(W_, X_, acc[mb]) : mma16<F16>(X_, W_, acc[mb])
 #pragma unroll
     for (int mb = 0; mb < NMB; ++mb) {

@@ -57,7 +57,7 @@ typedef enum gnn_precision {
     GNN_PREC_F16C8 = 3,      /* fused path: one f16 MFMA pass + MX-scaled fp8 (e4m3) MFMA corrections of
                                 both operands' f16 rounding residuals = 2.0 pass equivalents; inside the
                                 1e-4 tolerance on BASELINE config 2 with little head-room (DESIGN.md §2,
-                                profiles/r02_precision_study.json); needs |activation| < 65504 (f16 range) */
+                                profiles/history/r02_precision_study.json); needs |activation| < 65504 (f16 range) */
     GNN_PREC_F16C6 = 5,      /* fused path: one f16 MFMA pass + MX-scaled fp6 (e2m3) MFMA corrections, both operands block
                                 scaled (activations per row and 32 channels at run time) = 1.5 pass equivalents; the
                                 accuracy class of F16C8 (config 2: 8.2e-5); the fastest mode, OPT-IN:

@@ -4,7 +4,7 @@ inside 1e-4 WITH MARGIN?  
 TEST INFRASTRUCTURE ONLY — see oracle/__init__.py.  numpy emulation on top of oracle/precision_study.py (same operand rounding,
 same forward pass; products and sums in f64), no GPU:
 
-    python -m oracle.precision_mixes [windows, default 64] > profiles/r03_precision_mixes.txt
+    python -m oracle.precision_mixes [windows, default 64] > profiles/history/r03_precision_mixes.txt
 
 Each of the four matrix-pipe contractions (conv2, conv3, y @ w_v of head A / head B) gets its own scheme; the statistic is the
 rms of the score error over windows x classes next to the maximum (the maximum of a few dozen windows moves by 2x between

@@ -2,7 +2,7 @@
 
 TEST INFRASTRUCTURE ONLY — see oracle/__init__.py.  numpy emulation (no GPU):
 
-    python -m oracle.precision_study [--windows 48] [--seeds 42 43] [--out profiles/r02_precision_study.json]
+    python -m oracle.precision_study [--windows 48] [--seeds 42 43] [--out profiles/history/r02_precision_study.json]
 
 The fused kernel (genomad_amd/csrc/gnn_fused.hip) evaluates four contractions per window on the matrix
 pipe — conv2, conv3 (igloo.py:66: K = 6·128, N = 128) and y @ w_v of both IGLOO heads (igloo.py:208:

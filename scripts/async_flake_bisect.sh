@@ -1,6 +1,6 @@
 #!/bin/bash
 # Bisect the rare mismatch of tests/test_gpu_parity.py::test_asynchronous_classification_is_bit_identical
-# (profiles/r02c6_async_flake.md): the failure showed up once per ~17 FRESH processes and never inside one process, so every
+# (profiles/history/r02c6_async_flake.md): the failure showed up once per ~17 FRESH processes and never inside one process, so every
 # sample here is a new python process.  Each setting changes one thing the HIP runtime does between the two streams; the
 # table at the end says which settings still fail.  ~1 s per sample.
 # Usage (GPU box): bash scripts/async_flake_bisect.sh [samples per setting, default 40] > gpurun_out/async_bisect.txt

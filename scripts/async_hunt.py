@@ -1,4 +1,4 @@
-"""One FRESH-PROCESS sample of the call mix in which gnn_classify_dev_async once mismatched (profiles/r02c6_async_flake.md):
+"""One FRESH-PROCESS sample of the call mix in which gnn_classify_dev_async once mismatched (profiles/history/r02c6_async_flake.md):
 the mismatch showed up in about 1 of 17 fresh processes and never in > 800 in-process repetitions, so the unit of this
 hunt is a process.  Prints one line: "OK ..." or "FAIL <what differed, where>".  scripts/async_hunt.sh runs it under one
 runtime / library setting at a time.

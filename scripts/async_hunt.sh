@@ -1,5 +1,5 @@
 #!/bin/bash
-# Fresh-process hunt for the asynchronous-path mismatch (profiles/r02c6_async_flake.md): scripts/async_hunt.py once per
+# Fresh-process hunt for the asynchronous-path mismatch (profiles/history/r02c6_async_flake.md): scripts/async_hunt.py once per
 # process, N processes per setting, failures per setting and the first diagnostics.
 # Usage (GPU box): bash scripts/async_hunt.sh [N per setting, default 60] [setting ... | auto] > gpurun_out/async_hunt.txt
 # "auto": the two orderings with the round-2 kernel first; the bisecting settings only if one of them failed on this box

@@ -1,0 +1,49 @@
+#!/bin/bash
+# Evidence run (rounds 3 and 4) on the GPU box (via gpurun): rocprofv3 kernel trace + stats and the PMC passes of the default bench
+# command (default arithmetic f16x3tc = fused_front_tc_kernel; BENCH_ARGS='--precision f16c6' for another mode).
+#   scripts/gpu_profile_r04.sh [tag]      -> gpurun_out/<tag>/*
+set -u
+ROOT=$(pwd)
+TAG=${1:-r04}
+OUT=$ROOT/gpurun_out/$TAG
+mkdir -p $OUT
+cd /tmp && export TMPDIR=/tmp
+# 1. kernel trace + stats (back-end overlap off: concurrent kernels stretch each other's trace durations; the one-workgroup
+#    dispatches of the fused kernels in the trace are the all-N calibration windows of gnn_load_weights)
+rm -rf /tmp/kt
+timeout 600 env GNN_NO_BACKEND_OVERLAP=1 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/kt -- \
+  python $ROOT/bench.py --steps 8 --warmup 1 --cpu-sample 0 --check none ${BENCH_ARGS:-} > $OUT/kt.log 2>&1
+cp $(find /tmp/kt -name '*kernel_stats.csv' | head -1) $OUT/kernel_stats.csv 2>/dev/null
+# 2. PMC passes (own runs, kernel trace only; FETCH_SIZE and WRITE_SIZE each alone)
+i=0
+for set in "FETCH_SIZE" "WRITE_SIZE" "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_ANY SQ_LDS_BANK_CONFLICT" "TCC_HIT_sum TCC_MISS_sum TCC_EA0_RDREQ_sum TCC_EA0_WRREQ_sum" "TA_TA_BUSY_sum TD_TD_BUSY_sum SQ_LDS_IDX_ACTIVE SQ_INSTS_VALU SQ_INSTS_VMEM_RD SQ_INSTS_LDS"; do
+  i=$((i+1))
+  rm -rf /tmp/pmc_$i
+  timeout 300 rocprofv3 --kernel-trace --pmc $set --output-format csv -d /tmp/pmc_$i -- \
+    python $ROOT/bench.py --steps 1 --warmup 1 --windows-per-step 4096 --cpu-sample 0 --check none ${BENCH_ARGS:-} > $OUT/pmc_$i.log 2>&1
+  f=$(find /tmp/pmc_$i -name '*counter_collection.csv' | head -1)
+  g=$(find /tmp/pmc_$i -name '*kernel_trace.csv' | head -1)
+  python - "$f" "$g" > $OUT/pmc_$i.txt <<'PY'
+import csv, sys, collections
+def tiny(r):   # one-workgroup dispatches of a fused kernel = the calibration windows of gnn_load_weights, not the workload
+    if 'fused_front' not in r['Kernel_Name']: return False
+    for key in ('Grid_Size', 'Grid_Size_X'):
+        if r.get(key) not in (None, ''): return int(r[key]) <= 512
+    return False
+dur = collections.defaultdict(lambda: [0.0, 0])
+for r in csv.DictReader(open(sys.argv[2])):
+    if tiny(r): continue
+    k = r['Kernel_Name'][:56]
+    dur[k][0] += (int(r['End_Timestamp']) - int(r['Start_Timestamp'])) / 1e6; dur[k][1] += 1
+for k, (v, n) in sorted(dur.items()):
+    print(f"{k:56s} mean duration {v / n:.4f} ms (n={n})")
+acc = collections.defaultdict(lambda: [0.0, 0])
+for r in csv.DictReader(open(sys.argv[1])):
+    if tiny(r): continue
+    k = (r['Kernel_Name'][:56], r['Counter_Name'])
+    acc[k][0] += float(r['Counter_Value']); acc[k][1] += 1
+for (k, c), (v, n) in sorted(acc.items()):
+    print(f"{k:56s} {c:36s} mean/dispatch {v / n:.6g}  (n={n})")
+PY
+done
+ls -la $OUT

@@ -1,4 +1,4 @@
-"""Root-cause demonstration for the rare wrong-result mismatch recorded in profiles/r02c6_async_flake.md.
+"""Root-cause demonstration for the rare wrong-result mismatch recorded in profiles/history/r02c6_async_flake.md.
 
 Round 2's f16c6 kernel wrote the conv1 pair rows of the next step (LDS, one entry per helper thread) at the top of a step
 and let the OTHER helper waves' gathers read them after their pair-product loop, with no workgroup barrier in between: the

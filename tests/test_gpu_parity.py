@@ -957,7 +957,7 @@ def test_bench_command_line_prints_one_complete_json_line(tmp_path):
 
 
 def test_fresh_process_call_mix_is_bit_identical_24_times():
-    """The round-2 mismatch only ever showed up in the first launches of FRESH processes (profiles/r03_pair_row_race.md: a
+    """The round-2 mismatch only ever showed up in the first launches of FRESH processes (profiles/history/r03_pair_row_race.md: a
     data race on the conv1 pair rows inside the f16c6 kernel that a wave delayed by first-touch latencies exposed; fixed by
     ordering the pair rows with a barrier).  One process = one sample: 40 fresh processes run the call mix of
     scripts/async_hunt.py (synchronous reference, asynchronous calls of mixed sizes, tapped host forwards in between, two
