@@ -380,38 +380,37 @@ __device__ __forceinline__ void transform_store(const Raw16& r, const HLane& h, 
     }
 }
 
-// conv1 + LeakyReLU of one (row, 32-channel block) unit -> both planes of the row (gnn_fused_x3.hip)
-__device__ __forceinline__ void store_block32(unsigned char* __restrict__ buf, int buf_row, int blk, const float (&x)[32]) {
-    unsigned char* row = buf + buf_row * ROWX + blk * 64;
-    uint32_t hi[16], lo[16];
+// conv1 gather (model.py:11 + igloo.py:45-48 on the pair tables of gnn_load_weights): one lane = 16 consecutive channels of ONE row,
+// the 8 lanes of a row read one 128-B line per load; 96 rows x 8 = 768 items = exactly 3 per helper lane and step, so the four helper
+// waves carry the same load (the lane-pair scheme of gnn_fused_x3.hip handles 64 rows per round: 1.5 rounds here, two of them on two
+// of the four waves, and 48 lane-parity selects + 16 DPP moves per item that the single-row form does not need).
+struct GRow {
+    f32x4 v[3][4];      // [table][i]: channels 16 pq + 4 i ..
+};
+__device__ __forceinline__ void grow_issue(GRow& g, const uint16_t* __restrict__ prow, const float* __restrict__ pt, int row, int pq) {
 #pragma unroll
-    for (int i = 0; i < 16; ++i) split2<true>(f32x2{x[2 * i], x[2 * i + 1]}, hi[i], lo[i]);
+    for (int j = 0; j < 3; ++j) {
+        const uint32_t r = prow[row + 2 * j];
+        const float* src = pt + ((size_t)j * PAIR_ROWS + r) * C + pq * 4;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        *reinterpret_cast<uint4*>(row + i * 16) = make_uint4(hi[4 * i], hi[4 * i + 1], hi[4 * i + 2], hi[4 * i + 3]);
-        *reinterpret_cast<uint4*>(row + LOX + i * 16) = make_uint4(lo[4 * i], lo[4 * i + 1], lo[4 * i + 2], lo[4 * i + 3]);
+        for (int i = 0; i < 4; ++i) g.v[j][i] = *reinterpret_cast<const f32x4*>(src + i * 32);
     }
 }
-__device__ __forceinline__ void gather_store(const GatherSum& g, unsigned char* __restrict__ xbuf, int ua, int pq) {
-    const bool odd = pq & 1;
-    float x[32];
+__device__ __forceinline__ void grow_finish(const GRow& g, unsigned char* __restrict__ xbuf, int row, int pq) {
+    uint32_t hi[8], lo[8];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-        const f32x4 sa = g.sa[i], sb = g.sb[i];
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const float got = dpp_xor1(odd ? sa[k] : sb[k]);
-            const float c0 = odd ? got : sa[k], c1 = odd ? sb[k] : got;
-            x[4 * i + k] = vmax_raw(c0, c0 * LRELU);
-            x[16 + 4 * i + k] = vmax_raw(c1, c1 * LRELU);
-        }
+        const f32x4 t = g.v[0][i] + g.v[1][i] + g.v[2][i];           // the bias is folded into table 0
+        const float x0 = vmax_raw(t[0], t[0] * LRELU), x1 = vmax_raw(t[1], t[1] * LRELU);
+        const float x2 = vmax_raw(t[2], t[2] * LRELU), x3 = vmax_raw(t[3], t[3] * LRELU);
+        split2<true>(f32x2{x0, x1}, hi[2 * i], lo[2 * i]);
+        split2<true>(f32x2{x2, x3}, hi[2 * i + 1], lo[2 * i + 1]);
     }
-    store_block32(xbuf, CARRY + ua + (odd ? 1 : 0), pq >> 1, x);
-}
-__device__ __forceinline__ void gather_finish(const GatherUnit& g, unsigned char* __restrict__ xbuf, int ua, int pq) {
-    GatherSum t;
-    gather_sum(t, g);
-    gather_store(t, xbuf, ua, pq);
+    unsigned char* o = xbuf + (CARRY + row) * ROWX + pq * 32;
+    *reinterpret_cast<uint4*>(o) = make_uint4(hi[0], hi[1], hi[2], hi[3]);
+    *reinterpret_cast<uint4*>(o + 16) = make_uint4(hi[4], hi[5], hi[6], hi[7]);
+    *reinterpret_cast<uint4*>(o + LOX) = make_uint4(lo[0], lo[1], lo[2], lo[3]);
+    *reinterpret_cast<uint4*>(o + LOX + 16) = make_uint4(lo[4], lo[5], lo[6], lo[7]);
 }
 
 // dot product of an entry's 32 folded weights with block p of row u (x = hi + lo), summed over the entry's 4 lanes (gnn_fused_x3.hip)
@@ -523,10 +522,8 @@ __global__ __launch_bounds__(512, 2) void fused_front_tc_kernel(Args a) {
     __syncthreads();
     unsigned long long cyc[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     unsigned long long tick_ = 0;
-    // conv1 gather: a lane pair owns one 32-channel block of two neighbouring rows; 256 threads = 64 rows per round, 96 rows =
-    // round 0 (all threads) + round 1 (threads 0..127)
-    const int gpq = ht & 7, gua = (ht >> 3) * 2;
-    const bool g1_on = gua + 64 < FTT;
+    // conv1 gather: helper thread ht owns the 16 channels 16 (ht & 7) .. of rows (ht >> 3) + 32 k, k = 0, 1, 2
+    const int gpq = ht & 7, grow0 = ht >> 3;
 
     if (!helper) {
         __builtin_amdgcn_s_setprio(2);
@@ -590,12 +587,11 @@ __global__ __launch_bounds__(512, 2) void fused_front_tc_kernel(Args a) {
         }
     } else {
         {
-            GatherUnit g;
-            gather_issue(g, prow2(s_begin & 1), a.conv1_k, gua, gpq);
-            gather_finish(g, bufX, gua, gpq);
-            if (g1_on) {
-                gather_issue(g, prow2(s_begin & 1), a.conv1_k, gua + 64, gpq);
-                gather_finish(g, bufX, gua + 64, gpq);
+            GRow g;
+#pragma unroll 1
+            for (int k = 0; k < 3; ++k) {
+                grow_issue(g, prow2(s_begin & 1), a.conv1_k, grow0 + 32 * k, gpq);
+                grow_finish(g, bufX, grow0 + 32 * k, gpq);
             }
         }
         // the helpers are this kernel's critical path (the matrix waves wait for their chunks): they outrank the matrix waves, whose
@@ -675,10 +671,10 @@ __global__ __launch_bounds__(512, 2) void fused_front_tc_kernel(Args a) {
             load_x2(ra, h2, 2);
             transform_store<false>(rb, h2, 1);
             GNN_TICK(12)
-            // ---- conv3 phase: chunks 2 .. 7; the conv1 gather of the next step towards its end (round 0 finished beside unit 6,
-            // round 1 beside the conv3 epilogue), carry rows, pair rows
+            // ---- conv3 phase: chunks 2 .. 7; the conv1 gather of the next step (3 rows per lane, table loads two intervals ahead of
+            // their use) in its second half, carry rows, pair rows
             {
-                GatherUnit g;
+                GRow ga, gb;
                 TC_HPRIO_HIGH();
                 HBAR_W(13, 14);                                                  // b'_0: nobody reads bufX any more
                 if (ht < CARRY * ROW_U4) *reinterpret_cast<uint4*>(bufX + cr * ROWX + cc * 16) = carry;
@@ -693,22 +689,24 @@ __global__ __launch_bounds__(512, 2) void fused_front_tc_kernel(Args a) {
                 HBAR_W(13, 14);                                                  // b'_3
                 load_x2(ra, h2, 6);
                 transform_store<false>(rb, h2, 2);
+                grow_issue(ga, prow, a.conv1_k, grow0, gpq);
                 HBAR_W(13, 14);                                                  // b'_4
-                gather_issue(g, prow, a.conv1_k, gua, gpq);
                 load_x2(rb, h2, 7);
                 transform_store<false>(ra, h2, 0);
+                grow_issue(gb, prow, a.conv1_k, grow0 + 32, gpq);
                 HBAR_W(13, 14);                                                  // b'_5
                 transform_store<false>(rb, h2, 1);
+                grow_finish(ga, bufX, grow0, gpq);
+                grow_issue(ga, prow, a.conv1_k, grow0 + 64, gpq);
                 HBAR_W(13, 14);                                                  // b'_6: V3 is complete
-                gather_finish(g, bufX, gua, gpq);
-                if (g1_on) gather_issue(g, prow, a.conv1_k, gua + 64, gpq);
+                grow_finish(gb, bufX, grow0 + 32, gpq);
                 // x2 carry rows: nobody reads rows 0..4 of bufY any more, the conv3 epilogue (behind b'_7) overwrites rows 96..100
                 if (ht < CARRY * ROW_U4) {
                     const uint4 c2 = *reinterpret_cast<const uint4*>(bufY + (FTT + cr) * ROWX + cc * 16);
                     *reinterpret_cast<uint4*>(bufY + cr * ROWX + cc * 16) = c2;
                 }
                 HBAR_W(13, 14);                                                  // b'_7
-                if (g1_on) gather_finish(g, bufX, gua + 64, gpq);
+                grow_finish(ga, bufX, grow0 + 64, gpq);
             }
             if (ht < PROW_N) {                                                   // pair rows of step s+2 (parity buffer of step s: read last before b'_7)
                 const int t = t0 + 2 * FTT - CARRY + ht;
