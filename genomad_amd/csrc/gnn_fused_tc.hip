@@ -396,7 +396,10 @@ __device__ __forceinline__ void grow_issue(GRow& g, const uint16_t* __restrict__
         for (int i = 0; i < 4; ++i) g.v[j][i] = *reinterpret_cast<const f32x4*>(src + i * 32);
     }
 }
-__device__ __forceinline__ void grow_finish(const GRow& g, unsigned char* __restrict__ xbuf, int row, int pq) {
+struct GOut {         // a finished item: 16 channels as f16 hi | lo limbs, waiting for bufX to become writable
+    uint4 h0, h1, l0, l1;
+};
+__device__ __forceinline__ void grow_compute(GOut& o, const GRow& g) {
     uint32_t hi[8], lo[8];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
@@ -406,11 +409,22 @@ __device__ __forceinline__ void grow_finish(const GRow& g, unsigned char* __rest
         split2<true>(f32x2{x0, x1}, hi[2 * i], lo[2 * i]);
         split2<true>(f32x2{x2, x3}, hi[2 * i + 1], lo[2 * i + 1]);
     }
-    unsigned char* o = xbuf + (CARRY + row) * ROWX + pq * 32;
-    *reinterpret_cast<uint4*>(o) = make_uint4(hi[0], hi[1], hi[2], hi[3]);
-    *reinterpret_cast<uint4*>(o + 16) = make_uint4(hi[4], hi[5], hi[6], hi[7]);
-    *reinterpret_cast<uint4*>(o + LOX) = make_uint4(lo[0], lo[1], lo[2], lo[3]);
-    *reinterpret_cast<uint4*>(o + LOX + 16) = make_uint4(lo[4], lo[5], lo[6], lo[7]);
+    o.h0 = make_uint4(hi[0], hi[1], hi[2], hi[3]);
+    o.h1 = make_uint4(hi[4], hi[5], hi[6], hi[7]);
+    o.l0 = make_uint4(lo[0], lo[1], lo[2], lo[3]);
+    o.l1 = make_uint4(lo[4], lo[5], lo[6], lo[7]);
+}
+__device__ __forceinline__ void grow_store(const GOut& o, unsigned char* __restrict__ xbuf, int row, int pq) {
+    unsigned char* d = xbuf + (CARRY + row) * ROWX + pq * 32;
+    *reinterpret_cast<uint4*>(d) = o.h0;
+    *reinterpret_cast<uint4*>(d + 16) = o.h1;
+    *reinterpret_cast<uint4*>(d + LOX) = o.l0;
+    *reinterpret_cast<uint4*>(d + LOX + 16) = o.l1;
+}
+__device__ __forceinline__ void grow_finish(const GRow& g, unsigned char* __restrict__ xbuf, int row, int pq) {
+    GOut o;
+    grow_compute(o, g);
+    grow_store(o, xbuf, row, pq);
 }
 
 // dot product of an entry's 32 folded weights with block p of row u (x = hi + lo), summed over the entry's 4 lanes (gnn_fused_x3.hip)
@@ -463,6 +477,7 @@ __device__ __forceinline__ void pass_issue(PairPass& pp, const PairJob& jb, int 
 __device__ __forceinline__ void pass_compute(const PairPass& pp, const PairJob& jb, int k, int wave, int lane) {
     const int e = jb.e + wave * 16 + (lane >> 2) + 64 * k;
     if (e < jb.e_end) PairCompute::run(pp.w, jb, e, pp.u, lane & 3);
+    GNN_REGION_END();        // keeps the scheduler from hoisting the next pass's 8 row reads (32 registers) above this pass
 }
 // a crowded step (more than 3 passes; rare): the remaining passes one by one, loads not hidden
 __device__ __forceinline__ void pass_rest(PairPass& pp, const PairJob& jb, int k0, int wave, int lane) {
@@ -616,14 +631,13 @@ __global__ __launch_bounds__(512, 2) void fused_front_tc_kernel(Args a) {
         for (int step = s_begin; step < s_hi; ++step) {
             const int t0 = step * FTT;
             const uint16_t* prow = prow2((step + 1) & 1);
-            const bool hb = step - 1 >= s_lo, ha = step >= s_lo;                 // a warm-up step of a time-split run stores nothing
-            const int sb = max(step - 1, 0);
+            const bool ha = step >= s_lo;                                        // false in the warm-up step of a time-split run
             GNN_TICK(10)
-            // Pair products: head B's entries of step s-1 (x3 in bufY until the conv2 epilogue behind b_7) and head A's of step s (x1 in
-            // bufX until the gather behind b'_0), as a stream of 3 + 3 passes through two register sets: a pass is computed two or more
-            // units after its loads were requested, and the set is re-used for the pass after next.  A warm-up step (time split)
-            // stores nothing: hb / ha.
-            const PairJob jb = {bufY, a.weff[1], a.pos_sorted[1], mp_w[1], t0 - FTT, hb ? a.bucket_ptr[1][sb] : 0, hb ? a.bucket_ptr[1][sb + 1] : 0};
+            // Only the chunk transforms run beside the conv loops (the matrix waves wait for every chunk).  The pair products sit where
+            // the matrix waves need nothing from the helpers - head A's (x1 in bufX until the gather behind b'_0) beside units 6, 7 and the
+            // conv2 epilogue, head B's (x3 in bufY from B0 to the next conv2 epilogue) beside w_v B - as 3 passes through two register
+            // sets each (three sets spill).  A warm-up step (time split) stores nothing: ha.
+            const PairJob jb = {bufY, a.weff[1], a.pos_sorted[1], mp_w[1], t0, ha ? a.bucket_ptr[1][step] : 0, ha ? a.bucket_ptr[1][step + 1] : 0};
             const PairJob ja = {bufX, a.weff[0], a.pos_sorted[0], mp_w[0], t0, ha ? a.bucket_ptr[0][step] : 0, ha ? a.bucket_ptr[0][step + 1] : 0};
             // ---- conv2 phase: chunks 2 .. 7 (ra holds the rows of chunk 2; p0 / p1 the B passes 0 / 1, requested behind B0).  Only
             // the chunk transforms run beside the conv loop; the pair products sit in the intervals in which the matrix waves finish
@@ -647,37 +661,44 @@ __global__ __launch_bounds__(512, 2) void fused_front_tc_kernel(Args a) {
             HBAR_W(8, 9);                                                        // b_5
             transform_store<true>(rb, h1, 1);
             uint4 carry = make_uint4(0, 0, 0, 0);
-            pass_compute(p0, jb, 0, hw, lane);
-            pass_compute(p1, jb, 1, hw, lane);
-            pass_issue(p0, jb, 2, hw, lane);
-            pass_issue(p1, ja, 0, hw, lane);
+            // head A's pair products of this step (x1 in bufX until the gather behind b'_0) beside units 6, 7 and the conv2 epilogue:
+            // two register sets; the third pass is requested when the first is done and used last, where the helpers would wait for
+            // the matrix waves anyway
+            // The conv1 gather of the next step (3 rows per lane): rounds 0 and 1 are computed here and beside w_v A, where the helpers have
+            // slack, and wait in 16 registers each for b'_0, behind which bufX may be written; round 2 runs beside conv3.
+            GRow ga;
+            GOut o0, o1;
+            pass_issue(p0, ja, 0, hw, lane);
+            pass_issue(p1, ja, 1, hw, lane);
+            grow_issue(ga, prow, a.conv1_k, grow0, gpq);
             HBAR_W(8, 9);                                                        // b_6
-            pass_compute(p0, jb, 2, hw, lane);                                   // head B reads bufY: before b_7, behind which the conv2
-            pass_rest(p0, jb, 3, hw, lane);                                      // epilogue overwrites it
-            pass_issue(p0, ja, 1, hw, lane);
+            pass_compute(p0, ja, 0, hw, lane);
+            pass_issue(p0, ja, 2, hw, lane);
             HBAR(8, 9);                                                          // b_7
-            pass_compute(p1, ja, 0, hw, lane);
-            pass_issue(p1, ja, 2, hw, lane);
-            pass_compute(p0, ja, 1, hw, lane);
+            pass_compute(p1, ja, 1, hw, lane);
             if (ht < CARRY * ROW_U4) carry = *reinterpret_cast<const uint4*>(bufX + (FTT + cr) * ROWX + cc * 16);
+            grow_compute(o0, ga);
+            grow_issue(ga, prow, a.conv1_k, grow0 + 32, gpq);
+            pass_compute(p0, ja, 2, hw, lane);
+            pass_rest(p0, ja, 3, hw, lane);
             HBAR(8, 10);                                                         // ---- B1: x2 is in bufY
             TC_HPRIO_LOW();
-            // the last pass of head A, then V3 chunks 0, 1, beside the matrix waves' w_v A
+            // V3 chunks 0, 1 beside the matrix waves' w_v A
             load_x2(ra, h2, 0);
             load_x2(rb, h2, 1);
-            pass_compute(p1, ja, 2, hw, lane);
-            pass_rest(p1, ja, 3, hw, lane);
             transform_store<false>(ra, h2, 0);
             load_x2(ra, h2, 2);
             transform_store<false>(rb, h2, 1);
+            grow_compute(o1, ga);
             GNN_TICK(12)
             // ---- conv3 phase: chunks 2 .. 7; the conv1 gather of the next step (3 rows per lane, table loads two intervals ahead of
             // their use) in its second half, carry rows, pair rows
             {
-                GRow ga, gb;
                 TC_HPRIO_HIGH();
                 HBAR_W(13, 14);                                                  // b'_0: nobody reads bufX any more
                 if (ht < CARRY * ROW_U4) *reinterpret_cast<uint4*>(bufX + cr * ROWX + cc * 16) = carry;
+                grow_store(o0, bufX, grow0, gpq);
+                grow_store(o1, bufX, grow0 + 32, gpq);
                 load_x2(rb, h2, 3);
                 transform_store<false>(ra, h2, 2);
                 HBAR_W(13, 14);                                                  // b'_1
@@ -689,53 +710,46 @@ __global__ __launch_bounds__(512, 2) void fused_front_tc_kernel(Args a) {
                 HBAR_W(13, 14);                                                  // b'_3
                 load_x2(ra, h2, 6);
                 transform_store<false>(rb, h2, 2);
-                grow_issue(ga, prow, a.conv1_k, grow0, gpq);
                 HBAR_W(13, 14);                                                  // b'_4
                 load_x2(rb, h2, 7);
                 transform_store<false>(ra, h2, 0);
-                grow_issue(gb, prow, a.conv1_k, grow0 + 32, gpq);
+                grow_issue(ga, prow, a.conv1_k, grow0 + 64, gpq);
                 HBAR_W(13, 14);                                                  // b'_5
                 transform_store<false>(rb, h2, 1);
-                grow_finish(ga, bufX, grow0, gpq);
-                grow_issue(ga, prow, a.conv1_k, grow0 + 64, gpq);
                 HBAR_W(13, 14);                                                  // b'_6: V3 is complete
-                grow_finish(gb, bufX, grow0 + 32, gpq);
+                grow_finish(ga, bufX, grow0 + 64, gpq);
                 // x2 carry rows: nobody reads rows 0..4 of bufY any more, the conv3 epilogue (behind b'_7) overwrites rows 96..100
                 if (ht < CARRY * ROW_U4) {
                     const uint4 c2 = *reinterpret_cast<const uint4*>(bufY + (FTT + cr) * ROWX + cc * 16);
                     *reinterpret_cast<uint4*>(bufY + cr * ROWX + cc * 16) = c2;
                 }
                 HBAR_W(13, 14);                                                  // b'_7
-                grow_finish(ga, bufX, grow0 + 64, gpq);
             }
             if (ht < PROW_N) {                                                   // pair rows of step s+2 (parity buffer of step s: read last before b'_7)
                 const int t = t0 + 2 * FTT - CARRY + ht;
                 prow2(step & 1)[ht] = prow_make(nlo, nhi, t);
                 prow_fetch(bases, t + FTT, nlo, nhi);
             }
+            // head B's pair products of this step (x3 in bufY from B0 to the next conv2 epilogue): the first two passes requested
+            // beside the conv3 epilogue; behind B0, beside the matrix waves' w_v B: pass 0, the third pass's request, pass 1, V2 chunks
+            // 0, 1 of the next step, pass 2
+            pass_issue(p0, jb, 0, hw, lane);
+            pass_issue(p1, jb, 1, hw, lane);
             GNN_TICK(13)
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             HBAR(13, 11);                                                        // ---- B0: x3 is in bufY, x1(s+1) in bufX
             TC_HPRIO_LOW();
-            // V2 chunks 0, 1 of the next step beside the matrix waves' w_v B; head B's first two passes of THIS step are requested
-            // for the next iteration (or the tail below)
-            {
-                const PairJob jn = {bufY, a.weff[1], a.pos_sorted[1], mp_w[1], t0, ha ? a.bucket_ptr[1][step] : 0, ha ? a.bucket_ptr[1][step + 1] : 0};
-                pass_issue(p0, jn, 0, hw, lane);
-                pass_issue(p1, jn, 1, hw, lane);
-            }
             load_x1(ra, h1, 0);
             load_x1(rb, h1, 1);
+            pass_compute(p0, jb, 0, hw, lane);
+            pass_issue(p0, jb, 2, hw, lane);
+            pass_compute(p1, jb, 1, hw, lane);
             transform_store<true>(ra, h1, 0);
             load_x1(ra, h1, 2);
             transform_store<true>(rb, h1, 1);
+            pass_compute(p0, jb, 2, hw, lane);
+            pass_rest(p0, jb, 3, hw, lane);
             GNN_TICK(15)
-        }
-        if (s_hi > s_lo) {                                  // head B's entries of this run's last step
-            const PairJob jb = {bufY, a.weff[1], a.pos_sorted[1], mp_w[1], (s_hi - 1) * FTT, a.bucket_ptr[1][s_hi - 1], a.bucket_ptr[1][s_hi]};
-            pass_compute(p0, jb, 0, hw, lane);
-            pass_compute(p1, jb, 1, hw, lane);
-            pass_rest(p0, jb, 2, hw, lane);
         }
     }
     if (nsteps < STEPST && part == a.split - 1) {   // the all-N tail: copy instead of compute
