@@ -230,7 +230,6 @@ def _engine():
     return _ENGINE
 
 
-F16_MODES = ("f16c8", "f16c6", "f16x3", "f16x3tc")     # their operands are f16: activations beyond 65504 overflow to inf -> NaN scores
 
 
 def configured_precision() -> str:
@@ -244,22 +243,29 @@ def configured_precision() -> str:
 _WARNED = set()
 
 
-def _range_fallback(console, what):
-    """The f16-operand modes cannot represent activations beyond 65504; scores that come back
-    non-finite are recomputed with the split-bf16 kernel, which has the f32 range.  Said once per run."""
-    if what not in _WARNED:
-        _WARNED.add(what)
-        msg = (f"Non-finite class scores from the f16 arithmetic ({what}): activations left the f16 range; "
-               "recomputing the affected batch with bf16x3.")
+# what to recompute a batch with when an f16-operand arithmetic returns non-finite scores: the Toom-Cook form's transformed
+# activations leave the f16 range first (|activation| > ~2 000), the direct f16 forms at 65 504, bf16x3 has the f32 range
+RANGE_FALLBACKS = {"f16x3tc": ("f16x3", "bf16x3"), "f16x3": ("bf16x3",), "f16c6": ("bf16x3",), "f16c8": ("bf16x3",)}
+
+
+def _range_fallback(console, what, to):
+    """The f16-operand modes cannot represent activations beyond their range; scores that come back
+    non-finite are recomputed with the next arithmetic of RANGE_FALLBACKS.  Said once per run and pair."""
+    if (what, to) not in _WARNED:
+        _WARNED.add((what, to))
+        msg = (f"Non-finite class scores from the f16 arithmetic ({what}): activations left its range; "
+               f"recomputing the affected batch with {to}.")
         (console.log if console is not None else print)(msg)
 
 
 def classify_contigs_safely(eng, seq, offsets, single_window, precision, console=None):
     """NNEngine.classify_contigs with the range fallback of :func:`_range_fallback`."""
     pr, wid = eng.classify_contigs(seq, offsets, single_window, precision)
-    if precision in F16_MODES and not np.isfinite(pr).all():
-        _range_fallback(console, precision)
-        pr, wid = eng.classify_contigs(seq, offsets, single_window, "bf16x3")
+    for nxt in RANGE_FALLBACKS.get(precision, ()):
+        if np.isfinite(pr).all():
+            break
+        _range_fallback(console, precision, nxt)
+        pr, wid = eng.classify_contigs(seq, offsets, single_window, nxt)
     return pr, wid
 
 
@@ -275,9 +281,11 @@ class GpuBackend:
         out = []
         for a in range(0, len(windows), self.chunk):
             s = self.eng.classify(windows[a:a + self.chunk], self.precision)
-            if self.precision in F16_MODES and not np.isfinite(s).all():
-                _range_fallback(None, self.precision)
-                s = self.eng.classify(windows[a:a + self.chunk], "bf16x3")
+            for nxt in RANGE_FALLBACKS.get(self.precision, ()):
+                if np.isfinite(s).all():
+                    break
+                _range_fallback(None, self.precision, nxt)
+                s = self.eng.classify(windows[a:a + self.chunk], nxt)
             out.append(s)
         return np.concatenate(out) if out else np.zeros((0, 3), np.float32)
 

@@ -1075,3 +1075,35 @@ def test_deferred_execution_info_is_opt_in_and_writes_the_same_file(tmp_path, mo
     want = json.load(open(tmp_path / "o2" / "a_nn_classification" / "a_nn_classification.json"))
     got.pop("start_time"), want.pop("start_time")
     assert got == want and got["input_md5"] == real(fa)
+
+
+def test_range_fallback_chain_of_the_default_arithmetic():
+    """The Toom-Cook form's transformed activations leave the f16 range before the activations themselves do (|x| > ~2 000 vs
+    65 504): non-finite scores from f16x3tc are recomputed with the direct f16x3 form first - f32-class accuracy - and only if that
+    is non-finite too with bf16x3 (f32 range).  One log line per step of the chain."""
+    calls, logs = [], []
+
+    class Eng:
+        def __init__(self, finite):
+            self.finite = finite
+
+        def classify_contigs(self, seq, offsets, single_window, precision):
+            calls.append(precision)
+            pr = np.full((2, 3), 1 / 3, np.float32)
+            if precision not in self.finite:
+                pr[1, 0] = np.nan
+            return pr, np.array([0, 1])
+
+    console = type("C", (), {"log": lambda self, m, **k: logs.append(m)})()
+    nnc._WARNED.clear()
+    pr, _ = nnc.classify_contigs_safely(Eng({"f16x3", "bf16x3"}), None, None, False, "f16x3tc", console)
+    assert calls == ["f16x3tc", "f16x3"] and np.isfinite(pr).all() and len(logs) == 1 and "with f16x3." in logs[0]
+    calls.clear()
+    pr, _ = nnc.classify_contigs_safely(Eng({"bf16x3"}), None, None, False, "f16x3tc", console)
+    assert calls == ["f16x3tc", "f16x3", "bf16x3"] and np.isfinite(pr).all() and len(logs) == 2 and "with bf16x3." in logs[1]
+    calls.clear()
+    pr, _ = nnc.classify_contigs_safely(Eng({"f16x3tc"}), None, None, False, "f16x3tc", console)
+    assert calls == ["f16x3tc"] and len(logs) == 2
+    calls.clear()
+    nnc.classify_contigs_safely(Eng(set()), None, None, False, "f32", console)       # exact f32: nothing to fall back to
+    assert calls == ["f32"]
