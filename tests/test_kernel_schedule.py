@@ -102,3 +102,82 @@ def test_the_model_notices_a_missing_barrier():
 @pytest.mark.parametrize("steps", [1, 2, 47])
 def test_schedule_holds_for_short_and_full_windows(steps):
     assert check(list(schedule(False, steps))) == []
+
+
+# ------------------------------------------------------------------ the Toom-Cook kernel (gnn_fused_tc.hip): 18 barriers per step, a ring of 3 slots
+def tc_schedule(steps: int = 4, ahead: int = 2):
+    """Phases of the default kernel's step loop, transcribed from gnn_fused_tc.hip.  Regions: bufX.rows / bufX.carry (x1), bufY.rows
+    (x2 as f32, then x3) / bufY.carry, ring0..2 (one k16 unit of transformed activations each), prow0 / prow1.  A chunk's version is
+    (conv, step, chunk index).  `ahead` = how many chunks the helpers run ahead of the matrix waves (the kernel: 2; 3 would overwrite
+    the slot the matrix waves are reading)."""
+    def prow(s):
+        return f"prow{s & 1}"
+
+    def ring(c):
+        return f"ring{c % 3}"
+
+    yield [("all", "w", prow(0), ("prow", 0), True), ("all", "w", prow(1), ("prow", 1), True)]
+    yield [("helper", "r", prow(0), ("prow", 0), True), ("helper", "w", "bufX.rows", ("x1", 0), True)]       # gather of the first step
+    yield [("helper", "r", "bufX.rows", ("x1", 0), True), ("helper", "r", "bufX.carry", ("x1c", -1), True),   # V2 chunks 0, 1 of the first step
+           ("helper", "w", ring(0), ("c2", 0, 0), True), ("helper", "w", ring(1), ("c2", 0, 1), True)]
+
+    def conv_phase(conv, s, c, src_rows, src_ver, carry_reg, carry_ver):
+        """interval behind barrier b_c of a conv loop: the matrix waves consume chunk c (and fetch the first fragment of chunk c + 1),
+        the helpers produce chunk c + ahead"""
+        ph = [("matrix", "r", ring(c), (conv, s, c), True)]
+        if c + 1 < 8:
+            ph.append(("matrix", "r", ring(c + 1), (conv, s, c + 1), True))
+        if c + ahead < 8:
+            ph += [("helper", "r", src_rows, src_ver, True), ("helper", "r", carry_reg, carry_ver, True),
+                   ("helper", "w", ring(c + ahead), (conv, s, c + ahead), True)]
+        return ph
+
+    for s in range(steps):
+        for c in range(8):                                                   # ---- conv2: b_0 .. b_7
+            ph = conv_phase("c2", s, c, "bufX.rows", ("x1", s), "bufX.carry", ("x1c", s - 1))
+            if c == 5:
+                ph.append(("helper", "r", prow(s + 1), ("prow", s + 1), True))          # gather round 0: table loads
+            if c >= 6:
+                ph.append(("helper", "r", "bufX.rows", ("x1", s), True))                # head A's pair products; x1 carry rows into registers
+            if c == 7:
+                ph += [("helper", "r", prow(s + 1), ("prow", s + 1), True),             # gather round 1: table loads
+                       ("matrix", "w", "bufY.rows", ("x2", s), True)]                   # conv2 epilogue (the helpers touch bufX only)
+            yield ph
+        yield [("matrix", "r", "bufX.rows", ("x1", s), True),                           # ---- B1 .. b'_0: w_v A(s)
+               ("helper", "r", "bufY.rows", ("x2", s), True), ("helper", "r", "bufY.carry", ("x2c", s - 1), True),
+               ("helper", "w", ring(0), ("c3", s, 0), True), ("helper", "w", ring(1), ("c3", s, 1), True)]
+        for c in range(8):                                                   # ---- conv3: b'_0 .. b'_7
+            ph = conv_phase("c3", s, c, "bufY.rows", ("x2", s), "bufY.carry", ("x2c", s - 1))
+            if c == 0:
+                ph += [("helper", "w", "bufX.carry", ("x1c", s), False),                # own registers -> carry rows
+                       ("helper", "w", "bufX.rows", ("x1", s + 1), True)]               # gather rounds 0, 1 (held in registers since b_7 / B1)
+            if c == 4:
+                ph.append(("helper", "r", prow(s + 1), ("prow", s + 1), True))          # gather round 2: table loads
+            if c == 6:
+                ph += [("helper", "w", "bufX.rows", ("x1", s + 1), True),               # gather round 2
+                       ("helper", "r", "bufY.rows", ("x2", s), True), ("helper", "w", "bufY.carry", ("x2c", s), False)]
+            if c == 7:
+                ph += [("helper", "w", prow(s + 2), ("prow", s + 2), True),
+                       ("matrix", "w", "bufY.rows", ("x3", s), True)]                   # conv3 epilogue overwrites x2 with x3
+            yield ph
+        yield [("matrix", "r", "bufY.rows", ("x3", s), True),                           # ---- B0 .. b_0: w_v B(s)
+               ("helper", "r", "bufY.rows", ("x3", s), True),                           # head B's pair products
+               ("helper", "r", "bufX.rows", ("x1", s + 1), True), ("helper", "r", "bufX.carry", ("x1c", s), True),
+               ("helper", "w", ring(0), ("c2", s + 1, 0), True), ("helper", "w", ring(1), ("c2", s + 1, 1), True)]
+
+
+def test_toomcook_kernel_schedule_orders_every_lds_producer_and_consumer_with_a_barrier():
+    for steps in (1, 2, 63):
+        assert check(list(tc_schedule(steps))) == []
+
+
+def test_toomcook_model_notices_a_dropped_barrier_and_a_ring_overrun():
+    phases = list(tc_schedule(3))
+    # B1 dropped: the conv2 epilogue (last conv2 interval) and the helpers' V3 chunks 0, 1 would share a phase
+    k = 3 + 7
+    merged = phases[:k] + [phases[k] + phases[k + 1]] + phases[k + 2:]
+    assert any("bufY.rows" in msg for _, msg in check(merged))
+    # helpers three chunks ahead: chunk c + 3 lands in the slot the matrix waves read in the same interval
+    assert any("ring" in msg for _, msg in check(list(tc_schedule(3, ahead=3))))
+    # one chunk ahead is too little: the matrix waves fetch the first fragment of chunk c + 1 while they finish chunk c
+    assert any("ring" in msg for _, msg in check(list(tc_schedule(3, ahead=1))))
