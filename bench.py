@@ -206,7 +206,9 @@ def main():
     ap.add_argument("--windows-per-step", type=int, default=16384, help="windows per step of the whole job (strong) "
                     "or of every rank (weak)")
     ap.add_argument("--scaling", default="strong", choices=["strong", "weak"])
-    ap.add_argument("--chunk", type=int, default=4096, help="windows per launch of the fused kernel")
+    ap.add_argument("--chunk", type=int, default=16384, help="windows per launch of the fused kernel (one launch per default step: 183.9 k "
+                    "windows/s against 180.3 k with 4 launches of 4096 on one box - the launch's tail is amortised over 64 instead of 16 "
+                    "rounds of workgroups per CU)")
     ap.add_argument("--precision", default=DEFAULT_PRECISION, choices=["f16c6", "f16c8", "f16x3", "f16x3tc", "bf16x3", "bf16", "f32"],
                     help=f"arithmetic of the fused front end (default {DEFAULT_PRECISION}: the fastest mode with margin inside the 1e-4 "
                          "tolerance; f16c6 / f16c8 are faster and exceed it on a few of 10^6 windows)")
