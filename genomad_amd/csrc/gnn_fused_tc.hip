@@ -1,4 +1,4 @@
-// Fused front end, GNN_PREC_F16X3TC (opt-in, experimental): the f16x3 arithmetic of gnn_fused_x3.hip with conv2 and conv3
+// Fused front end, GNN_PREC_F16X3TC (the default since round 4): the f16x3 arithmetic of gnn_fused_x3.hip with conv2 and conv3
 // (igloo.py:65-67) evaluated by Toom-Cook minimal filtering F(3,6) over the time axis - VERDICT r03 item 1.
 //
 //   y[3t + i] = sum_xi AT[i][xi] * M_xi[t],   M_xi[t] = sum_c V_xi[t][c] * U_xi[c][n],   V_xi[t] = sum_j BT[xi][j] x[3t - 5 + j],
@@ -11,7 +11,8 @@
 // What it costs (measured before it was built: scripts/probe_tc_loop.hip, profiles/r04/): a transformed weight fragment feeds 3
 // MFMAs (one tile block) where a direct one feeds 12 (four row blocks), so the L2 -> CU weight stream is 4x denser per MFMA
 // (the conv loops run at the chip's L2 ceiling, ~57 B/clk/CU), and the input transform is ~100 VALU instructions per (tile, 2
-// channels) on the helper waves.  DESIGN.md section 8 has the accounting.
+// channels) on the helper waves, which get ~6 issue slots per MFMA of the matrix wave they share a SIMD with.  Result: 21.7 vs
+// 26.7 ms per 4096 windows against the direct form (gnn_fused_x3.hip) on one box; DESIGN.md section 4.0 has the accounting.
 //
 // Structure: the streaming structure of gnn_fused_x3.hip (one workgroup = one window, both activation buffers in LDS with 5 carry
 // rows, 4 matrix waves + 4 helper waves) with steps of 96 rows and a ring of 3 x 16 KB in LDS through which the helper waves hand
@@ -19,8 +20,11 @@
 //
 //   matrix : [b0 it0 | b1 it1 | ... | b7 it7] conv2 -> inverse transform -> x2 (f32 rows) -> bufY | B1 | w_v A(s) [bufX] |
 //            [b0' .. b7'] conv3 -> inverse transform -> x3 (hi | lo rows) -> bufY | B0 | w_v B(s) [bufY]   -> step s+1
-//   helpers: during conv2 unit c: V2 chunk c+2 [bufX], pair products B(s-1) [bufY] and A(s) [bufX] | B1 | V3 chunks 0, 1 [bufY] |
-//            during conv3 unit c: V3 chunk c+2, conv1 gather of x1(s+1) -> bufX, carry rows, pair rows | B0 | V2(s+1) chunks 0, 1
+//   helpers: beside conv2 units 0..5: V2 chunks 2..7 [bufX]; beside units 6, 7 and the conv2 epilogue: head A's pair products [bufX],
+//            gather round 0 of x1(s+1) (into registers) | B1 | V3 chunks 0, 1 [bufY], gather round 1 (registers) |
+//            beside conv3 units 0..5: V3 chunks 2..7, the held gather rounds -> bufX; units 6, 7 and the conv3 epilogue: gather round 2,
+//            carry rows, pair rows | B0 | head B's pair products [bufY], V2(s+1) chunks 0, 1
+//   (tests/test_kernel_schedule.py is an executable model of this schedule: every LDS producer / consumer pair is ordered by a barrier)
 //
 // 18 workgroup barriers per step (bare s_barrier: a __syncthreads() would drain the matrix waves' weight loads in flight).  The
 // helpers run two chunks ahead of the matrix waves: before barrier b_c chunks <= c + 1 are complete, during unit c chunk c + 2
