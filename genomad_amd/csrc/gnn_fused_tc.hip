@@ -639,9 +639,13 @@ __global__ __launch_bounds__(512, 2) void fused_front_tc_kernel(Args a) {
             GNN_TICK(10)
             // Only the chunk transforms run beside the conv loops (the matrix waves wait for every chunk).  The pair products sit where
             // the matrix waves need nothing from the helpers - head A's (x1 in bufX until the gather behind b'_0) beside units 6, 7 and the
-            // conv2 epilogue, head B's (x3 in bufY from B0 to the next conv2 epilogue) beside w_v B - as 3 passes through two register
-            // sets each (three sets spill).  A warm-up step (time split) stores nothing: ha.
+            // conv2 epilogue, head B's (x3 in bufY from B0 to the next conv2 epilogue) beside w_v B and, its last pass, beside unit 6 of
+            // the next step - 3 passes of 64 entries per head through two register sets (three sets spill).  A warm-up step (time
+            // split) stores nothing: ha / hb.
             const PairJob jb = {bufY, a.weff[1], a.pos_sorted[1], mp_w[1], t0, ha ? a.bucket_ptr[1][step] : 0, ha ? a.bucket_ptr[1][step + 1] : 0};
+            const bool hb = step - 1 >= s_lo;                                    // head B of the previous step belongs to this run
+            const int sb = max(step - 1, 0);
+            const PairJob jbp = {bufY, a.weff[1], a.pos_sorted[1], mp_w[1], t0 - FTT, hb ? a.bucket_ptr[1][sb] : 0, hb ? a.bucket_ptr[1][sb + 1] : 0};
             const PairJob ja = {bufX, a.weff[0], a.pos_sorted[0], mp_w[0], t0, ha ? a.bucket_ptr[0][step] : 0, ha ? a.bucket_ptr[0][step + 1] : 0};
             // ---- conv2 phase: chunks 2 .. 7 (ra holds the rows of chunk 2; p0 / p1 the B passes 0 / 1, requested behind B0).  Only
             // the chunk transforms run beside the conv loop; the pair products sit in the intervals in which the matrix waves finish
@@ -672,24 +676,26 @@ __global__ __launch_bounds__(512, 2) void fused_front_tc_kernel(Args a) {
             // slack, and wait in 16 registers each for b'_0, behind which bufX may be written; round 2 runs beside conv3.
             GRow ga;
             GOut o0, o1;
-            pass_issue(p0, ja, 0, hw, lane);
-            pass_issue(p1, ja, 1, hw, lane);
+            pass_issue(p1, ja, 0, hw, lane);
             grow_issue(ga, prow, a.conv1_k, grow0, gpq);
             HBAR_W(8, 9);                                                        // b_6
-            pass_compute(p0, ja, 0, hw, lane);
-            pass_issue(p0, ja, 2, hw, lane);
+            pass_compute(p0, jbp, 2, hw, lane);                                  // head B's last pass of step s-1 (requested behind B0(s-1)):
+            pass_rest(p0, jbp, 3, hw, lane);                                     // bufY holds x3(s-1) until the conv2 epilogue behind b_7
+            pass_issue(p0, ja, 1, hw, lane);
             HBAR(8, 9);                                                          // b_7
-            pass_compute(p1, ja, 1, hw, lane);
+            pass_compute(p1, ja, 0, hw, lane);
+            pass_issue(p1, ja, 2, hw, lane);
+            pass_compute(p0, ja, 1, hw, lane);
             if (ht < CARRY * ROW_U4) carry = *reinterpret_cast<const uint4*>(bufX + (FTT + cr) * ROWX + cc * 16);
             grow_compute(o0, ga);
             grow_issue(ga, prow, a.conv1_k, grow0 + 32, gpq);
-            pass_compute(p0, ja, 2, hw, lane);
-            pass_rest(p0, ja, 3, hw, lane);
             HBAR(8, 10);                                                         // ---- B1: x2 is in bufY
             TC_HPRIO_LOW();
-            // V3 chunks 0, 1 beside the matrix waves' w_v A
+            // head A's last pass, V3 chunks 0, 1 and gather round 1 beside the matrix waves' w_v A
             load_x2(ra, h2, 0);
             load_x2(rb, h2, 1);
+            pass_compute(p1, ja, 2, hw, lane);
+            pass_rest(p1, ja, 3, hw, lane);
             transform_store<false>(ra, h2, 0);
             load_x2(ra, h2, 2);
             transform_store<false>(rb, h2, 1);
@@ -751,9 +757,12 @@ __global__ __launch_bounds__(512, 2) void fused_front_tc_kernel(Args a) {
             transform_store<true>(ra, h1, 0);
             load_x1(ra, h1, 2);
             transform_store<true>(rb, h1, 1);
-            pass_compute(p0, jb, 2, hw, lane);
-            pass_rest(p0, jb, 3, hw, lane);
             GNN_TICK(15)
+        }
+        if (s_hi > s_lo) {                                  // head B's last pass of this run's last step
+            const PairJob jl = {bufY, a.weff[1], a.pos_sorted[1], mp_w[1], (s_hi - 1) * FTT, a.bucket_ptr[1][s_hi - 1], a.bucket_ptr[1][s_hi]};
+            pass_compute(p0, jl, 2, hw, lane);
+            pass_rest(p0, jl, 3, hw, lane);
         }
     }
     if (nsteps < STEPST && part == a.split - 1) {   // the all-N tail: copy instead of compute
