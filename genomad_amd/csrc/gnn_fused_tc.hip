@@ -259,20 +259,27 @@ __device__ __forceinline__ void split2(f32x2 v, uint32_t& hi, uint32_t& lo) {
     lo = __builtin_bit_cast(uint32_t, __builtin_convertvector(f32x2{sub_f16_lo(v[0], hi), sub_f16_hi(v[1], hi)}, f16x2));
 }
 
-// A^T of F(3,6) (oracle/toomcook.py) on one accumulator register of the 8 points, then scale, bias, LeakyReLU:
+// A^T of F(3,6) (oracle/toomcook.py) on TWO neighbouring accumulator registers of the 8 points at a time, then scale, bias,
+// LeakyReLU:
 //   y0 = m0 + (m1 + m2) + (m3 + m4) + (m5 + m6);  y1 = (m1 - m2) + 2 (m3 - m4) + (m5 - m6) / 2;
 //   y2 = (m1 + m2) + 4 (m3 + m4) + (m5 + m6) / 4 + m7
-__device__ __forceinline__ void inverse3(const f32x16 (&acc)[NXI], int r, float inv_s, float bias, float (&y)[3]) {
-    const float s12 = acc[1][r] + acc[2][r], d12 = acc[1][r] - acc[2][r];
-    const float s34 = acc[3][r] + acc[4][r], d34 = acc[3][r] - acc[4][r];
-    const float s56 = acc[5][r] + acc[6][r], d56 = acc[5][r] - acc[6][r];
-    const float y0 = ((acc[0][r] + s12) + s34) + s56;
-    const float y1 = fmaf(d56, 0.5f, fmaf(d34, 2.f, d12));
-    const float y2 = fmaf(s56, 0.25f, fmaf(s34, 4.f, s12)) + acc[7][r];
-    const float v0 = fmaf(y0, inv_s, bias), v1 = fmaf(y1, inv_s, bias), v2 = fmaf(y2, inv_s, bias);
-    y[0] = vmax_raw(v0, v0 * LRELU);
-    y[1] = vmax_raw(v1, v1 * LRELU);
-    y[2] = vmax_raw(v2, v2 * LRELU);
+// The epilogues run while no MFMA is in flight on the SIMD, where the packed f32 forms (v_pk_add / v_pk_fma / v_pk_mul_f32) issue
+// at full rate: 26 instead of 46 instructions per register pair (the file is compiled without SLP packing - the helpers' transform
+// runs beside the MFMA stream, where packed f32 is an anti-lever -, so the pairs are spelled out with 2-vectors here).
+__device__ __forceinline__ f32x2 pair_of(const f32x16& a, int r) { return f32x2{a[r], a[r + 1]}; }
+__device__ __forceinline__ void inverse3(const f32x16 (&acc)[NXI], int r, float inv_s, f32x2 bias, f32x2 (&y)[3]) {
+    const f32x2 m0 = pair_of(acc[0], r), m1 = pair_of(acc[1], r), m2 = pair_of(acc[2], r), m3 = pair_of(acc[3], r);
+    const f32x2 m4 = pair_of(acc[4], r), m5 = pair_of(acc[5], r), m6 = pair_of(acc[6], r), m7 = pair_of(acc[7], r);
+    const f32x2 s12 = m1 + m2, d12 = m1 - m2, s34 = m3 + m4, d34 = m3 - m4, s56 = m5 + m6, d56 = m5 - m6;
+    const f32x2 y0 = ((m0 + s12) + s34) + s56;
+    const f32x2 y1 = __builtin_elementwise_fma(d56, f32x2{0.5f, 0.5f}, __builtin_elementwise_fma(d34, f32x2{2.f, 2.f}, d12));
+    const f32x2 y2 = __builtin_elementwise_fma(s56, f32x2{0.25f, 0.25f}, __builtin_elementwise_fma(s34, f32x2{4.f, 4.f}, s12)) + m7;
+    const f32x2 sc = {inv_s, inv_s}, lr = {LRELU, LRELU};
+    const f32x2 v0 = __builtin_elementwise_fma(y0, sc, bias), v1 = __builtin_elementwise_fma(y1, sc, bias), v2 = __builtin_elementwise_fma(y2, sc, bias);
+    const f32x2 w0 = v0 * lr, w1 = v1 * lr, w2 = v2 * lr;
+    y[0] = f32x2{vmax_raw(v0[0], w0[0]), vmax_raw(v0[1], w0[1])};
+    y[1] = f32x2{vmax_raw(v1[0], w1[0]), vmax_raw(v1[1], w1[1])};
+    y[2] = f32x2{vmax_raw(v2[0], w2[0]), vmax_raw(v2[1], w2[1])};
 }
 // conv2 epilogue: x2 rows as f32 (only the input transform of conv3 reads them).  Register r of lane l = channel
 // 8 (r >> 2) + 4 (l >> 5) + (r & 3) of tile l & 31: one 16-B store per (row of the tile, register group)
@@ -282,12 +289,12 @@ __device__ __forceinline__ void epilogue_f32(unsigned char* __restrict__ obuf, c
     for (int rg = 0; rg < 4; ++rg) {
         const int f0 = wave * 32 + rg * 8 + (lane >> 5) * 4;
         const f32x4 b = *reinterpret_cast<const f32x4*>(bias + f0);
-        float y[4][3];
-#pragma unroll
-        for (int e = 0; e < 4; ++e) inverse3(acc, rg * 4 + e, inv_s, b[e], y[e]);
+        f32x2 ya[3], yb[3];
+        inverse3(acc, rg * 4, inv_s, f32x2{b[0], b[1]}, ya);
+        inverse3(acc, rg * 4 + 2, inv_s, f32x2{b[2], b[3]}, yb);
 #pragma unroll
         for (int i = 0; i < 3; ++i)
-            *reinterpret_cast<f32x4*>(obuf + (CARRY + 3 * (lane & 31) + i) * ROWX + f0 * 4) = f32x4{y[0][i], y[1][i], y[2][i], y[3][i]};
+            *reinterpret_cast<f32x4*>(obuf + (CARRY + 3 * (lane & 31) + i) * ROWX + f0 * 4) = f32x4{ya[i][0], ya[i][1], yb[i][0], yb[i][1]};
     }
 }
 // conv3 epilogue: x3 rows as hi | lo planes (y @ w_v of head B and its pair products read them)
@@ -297,14 +304,14 @@ __device__ __forceinline__ void epilogue_x3(unsigned char* __restrict__ obuf, co
     for (int rg = 0; rg < 4; ++rg) {
         const int f0 = wave * 32 + rg * 8 + (lane >> 5) * 4;
         const f32x4 b = *reinterpret_cast<const f32x4*>(bias + f0);
-        float y[4][3];
-#pragma unroll
-        for (int e = 0; e < 4; ++e) inverse3(acc, rg * 4 + e, inv_s, b[e], y[e]);
+        f32x2 ya[3], yb[3];
+        inverse3(acc, rg * 4, inv_s, f32x2{b[0], b[1]}, ya);
+        inverse3(acc, rg * 4 + 2, inv_s, f32x2{b[2], b[3]}, yb);
 #pragma unroll
         for (int i = 0; i < 3; ++i) {
             uint2 h, l;
-            split2<true>(f32x2{y[0][i], y[1][i]}, h.x, l.x);
-            split2<true>(f32x2{y[2][i], y[3][i]}, h.y, l.y);
+            split2<true>(ya[i], h.x, l.x);
+            split2<true>(yb[i], h.y, l.y);
             unsigned char* o = obuf + (CARRY + 3 * (lane & 31) + i) * ROWX + f0 * 2;
             *reinterpret_cast<uint2*>(o) = h;
             *reinterpret_cast<uint2*>(o + LOX) = l;
@@ -441,9 +448,10 @@ struct PairCompute {
             hx[i] = *reinterpret_cast<const uint4*>(xr + i * 16);
             lx[i] = *reinterpret_cast<const uint4*>(xr + LOX + i * 16);
         }
-        // s += (hi + lo) * w as two v_fma_mix_f32 per value (the f16 halves are read in place: no conversion, no addition); the
-        // products hi * w and lo * w are exact in f32 up to one rounding each, like (hi + lo) * w
-        float s = 0.f;
+        // (hi + lo) * w as two v_fma_mix_f32 per value (the f16 halves are read in place: no conversion, no addition; hi * w and lo * w
+        // are exact in f32 up to one rounding each, like (hi + lo) * w).  Four independent accumulators: one chain of 64 dependent
+        // FMAs is latency-bound on a wave that has the SIMD's leftover issue slots
+        float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const uint32_t hv[4] = {hx[i].x, hx[i].y, hx[i].z, hx[i].w}, lv[4] = {lx[i].x, lx[i].y, lx[i].z, lx[i].w};
@@ -451,12 +459,13 @@ struct PairCompute {
             for (int k = 0; k < 4; ++k) {
                 const float4 w0 = w.w[2 * i + (k >> 1)];
                 const float wa = (k & 1) ? w0.z : w0.x, wb = (k & 1) ? w0.w : w0.y;
-                asm("v_fma_mix_f32 %0, %1, %2, %0 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "+v"(s) : "v"(hv[k]), "v"(wa));
-                asm("v_fma_mix_f32 %0, %1, %2, %0 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "+v"(s) : "v"(lv[k]), "v"(wa));
-                asm("v_fma_mix_f32 %0, %1, %2, %0 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(s) : "v"(hv[k]), "v"(wb));
-                asm("v_fma_mix_f32 %0, %1, %2, %0 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(s) : "v"(lv[k]), "v"(wb));
+                asm("v_fma_mix_f32 %0, %1, %2, %0 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "+v"(s0) : "v"(hv[k]), "v"(wa));
+                asm("v_fma_mix_f32 %0, %1, %2, %0 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "+v"(s1) : "v"(lv[k]), "v"(wa));
+                asm("v_fma_mix_f32 %0, %1, %2, %0 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(s2) : "v"(hv[k]), "v"(wb));
+                asm("v_fma_mix_f32 %0, %1, %2, %0 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(s3) : "v"(lv[k]), "v"(wb));
             }
         }
+        float s = (s0 + s2) + (s1 + s3);
         s += dpp_xor1(s);
         s += dpp_xor2(s);
         if (p == 0) jb.mp[e] = s;
