@@ -160,6 +160,10 @@ struct HRaw {
     uint32_t h[8], l[8];
 };
 __device__ __forceinline__ void helper_load(HRaw& r, const unsigned char* smem, int unit, int hw, int lane) {
+#ifdef HELP_NOLDS        // measurement variant: barriers only on the helper side
+    for (int j = 0; j < 8; ++j) r.h[j] = r.l[j] = (uint32_t)(unit + lane + j);
+    return;
+#endif
     // lane -> (tile, k half, channel pair) so that both the row reads and the fragment stores are bank-conflict free: the 4 lanes
     // of a (tile, half) cover its 8 channels = 16 consecutive bytes; a wave covers 16 (tile, half) combinations
     const int pr = lane & 3, th = hw * 16 + (lane >> 2), tile = th & 31, half = th >> 5;
@@ -171,6 +175,10 @@ __device__ __forceinline__ void helper_load(HRaw& r, const unsigned char* smem, 
     }
 }
 __device__ __forceinline__ void helper_transform(const HRaw& r, unsigned char* smem, int slot, int hw, int lane) {
+#ifdef HELP_NOLDS
+    asm volatile("" ::"v"(r.h[0]), "v"(r.l[7]));
+    return;
+#endif
 #ifdef HELP_NOVALU       // measurement variant: the 16 loads and 16 stores without the arithmetic between them
     {
         unsigned char* vo = smem + VOFF + slot * VSLOT + (hw * 64 + lane) * 4;
