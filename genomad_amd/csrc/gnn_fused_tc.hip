@@ -87,7 +87,20 @@ struct WU {
     uint4 h, l;
 };
 
-#define TC_BARRIER() asm volatile("s_barrier" ::: "memory")
+// -DTC_JITTER (test builds only, scripts/tc_jitter_check.py): every wave sleeps a pseudo-random time (0 .. ~2 000 cycles, a hash of wave,
+// step-local counter and lane-uniform salt) behind every barrier.  Results must not change by a bit: a producer / consumer pair of LDS
+// data that is not ordered by a barrier shows up as a mismatch against the normal build.
+#ifdef TC_JITTER
+__device__ __forceinline__ void tc_jitter(unsigned& state) {
+    state = state * 1664525u + 1013904223u;
+    const unsigned n = __builtin_amdgcn_readfirstlane((state >> 24) & 31u);
+    for (unsigned i = 0; i < n; ++i) __builtin_amdgcn_s_sleep(1);
+}
+#define TC_JITTER_HERE() tc_jitter(jitter_state)
+#else
+#define TC_JITTER_HERE()
+#endif
+#define TC_BARRIER() asm volatile("s_barrier" ::: "memory"); TC_JITTER_HERE()
 // The helpers outrank the matrix waves (priority 2) while the conv loops wait for their chunks, and yield beside the w_v tiles,
 // where the matrix waves are the critical path and the helpers have time to spare.  -DTC_HPRIO_STATIC keeps them at 3 throughout.
 #ifdef TC_HPRIO_STATIC
@@ -101,7 +114,7 @@ struct WU {
 #define HBAR_W(work, wait) GNN_TICK(work) TC_BARRIER_W(); GNN_TICK(wait)
 #define HBAR(work, wait) GNN_TICK(work) TC_BARRIER(); GNN_TICK(wait)
 // this wave stored to LDS since the last barrier: the stores must have landed before the others are released
-#define TC_BARRIER_W() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
+#define TC_BARRIER_W() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); TC_JITTER_HERE()
 
 __device__ __forceinline__ f32x16 mma(uint4 a, uint4 b, f32x16 c) {
     return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
@@ -230,7 +243,7 @@ __device__ __forceinline__ void prime_tc(WU (&ring)[RINGT], wrsrc_t wr, int woff
 // 8 k16 units x 8 points; barrier b_c in front of unit c (the helpers' chunk c + 1 is complete, the slot of chunk c - 1 is free).
 // The weight requests of the last 7 (unit, xi) wrap onto the conv's first ones (in-bounds, unused).
 __device__ __forceinline__ void conv_tc(const unsigned char* __restrict__ smem, wrsrc_t wr, int woff, WU (&ring)[RINGT], f32x16 (&acc)[NXI],
-                                        int lane) {
+                                        int lane, unsigned& jitter_state) {
     const uint32_t l16 = (uint32_t)lane * 16u;
     uint32_t voff = (uint32_t)VRING_OFF + l16;
     asm volatile("" : "+v"(voff));
@@ -548,6 +561,8 @@ __global__ __launch_bounds__(512, 2) void fused_front_tc_kernel(Args a) {
         }
     }
     __syncthreads();
+    unsigned jitter_state = 0x9E3779B9u * (unsigned)(wave + 1) + (unsigned)blockIdx.x * 7919u;     // TC_JITTER builds only
+    (void)jitter_state;
     unsigned long long cyc[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     unsigned long long tick_ = 0;
     // conv1 gather: helper thread ht owns the 16 channels 16 (ht & 7) .. of rows (ht >> 3) + 32 k, k = 0, 1, 2
@@ -573,7 +588,7 @@ __global__ __launch_bounds__(512, 2) void fused_front_tc_kernel(Args a) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[xi][r] = 0.f;
             GNN_TICK(7)
-            conv_tc(smem, cw[0], woff, ring, acc, lane);                         // b_0 .. b_7, conv2
+            conv_tc(smem, cw[0], woff, ring, acc, lane, jitter_state);                         // b_0 .. b_7, conv2
             GNN_TICK(0)
             prime_wv(ring, vw[0], woff, lane);
             epilogue_f32(bufY, acc, a.inv_s[0], bias_s, hw, lane);
@@ -595,7 +610,7 @@ __global__ __launch_bounds__(512, 2) void fused_front_tc_kernel(Args a) {
             for (int xi = 0; xi < NXI; ++xi)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[xi][r] = 0.f;
-            conv_tc(smem, cw[1], woff, ring, acc, lane);                         // b'_0 .. b'_7, conv3
+            conv_tc(smem, cw[1], woff, ring, acc, lane, jitter_state);                         // b'_0 .. b'_7, conv3
             GNN_TICK(4)
             prime_wv(ring, vw[1], woff, lane);
             epilogue_x3(bufY, acc, a.inv_s[1], bias_s + C, hw, lane);

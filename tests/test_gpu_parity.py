@@ -1018,3 +1018,25 @@ def test_time_split_small_batches_are_bit_identical(engine):
     finally:
         _lib.check(engine.lib.gnn_debug_set_time_split(engine.ctx, 1))
         _lib.check(engine.lib.gnn_debug_set_pad_skip(engine.ctx, 1))
+
+
+def test_toomcook_kernel_is_bit_identical_under_delay_injection(tmp_path):
+    """The default kernel orders its LDS producers and consumers with 18 bare s_barriers per step (tests/test_kernel_schedule.py
+    models the schedule).  libgenomad_nn_hip_jitter.so is the same library with every wave sleeping a pseudo-random 0..2 000
+    cycles behind every barrier (3.5x the run time): scores, pair products and pooled y @ w_v rows of 600 / 128 / 40 windows
+    (padded and all-N ones included, time split included) must be the bits the normal library produces - the method that made
+    round 2's pair-row race deterministic (profiles/history/r03_pair_row_race.md), applied to the new kernel."""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    jitter = os.path.join(root, "genomad_amd", "csrc", "libgenomad_nn_hip_jitter.so")
+    if not os.path.exists(jitter):
+        pytest.skip("libgenomad_nn_hip_jitter.so not built (genomad_amd/csrc/build.sh builds it)")
+    script = os.path.join(root, "scripts", "tc_jitter_check.py")
+    ref = str(tmp_path / "ref.npz")
+    env = {k: v for k, v in os.environ.items() if k != "GENOMAD_AMD_LIB"}
+    r = subprocess.run([sys.executable, script, "ref", ref], env=env, capture_output=True, text=True, timeout=300, cwd=root)
+    assert r.returncode == 0, r.stderr[-1500:]
+    for _ in range(2):
+        r = subprocess.run([sys.executable, script, "cmp", ref], env=dict(env, GENOMAD_AMD_LIB=jitter), capture_output=True, text=True,
+                           timeout=300, cwd=root)
+        assert r.returncode == 0 and "OK:" in r.stdout, (r.stdout[-800:], r.stderr[-800:])
