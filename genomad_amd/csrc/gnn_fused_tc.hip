@@ -167,6 +167,9 @@ __device__ __forceinline__ void wv_unit(const WU& wc, WU& wl, bool lw, const XU&
 // The ring's first RINGV - 1 units were requested by prime_wv.
 __device__ __forceinline__ void wv_tile(const unsigned char* __restrict__ smem, int xoff, wrsrc_t wr, int woff, WU (&ring)[RINGT],
                                         f32x16 (&acc)[NMB], int lane) {
+#ifdef TC_ABL_NOWV
+    return;
+#endif
     uint32_t rowoff = (uint32_t)xoff + (uint32_t)(lane & 31) * ROWX + (uint32_t)(lane >> 5) * 16u;
     asm volatile("" : "+v"(rowoff));
     const unsigned char* xh = smem + rowoff;
@@ -219,12 +222,20 @@ struct XV {
 template <int VOFFN>
 __device__ __forceinline__ void xi_mma(const WU& wc, WU& wl, const XV& vc, XV& vl, const unsigned char* __restrict__ vb, wrsrc_t wr, int wnext,
                                        uint32_t l16, f32x16& acc) {
+#ifndef TC_ABL_NOVREAD
     vl.h = *reinterpret_cast<const uint4*>(vb + VOFFN);
     vl.l = *reinterpret_cast<const uint4*>(vb + VOFFN + 1024);
+#endif
+#ifndef TC_ABL_NOWEIGHTS
     load_wu(wl, wr, l16, wnext);
+#endif
+#ifndef TC_ABL_NOCONVMMA
     acc = mma(wc.l, vc.h, acc);            // D = U^T V: a lane ends up with 16 channels of one tile
     acc = mma(wc.h, vc.h, acc);
     acc = mma(wc.h, vc.l, acc);
+#else
+    asm volatile("" ::"v"(wc.l.x), "v"(wc.l.w), "v"(wc.h.x), "v"(wc.h.w), "v"(vc.h.x), "v"(vc.h.w), "v"(vc.l.x), "v"(vc.l.w));
+#endif
     __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
     __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
     __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
@@ -281,6 +292,19 @@ __device__ __forceinline__ void split2(f32x2 v, uint32_t& hi, uint32_t& lo) {
 // runs beside the MFMA stream, where packed f32 is an anti-lever -, so the pairs are spelled out with 2-vectors here).
 __device__ __forceinline__ f32x2 pair_of(const f32x16& a, int r) { return f32x2{a[r], a[r + 1]}; }
 __device__ __forceinline__ void inverse3(const f32x16 (&acc)[NXI], int r, float inv_s, f32x2 bias, f32x2 (&y)[3]) {
+#ifdef TC_ABL_NOEPI            // the sums of A^T left out; scale, bias, LeakyReLU kept (magnitudes stay realistic), every accumulator kept alive
+    {
+#pragma unroll
+        for (int xi = 3; xi < NXI; ++xi) asm volatile("" ::"v"(acc[xi][r]), "v"(acc[xi][r + 1]));
+        const f32x2 sc = {inv_s, inv_s}, lr = {LRELU, LRELU};
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            const f32x2 v = __builtin_elementwise_fma(pair_of(acc[i], r), sc, bias), w = v * lr;
+            y[i] = f32x2{vmax_raw(v[0], w[0]), vmax_raw(v[1], w[1])};
+        }
+        return;
+    }
+#endif
     const f32x2 m0 = pair_of(acc[0], r), m1 = pair_of(acc[1], r), m2 = pair_of(acc[2], r), m3 = pair_of(acc[3], r);
     const f32x2 m4 = pair_of(acc[4], r), m5 = pair_of(acc[5], r), m6 = pair_of(acc[6], r), m7 = pair_of(acc[7], r);
     const f32x2 s12 = m1 + m2, d12 = m1 - m2, s34 = m3 + m4, d34 = m3 - m4, s56 = m5 + m6, d56 = m5 - m6;
@@ -381,6 +405,24 @@ __device__ __forceinline__ void bt8(const float (&d)[8], float (&v)[8]) {
 }
 template <bool X1>
 __device__ __forceinline__ void transform_store(const Raw16& r, const HLane& h, int slot) {
+#ifdef TC_ABL_NOTRANSFORM      // loads and stores only, data of a realistic magnitude
+    {
+        unsigned char* o = h.frag + slot * VSLOT;
+#pragma unroll
+        for (int xi = 0; xi < NXI; ++xi) {
+            uint32_t hi, lo;
+            if constexpr (X1) {
+                hi = r.a[xi], lo = r.b[xi];
+            } else {
+                hi = __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_pkrtz(__uint_as_float(r.a[xi]), __uint_as_float(r.b[xi])));
+                lo = hi & 0x83ff83ffu;
+            }
+            *reinterpret_cast<uint32_t*>(o + xi * 2048) = hi;
+            *reinterpret_cast<uint32_t*>(o + xi * 2048 + 1024) = lo;
+        }
+        return;
+    }
+#endif
     float d0[8], d1[8], v0[8], v1[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
@@ -412,6 +454,20 @@ struct GRow {
     f32x4 v[3][4];      // [table][i]: channels 16 pq + 4 i ..
 };
 __device__ __forceinline__ void grow_issue(GRow& g, const uint16_t* __restrict__ prow, const float* __restrict__ pt, int row, int pq) {
+#ifdef TC_ABL_NOGATHER
+    return;
+#endif
+#ifdef TC_ABL_GATHER_ONE       // one table row instead of three (a third of the gather's L2 traffic), data still window-dependent
+    {
+        const uint32_t r = prow[row];
+        const float* src = pt + (size_t)r * C + pq * 4;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) g.v[0][i] = *reinterpret_cast<const f32x4*>(src + i * 32);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) g.v[1][i] = g.v[2][i] = g.v[0][i] * 0.5f;
+        return;
+    }
+#endif
 #pragma unroll
     for (int j = 0; j < 3; ++j) {
         const uint32_t r = prow[row + 2 * j];
@@ -424,6 +480,11 @@ struct GOut {         // a finished item: 16 channels as f16 hi | lo limbs, wait
     uint4 h0, h1, l0, l1;
 };
 __device__ __forceinline__ void grow_compute(GOut& o, const GRow& g) {
+#ifdef TC_ABL_NOGATHER
+    o.h0 = o.h1 = make_uint4(0x3c003800u, 0xb8003c00u, 0x38003a00u, 0xbc003400u);
+    o.l0 = o.l1 = make_uint4(0x10001100u, 0x90001200u, 0x11009000u, 0x12001000u);
+    return;
+#endif
     uint32_t hi[8], lo[8];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
@@ -493,6 +554,9 @@ struct PairPass {
     int u;
 };
 __device__ __forceinline__ void pass_issue(PairPass& pp, const PairJob& jb, int k, int wave, int lane) {
+#ifdef TC_ABL_NOPAIRS
+    return;
+#endif
     const int e = jb.e + wave * 16 + (lane >> 2) + 64 * k;
     pp.u = jb.t0;
     if (e < jb.e_end) {
@@ -501,12 +565,18 @@ __device__ __forceinline__ void pass_issue(PairPass& pp, const PairJob& jb, int 
     }
 }
 __device__ __forceinline__ void pass_compute(const PairPass& pp, const PairJob& jb, int k, int wave, int lane) {
+#ifdef TC_ABL_NOPAIRS
+    return;
+#endif
     const int e = jb.e + wave * 16 + (lane >> 2) + 64 * k;
     if (e < jb.e_end) PairCompute::run(pp.w, jb, e, pp.u, lane & 3);
     GNN_REGION_END();        // keeps the scheduler from hoisting the next pass's 8 row reads (32 registers) above this pass
 }
 // a crowded step (more than 3 passes; rare): the remaining passes one by one, loads not hidden
 __device__ __forceinline__ void pass_rest(PairPass& pp, const PairJob& jb, int k0, int wave, int lane) {
+#ifdef TC_ABL_NOPAIRS
+    return;
+#endif
     for (int e = jb.e + wave * 16 + (lane >> 2) + 64 * k0; e < jb.e_end; e += 64) {
         pair_load_w(pp.w, jb, e, lane & 3);
         PairCompute::run(pp.w, jb, e, jb.pos[e], lane & 3);
@@ -616,6 +686,9 @@ __global__ __launch_bounds__(512, 2) void fused_front_tc_kernel(Args a) {
             epilogue_x3(bufY, acc, a.inv_s[1], bias_s + C, hw, lane);
             GNN_TICK(5)
             TC_BARRIER_W();                                                      // ---- B0: x3 is in bufY
+#ifdef TC_SLEEP_B0
+            __builtin_amdgcn_s_sleep(TC_SLEEP_B0);
+#endif
             GNN_TICK(6)
             {
                 f32x16 ac[NMB];
@@ -772,6 +845,9 @@ __global__ __launch_bounds__(512, 2) void fused_front_tc_kernel(Args a) {
             GNN_TICK(13)
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             HBAR(13, 11);                                                        // ---- B0: x3 is in bufY, x1(s+1) in bufX
+#ifdef TC_SLEEP_B0
+            __builtin_amdgcn_s_sleep(TC_SLEEP_B0);
+#endif
             TC_HPRIO_LOW();
             load_x1(ra, h1, 0);
             load_x1(rb, h1, 1);
