@@ -21,7 +21,11 @@ echo "built $(pwd)/libgenomad_nn_hip.so"
 # Test variant (tests/test_gpu_parity.py::test_toomcook_kernel_is_bit_identical_under_delay_injection): the same library with random
 # sleeps behind every barrier of the default kernel.  Never loaded by the product; built with the main library so that it travels
 # to the GPU box.
-if [ ! -f libgenomad_nn_hip_jitter.so ] || [ gnn_fused_tc.hip -nt libgenomad_nn_hip_jitter.so ] || [ gnn_fused_helpers.h -nt libgenomad_nn_hip_jitter.so ]; then
+stale=0
+for o in obj/gnn_api.o obj/gnn_encode.o obj/gnn_front_f32.o obj/gnn_backend.o obj/gnn_fused.o obj/gnn_fused_c8.o obj/gnn_fused_c6.o obj/gnn_fused_x3.o obj/gnn_fused_tc.o obj/gnn_probe.o obj/gnn_consumers.o obj/gnn_fasta.o obj/gnn_comm.o obj/gnn_contigs.o; do
+  [ $o -nt libgenomad_nn_hip_jitter.so ] && stale=1
+done
+if [ ! -f libgenomad_nn_hip_jitter.so ] || [ $stale = 1 ]; then
   $HIPCC $FLAGS -fno-slp-vectorize -DTC_JITTER -c gnn_fused_tc.hip -o obj/gnn_fused_tc_jitter.o
   $HIPCC --offload-arch=gfx950 -shared -fPIC -o libgenomad_nn_hip_jitter.so obj/gnn_api.o obj/gnn_encode.o obj/gnn_front_f32.o obj/gnn_backend.o obj/gnn_fused.o obj/gnn_fused_c8.o obj/gnn_fused_c6.o obj/gnn_fused_x3.o obj/gnn_fused_tc_jitter.o obj/gnn_probe.o obj/gnn_consumers.o obj/gnn_fasta.o obj/gnn_comm.o obj/gnn_contigs.o -ldl
   echo "built $(pwd)/libgenomad_nn_hip_jitter.so"
