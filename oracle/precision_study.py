@@ -349,6 +349,14 @@ def forward(tokens, W, layer_scheme):
     return IO._softmax(h2 @ w["out_dense_kernel"] + w["out_dense_bias"])
 
 
+# The log-normal through the median and the 99th percentile describes weight seed 42 (every window carries a comparable error).  With the
+# second seed most windows' scores saturate and carry almost no error while a few carry all of it: the fitted sigma explodes and the
+# "extrapolation" exceeds anything the device measures on the full 10^6 windows (profiles/r04_tails.txt is the authoritative tail).
+LOGNORMAL_SIGMA_LIMIT = 1.2
+EXTRAPOLATION_NOTE = ("bimodal per-window errors (most windows saturated): the log-normal fit is not a bound here; the measured "
+                      "1M-window tails on the device (profiles/r04_tails.txt) are authoritative")
+
+
 def run(n_windows, seeds, names, per_layer, batch=8):
     bases = synthetic.synth_windows(0, n_windows)
     tokens = sequence_oracle.tokenize_closed_form(bases)
@@ -379,6 +387,8 @@ def run(n_windows, seeds, names, per_layer, batch=8):
                 lm, l99 = np.log(np.median(d)), np.log(np.quantile(d, 0.99))
                 sig = (l99 - lm) / NormalDist().inv_cdf(0.99)
                 row["extrapolated_max_1M"] = float(np.exp(lm + sig * NormalDist().inv_cdf(1 - 1e-6)))
+                if sig > LOGNORMAL_SIGMA_LIMIT:
+                    row["extrapolation_note"] = EXTRAPOLATION_NOTE
             rows.append(row)
             print(f"seed {seed}: {label:75s} cost {cost:5.2f}  max|dscore| {err:.2e}  rms {row['rms']:.2e}  p99.9 {row['p999']:.2e}"
                   f"{'  1M-extrapolated ' + format(row['extrapolated_max_1M'], '.2e') if 'extrapolated_max_1M' in row else ''}  ({time.time() - t:.0f} s)", flush=True)
