@@ -119,9 +119,12 @@ __device__ __forceinline__ void tc_jitter(unsigned& state) {
 __device__ __forceinline__ f32x16 mma(uint4 a, uint4 b, f32x16 c) {
     return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
 }
+#ifndef TC_WAUX
+#define TC_WAUX 0     // cache policy bits of the weight stream (bit 0 sc0, bit 1 nt, bit 4 sc1): A/B in profiles/r04/tc_ablation.txt
+#endif
 __device__ __forceinline__ void load_wu(WU& w, wrsrc_t r, uint32_t l16, int soff) {
-    const u32x4 a = __builtin_amdgcn_raw_buffer_load_b128(r, l16, soff, 0);
-    const u32x4 b = __builtin_amdgcn_raw_buffer_load_b128(r, l16 + 1024, soff, 0);
+    const u32x4 a = __builtin_amdgcn_raw_buffer_load_b128(r, l16, soff, TC_WAUX);
+    const u32x4 b = __builtin_amdgcn_raw_buffer_load_b128(r, l16 + 1024, soff, TC_WAUX);
     w.h = make_uint4(a[0], a[1], a[2], a[3]);
     w.l = make_uint4(b[0], b[1], b[2], b[3]);
 }

@@ -27,8 +27,9 @@ if os.path.exists(cache):
     W = dict(np.load(cache))
 else:
     W = synthetic.synth_weights()
-    np.savez(cache + ".tmp.npz", **W)
-    os.replace(cache + ".tmp.npz", cache)
+    tmp = f"{cache}.{os.getpid()}.tmp.npz"                 # several fresh processes may start at once (tests run three at a time)
+    np.savez(tmp, **W)
+    os.replace(tmp, cache)
 eng = NNEngine(0, W)
 n = 6 * 1024 + 300
 bases, a, b = eng.alloc(n * 6000), eng.alloc(n * 12), eng.alloc(n * 12)
