@@ -32,6 +32,10 @@
 //
 // LDS: bufX 101 rows x 528 B (x1: hi | lo planes), bufY 101 x 528 (x2 as f32 rows, then x3 as hi | lo planes), ring 3 x 16 KB,
 // pair rows, biases: 157.3 KB.
+//
+// Compile-time switches, all off in the shipped library: -DTC_JITTER (libgenomad_nn_hip_jitter.so: random sleeps behind every barrier,
+// results must not move), -DTC_ABL_* (parts compiled out, wrong results: what the launch is made of, profiles/r04/tc_ablation.txt),
+// -DTC_SLEEP_B0=n, -DTC_WAUX=n, -DTC_HPRIO_STATIC (A/B knobs of the same file).
 #include <algorithm>
 #include <cmath>
 #include <cstdlib>
