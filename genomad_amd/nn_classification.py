@@ -37,7 +37,7 @@ from ._lib import DEFAULT_PRECISION
 
 # arithmetic of the fused front end (GENOMAD_AMD_PRECISION overrides): "f16x3tc" = split-f16 limbs with conv2 / conv3 by Toom-Cook
 # minimal filtering, f32-class accuracy - the default, because the TSV prints four decimals and the 1e-4 tolerance has to hold
-# with margin on inputs and weights nobody has measured; "f16x3" = the direct three-pass form (round 3's default, 0.86x the
+# with margin on inputs and weights nobody has measured; "f16x3" = the direct three-pass form (round 3's default, 0.82x the
 # speed); "f16c6" / "f16c8" = f16 MFMA + MX-fp6 / fp8 corrections (faster, no head-room: DESIGN.md section 2); "bf16x3" =
 # split-bf16 three passes (f32 range); "f32" = exact f32 reference kernels
 MODULE_NAME = "nn_classification"   # utils.write_execution_info("nn_classification", ...) :207-212
