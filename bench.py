@@ -14,10 +14,11 @@ N = 1 too: the communicator is always created, so the N = 1 line goes through th
 Workload (config.workload): synthetic 6 kbp windows (seed 1234) + synthetic weights (seed 42) of the
 reference shapes, resident in HBM before the timed region.  A "step" is one pass of the whole hot path
 (tokenise -> conv1..3 -> IGLOO heads -> dense/softmax) over one batch of --windows-per-step windows.
-  --scaling strong (default, BASELINE configs[2]/[3]: "1 M windows sharded across the GPUs"): the K x 16384 =
-      1 M windows of the job are split into contiguous shards, rank r classifies windows [r*n/N, (r+1)*n/N)
-      (every step = 16384 / N windows per rank), ONE RCCL gather of the scores to rank 0 at the end.
-  --scaling weak: every rank classifies its own K x 16384 windows.
+  --scaling strong (default, BASELINE configs[2]/[3]: "1 M windows sharded across the GPUs"): the K x 65536 =
+      1 M windows of the job (default K = 16) are split into contiguous shards, rank r classifies windows
+      [r*n/N, (r+1)*n/N) (every step = 65536 / N windows per rank, in launches of --chunk), ONE RCCL gather of the
+      scores to rank 0 at the end.
+  --scaling weak: every rank classifies its own K x 65536 windows.
   --workload metagenome --gbp-total G (BASELINE configs[4]): a synthetic metagenome of G Gbp (contigs of
       1-500 kbp, log-uniform) sharded by contigs over the ranks and streamed through HBM in chunks of
       --gbp-per-step; spans -> N rule -> encode+IGLOO -> per-contig mean on the device, per-contig scores
@@ -201,14 +202,14 @@ def main():
     from genomad_amd._lib import DEFAULT_PRECISION
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=64)
+    ap.add_argument("--steps", type=int, default=16)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--windows-per-step", type=int, default=16384, help="windows per step of the whole job (strong) "
-                    "or of every rank (weak)")
+    ap.add_argument("--windows-per-step", type=int, default=65536, help="windows per step of the whole job (strong) or of every rank (weak): "
+                    "16 x 65536 = the 1 M windows of BASELINE configs[2]/[3]; at 8 ranks a step is still 8192 windows = 32 rounds of workgroups "
+                    "per rank (one GPU: 187.8-188.0 k windows/s for 16384, 32768 and 65536 per step, profiles/r04/backend_overlap_ab.txt)")
     ap.add_argument("--scaling", default="strong", choices=["strong", "weak"])
-    ap.add_argument("--chunk", type=int, default=16384, help="windows per launch of the fused kernel (one launch per default step: 183.9 k "
-                    "windows/s against 180.3 k with 4 launches of 4096 on one box - the launch's tail is amortised over 64 instead of 16 "
-                    "rounds of workgroups per CU)")
+    ap.add_argument("--chunk", type=int, default=16384, help="windows per launch of the fused kernel (183.9 k windows/s against 180.3 k with "
+                    "launches of 4096 on one box - the launch's tail is amortised over 64 instead of 16 rounds of workgroups per CU)")
     ap.add_argument("--precision", default=DEFAULT_PRECISION, choices=["f16c6", "f16c8", "f16x3", "f16x3tc", "bf16x3", "bf16", "f32"],
                     help=f"arithmetic of the fused front end (default {DEFAULT_PRECISION}: the fastest mode with margin inside the 1e-4 "
                          "tolerance; f16c6 / f16c8 are faster and exceed it on a few of 10^6 windows)")

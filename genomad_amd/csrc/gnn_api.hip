@@ -14,7 +14,7 @@ namespace gnn {
 static thread_local std::string g_last_error;
 void set_error(const std::string& msg) { g_last_error = msg; }
 
-// Debug / measurement switches read from the environment (GNN_ASYNC_EVENT_WAIT, GNN_NO_BACKEND_OVERLAP, GNN_DEBUG_POISON,
+// Debug / measurement switches read from the environment (GNN_ASYNC_EVENT_WAIT, GNN_NO_BACKEND_OVERLAP, GNN_BACKEND_OVERLAP, GNN_DEBUG_POISON,
 // GNN_X3_ROUND1, GNN_NO_PAD_SKIP, GNN_LOGITS_F32): each is read ONCE per process, and a switch that is set says so on stderr -
 // a stray variable in a user's environment must not silently change ordering or arithmetic.
 bool debug_switch(const char* name) {
@@ -309,16 +309,20 @@ int classify_chunks(gnn_ctx* ctx, const uint8_t* bases_dev, int64_t n, int preci
     const int64_t chunk = std::min<int64_t>(f32 ? ctx->chunk_f32 : ctx->chunk_fused, std::max<int64_t>(n, 1));
     int rc = ensure_ws(ctx, ctx->ws, chunk, f32 ? chunk : 0);
     if (rc) return rc;
-    // More than one chunk of a fused precision, or an asynchronous call: the back end of chunk i (five small, mostly
-    // HBM-bound kernels, 5 % of the time) is enqueued on a second stream and runs beside the front end of chunk i+1 (of this
-    // call or of the next one), on whatever the power-bound fused kernel leaves idle between its workgroups; two workspaces
-    // alternate.  GNN_NO_BACKEND_OVERLAP=1 disables it.
+    // An asynchronous call (gnn_classify_dev_async, or whatever one left pending): the back end of chunk i (five small, mostly
+    // HBM-bound kernels, 4 % of the time) is enqueued on a second stream and runs beside the front end of chunk i+1 (of this call
+    // or of the next one); two workspaces alternate.  A synchronous multi-chunk call no longer does that (rounds 2-4 did): beside
+    // the power-bound default kernel the overlapped back end costs the front end more than it saves - 184.6 vs 180.4 k windows/s
+    // at 8192 windows per launch, 185.9 vs 183.5 k at 16384 (profiles/r04/backend_overlap_ab.txt) - and the second workspace
+    // is not allocated.  GNN_BACKEND_OVERLAP=1 brings the old policy back for A/B runs, GNN_NO_BACKEND_OVERLAP=1 serialises
+    // the asynchronous path too.
     static const bool allow_overlap = !debug_switch("GNN_NO_BACKEND_OVERLAP");
+    static const bool chunk_overlap = debug_switch("GNN_BACKEND_OVERLAP");
     const bool pending = ctx->back_pending[0] || ctx->back_pending[1];
     if (pending && (f32 || !allow_overlap)) {
         if ((rc = flush_backend(ctx))) return rc;
     }
-    const bool overlap = allow_overlap && !f32 && (n > chunk || defer_last || pending);
+    const bool overlap = allow_overlap && !f32 && ((chunk_overlap && n > chunk) || defer_last || pending);
     if (overlap) {
         if ((rc = ensure_ws(ctx, ctx->ws_alt, chunk, 0))) return rc;
         if (!ctx->stream2) {

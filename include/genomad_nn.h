@@ -176,6 +176,8 @@ int gnn_classify(gnn_ctx* ctx, const uint8_t* bases_host, int64_t n_windows, int
  * bit-identical to gnn_classify_dev (bench.py checks every window of every run).  Worth +8-10 % for F16C6 at 2048 windows per
  * call, nothing for the power-bound default arithmetic.
  * Debug switches of the library (environment, read once): GNN_NO_BACKEND_OVERLAP=1 keeps every back end on the ctx stream;
+ * GNN_BACKEND_OVERLAP=1 also overlaps the chunks of a synchronous multi-chunk call (the policy of rounds 2-4, slower beside the
+ * power-bound default kernel: profiles/r04/backend_overlap_ab.txt);
  * GNN_DEBUG_POISON=1 fills the workspaces with NaN patterns before every launch (a kernel reading what its launch has not
  * written turns the scores into NaN); GNN_X3_ROUND1=1 serves F16X3 / BF16X3 with the round-1 kernel (A/B measurements). */
 int gnn_classify_dev_async(gnn_ctx* ctx, const uint8_t* bases_dev, int64_t n_windows, int precision, float* scores_dev);
