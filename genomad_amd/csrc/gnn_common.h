@@ -139,7 +139,8 @@ struct gnn_ctx {
     hipEvent_t ev_front[2] = {nullptr, nullptr}, ev_back[2] = {nullptr, nullptr};
     bool back_pending[2] = {false, false};   // ev_back[i] recorded on stream2 and not yet waited for by `stream`
     int buf_cur = 0;                         // which of the two alternating workspaces `ws` currently is
-    int64_t chunk_fused = 8192;      // windows per launch of a fused front end (gnn_set_chunk): larger grids amortise the launch's tail, +1-2 %
+    int64_t chunk_fused = 16384;     // windows per launch of a fused front end (gnn_set_chunk): larger grids amortise the launch's tail (185.9 vs
+                                     // 184.6 k windows/s against 8192, profiles/r04/backend_overlap_ab.txt); 13 GB of workspace at full size, one set
     int64_t chunk_f32 = 64;
     bool profile = false;
     gnn::ProfileSlot prof[GNN_K_COUNT];

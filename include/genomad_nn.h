@@ -333,7 +333,7 @@ int gnn_debug_set_time_split(gnn_ctx* ctx, int on);
  * [k / 128][block][lane], byte (k / 32) % 4.  need_words receives the size in 32-bit words; out may be NULL to query it. */
 int gnn_debug_pack_c6(const float* w, int k, int n, uint32_t* out, size_t out_words, size_t* need_words);
 
-/* windows the ctx processes per launch of the fused front end (workspace sizing) */
+/* windows the ctx processes per launch of the fused front end (workspace sizing: 0.79 MB per window; default 16384) */
 int gnn_set_chunk(gnn_ctx* ctx, int64_t windows_per_chunk);
 
 #ifdef __cplusplus
