@@ -57,6 +57,7 @@ _vp, _i64, _int, _sz, _u64 = C.c_void_p, C.c_int64, C.c_int, C.c_size_t, C.c_uin
 SIGNATURES = {
     "gnn_last_error": (C.c_char_p, []),
     "gnn_version": (_int, []),
+    "gnn_has_experimental": (_int, []),
     "gnn_device_count": (_int, [C.POINTER(_int)]),
     "gnn_create": (_int, [_int, C.POINTER(_vp)]),
     "gnn_destroy": (_int, [_vp]),
@@ -90,6 +91,7 @@ SIGNATURES = {
     "gnn_fused_rows_per_step": (_int, [_int]),
     "gnn_debug_set_pad_skip": (_int, [_vp, _int]),
     "gnn_debug_set_time_split": (_int, [_vp, _int]),
+    "gnn_debug_last_split": (_int, [_vp, C.POINTER(_int)]),
     "gnn_debug_pack_c6": (_int, [_f32p, _int, _int, C.POINTER(C.c_uint32), _sz, C.POINTER(_sz)]),
     "gnn_crc32c": (C.c_uint32, [_vp, _sz]),
     "gnn_fasta_scan": (_int, [_vp, _i64, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_int)]),

@@ -15,7 +15,7 @@ static thread_local std::string g_last_error;
 void set_error(const std::string& msg) { g_last_error = msg; }
 
 // Debug / measurement switches read from the environment (GNN_ASYNC_EVENT_WAIT, GNN_NO_BACKEND_OVERLAP, GNN_BACKEND_OVERLAP, GNN_DEBUG_POISON,
-// GNN_X3_ROUND1, GNN_NO_PAD_SKIP, GNN_LOGITS_F32): each is read ONCE per process, and a switch that is set says so on stderr -
+// GNN_X3_ROUND1, GNN_NO_PAD_SKIP, GNN_NO_TIME_SPLIT, GNN_LOGITS_F32): each is read ONCE per process, and a switch that is set says so on stderr -
 // a stray variable in a user's environment must not silently change ordering or arithmetic.
 bool debug_switch(const char* name) {
     static std::mutex mu;
@@ -96,6 +96,10 @@ static void free_ws(Workspace& ws) {
     ws.chunk = 0;
     ws.x_chunk = 0;
 }
+
+// bytes of workspace per window of a fused launch (mp, m, yp, logits, alpha, feat): 0.86 MB
+constexpr size_t WS_BYTES_PER_WINDOW = ((size_t)2 * NPAIR + 2 * NP + (size_t)2 * POOLED * C + 4 * POOLED + FEAT) * sizeof(float);
+constexpr int64_t MIN_CHUNK = 256;       // one round of workgroups
 
 // Make sure the workspace holds `chunk` windows (and the f32 activation buffers `x_chunk`).
 static int ensure_ws(gnn_ctx* ctx, Workspace& ws, int64_t chunk, int64_t x_chunk) {
@@ -306,9 +310,33 @@ int classify_chunks(gnn_ctx* ctx, const uint8_t* bases_dev, int64_t n, int preci
         return GNN_ERR_ARG;
     }
     const bool f32 = precision == GNN_PREC_F32;
-    const int64_t chunk = std::min<int64_t>(f32 ? ctx->chunk_f32 : ctx->chunk_fused, std::max<int64_t>(n, 1));
+    int64_t chunk = std::min<int64_t>(f32 ? ctx->chunk_f32 : ctx->chunk_fused, std::max<int64_t>(n, 1));
+    // Workspace growth of a fused launch shape (WS_BYTES_PER_WINDOW each, 13 GB at the default 16384): the library default is
+    // clamped to a quarter of the device memory that is free right now (an integrator on a shared or partitioned GPU never asked
+    // for 13 GB), and whatever size is asked for is halved and retried when the allocation fails.  The size that worked becomes
+    // the ctx's chunk, so later calls (and the taps limit of gnn_debug_forward) see one consistent value.
+    if (!f32 && ctx->ws.chunk < chunk) {
+        if (!ctx->chunk_explicit) {
+            size_t free_b = 0, total_b = 0;
+            if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) {
+                const int64_t cap = std::max<int64_t>(MIN_CHUNK, (int64_t)(free_b / 4 / WS_BYTES_PER_WINDOW) / MIN_CHUNK * MIN_CHUNK);
+                if (cap < chunk) {
+                    std::fprintf(stderr, "libgenomad_nn_hip: %lld windows per launch need %.1f GB of workspace, %.1f GB of device memory are free: "
+                                 "using launches of %lld windows (gnn_set_chunk overrides)\n", (long long)chunk,
+                                 chunk * (double)WS_BYTES_PER_WINDOW / 1e9, free_b / 1e9, (long long)cap);
+                    chunk = cap;
+                }
+            }
+        }
+    }
     int rc = ensure_ws(ctx, ctx->ws, chunk, f32 ? chunk : 0);
+    while (rc == GNN_ERR_NOMEM && !f32 && chunk > MIN_CHUNK) {
+        chunk = std::max<int64_t>(MIN_CHUNK, chunk / 2);
+        std::fprintf(stderr, "libgenomad_nn_hip: workspace allocation failed, retrying with launches of %lld windows\n", (long long)chunk);
+        rc = ensure_ws(ctx, ctx->ws, chunk, 0);
+    }
     if (rc) return rc;
+    if (!f32 && chunk < std::min<int64_t>(ctx->chunk_fused, std::max<int64_t>(n, 1))) ctx->chunk_fused = chunk;
     // An asynchronous call (gnn_classify_dev_async, or whatever one left pending): the back end of chunk i (five small, mostly
     // HBM-bound kernels, 4 % of the time) is enqueued on a second stream and runs beside the front end of chunk i+1 (of this call
     // or of the next one); two workspaces alternate.  A synchronous multi-chunk call no longer does that (rounds 2-4 did): beside
@@ -322,9 +350,15 @@ int classify_chunks(gnn_ctx* ctx, const uint8_t* bases_dev, int64_t n, int preci
     if (pending && (f32 || !allow_overlap)) {
         if ((rc = flush_backend(ctx))) return rc;
     }
-    const bool overlap = allow_overlap && !f32 && ((chunk_overlap && n > chunk) || defer_last || pending);
+    bool overlap = allow_overlap && !f32 && ((chunk_overlap && n > chunk) || defer_last || pending);
+    if (overlap && (rc = ensure_ws(ctx, ctx->ws_alt, chunk, 0)) == GNN_ERR_NOMEM) {
+        // no room for the second workspace (the asynchronous path costs 2 x the workspace): run in order on one
+        if ((rc = flush_backend(ctx))) return rc;
+        overlap = false;
+    } else if (rc) {
+        return rc;
+    }
     if (overlap) {
-        if ((rc = ensure_ws(ctx, ctx->ws_alt, chunk, 0))) return rc;
         if (!ctx->stream2) {
             GNN_HIP(hipStreamCreateWithFlags(&ctx->stream2, hipStreamNonBlocking));
             for (int i = 0; i < 2; ++i) {
@@ -447,6 +481,15 @@ int gnn_debug_set_time_split(gnn_ctx* ctx, int on) {
     int rc = check_ctx(ctx);
     if (rc) return rc;
     ctx->time_split = on != 0;
+    return GNN_OK;
+}
+
+int gnn_debug_last_split(gnn_ctx* ctx, int* workgroups_per_window) {
+    if (!ctx || !workgroups_per_window) {
+        set_error("bad argument to gnn_debug_last_split");
+        return GNN_ERR_ARG;
+    }
+    *workgroups_per_window = ctx->last_split;
     return GNN_OK;
 }
 
@@ -594,6 +637,7 @@ int gnn_set_chunk(gnn_ctx* ctx, int64_t windows_per_chunk) {
         return GNN_ERR_ARG;
     }
     ctx->chunk_fused = windows_per_chunk;
+    ctx->chunk_explicit = true;
     return GNN_OK;
 }
 

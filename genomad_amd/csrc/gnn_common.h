@@ -140,13 +140,18 @@ struct gnn_ctx {
     bool back_pending[2] = {false, false};   // ev_back[i] recorded on stream2 and not yet waited for by `stream`
     int buf_cur = 0;                         // which of the two alternating workspaces `ws` currently is
     int64_t chunk_fused = 16384;     // windows per launch of a fused front end (gnn_set_chunk): larger grids amortise the launch's tail (185.9 vs
-                                     // 184.6 k windows/s against 8192, profiles/r04/backend_overlap_ab.txt); 13 GB of workspace at full size, one set
+                                     // 184.6 k windows/s against 8192, profiles/r04/backend_overlap_ab.txt); 13 GB of workspace at full size, one set.
+                                     // The DEFAULT is a ceiling, not a demand: classify_chunks clamps it to a quarter of the device memory that is
+                                     // free when the workspace first grows, and any size (explicit or not) is halved and retried when the
+                                     // allocation fails (shared / partitioned GPUs)
+    bool chunk_explicit = false;     // gnn_set_chunk was called: no clamp against free memory, only the halve-and-retry on failure
     int64_t chunk_f32 = 64;
     bool profile = false;
     gnn::ProfileSlot prof[GNN_K_COUNT];
     std::vector<hipEvent_t> event_pool;
     std::vector<void*> owned;   // device allocations to free at destroy
     int cu_count = 0;
+    int last_split = 1;                           // workgroups per window of the last streaming-kernel launch (gnn_debug_last_split)
     bool time_split = true;                       // x3 kernel: several workgroups per window when a launch is smaller than the chip (gnn_debug_set_time_split)
     bool c6_pad_skip = true;                      // f16c6: copy the all-N tail of a window instead of computing it (gnn_debug_set_pad_skip)
     unsigned long long* phase_cycles = nullptr;   // non-null: fused kernel runs its instrumented build

@@ -679,3 +679,5 @@ int launch_front_c8(gnn_ctx* ctx, const uint8_t* bases, int64_t n) {
 }
 
 }  // namespace gnn
+
+extern "C" int gnn_has_experimental(void) { return 1; }

@@ -1026,6 +1026,7 @@ int launch_front_tc(gnn_ctx* ctx, const uint8_t* bases, int64_t n) {
     a.mp_c = ctx->c6_pad_skip ? ctx->w.tc_mp_const : nullptr;
     a.cycles = ctx->phase_cycles;
     if (ctx->time_split && n > 0 && ctx->cu_count > 0) a.split = (int)std::max<int64_t>(1, std::min<int64_t>(4, ctx->cu_count / n));
+    ctx->last_split = a.split;
     launch(a, ctx->phase_cycles != nullptr, (unsigned)n, ctx->stream);
     GNN_HIP(hipGetLastError());
     return GNN_OK;

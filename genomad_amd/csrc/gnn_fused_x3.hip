@@ -671,6 +671,7 @@ int launch_front_x3(gnn_ctx* ctx, const uint8_t* bases, int64_t n, int precision
     // fewer windows than CUs (one workgroup owns a CU): deal every window's steps to several workgroups.  Capped at 4: each
     // additional workgroup recomputes one step of 47, and below 12 steps per run the prologue starts to show
     if (ctx->time_split && n > 0 && ctx->cu_count > 0) a.split = (int)std::max<int64_t>(1, std::min<int64_t>(4, ctx->cu_count / n));
+    ctx->last_split = a.split;
     launch(a, f16, ctx->phase_cycles != nullptr, (unsigned)n, ctx->stream);
     GNN_HIP(hipGetLastError());
     return GNN_OK;

@@ -250,7 +250,9 @@ RANGE_FALLBACKS = {"f16x3tc": ("f16x3", "bf16x3"), "f16x3": ("bf16x3",), "f16c6"
 
 def _range_fallback(console, what, to):
     """The f16-operand modes cannot represent activations beyond their range; scores that come back
-    non-finite are recomputed with the next arithmetic of RANGE_FALLBACKS.  Said once per run and pair."""
+    non-finite are recomputed with the next arithmetic of RANGE_FALLBACKS.  ``what`` is the arithmetic that just
+    returned the non-finite scores (on the second hop of a chain: the first fallback, not the configured one).
+    Said once per run and pair."""
     if (what, to) not in _WARNED:
         _WARNED.add((what, to))
         msg = (f"Non-finite class scores from the f16 arithmetic ({what}): activations left its range; "
@@ -258,34 +260,100 @@ def _range_fallback(console, what, to):
         (console.log if console is not None else print)(msg)
 
 
-def classify_contigs_safely(eng, seq, offsets, single_window, precision, console=None):
-    """NNEngine.classify_contigs with the range fallback of :func:`_range_fallback`."""
-    pr, wid = eng.classify_contigs(seq, offsets, single_window, precision)
+def _with_range_fallback(run, precision, console=None):
+    """``run(arithmetic)`` -> (scores, extra); walks RANGE_FALLBACKS[precision] while the scores are non-finite.
+    Returns (scores, extra, arithmetic that produced them)."""
+    used = precision
+    pr, extra = run(used)
     for nxt in RANGE_FALLBACKS.get(precision, ()):
         if np.isfinite(pr).all():
             break
-        _range_fallback(console, precision, nxt)
-        pr, wid = eng.classify_contigs(seq, offsets, single_window, nxt)
+        _range_fallback(console, used, nxt)
+        used = nxt
+        pr, extra = run(used)
+    return pr, extra, used
+
+
+def classify_contigs_safely(eng, seq, offsets, single_window, precision, console=None):
+    """NNEngine.classify_contigs with the range fallback of :func:`_range_fallback`."""
+    pr, wid, _ = _with_range_fallback(lambda a: eng.classify_contigs(seq, offsets, single_window, a), precision, console)
     return pr, wid
+
+
+# ---- runtime parity sentinel (VERDICT r04 item 4) ---------------------------------------------------------------------
+# The 1e-4 claim of the production arithmetic has only ever met synthetic weights (the trained nn_classifier.h5 is not in the
+# checkout).  So every run of main() classifies its first windows a second time with the exact-f32 device path (GNN_PREC_F32:
+# unfused f32 FMA kernels, the parity anchor of tests/ and bench.py) and compares: the only parity evidence a user with the real
+# weights ever gets, and what turns the range / precision assumptions of the f16 limb arithmetic (activations neither beyond
+# ~2 000 nor so small that the low limbs go subnormal) into checked ones.  Cost: one 64-window launch of the f32 path, ~0.1 s
+# including its 0.6 GB activation workspace (scripts/sentinel_cost.py).  GENOMAD_AMD_NO_SENTINEL=1 opts out.
+SENTINEL_WINDOWS = 64
+SENTINEL_TOL = 1e-4            # BASELINE.json north_star: per-class scores within 1e-4 absolute of the reference path
+
+
+class ParitySentinelError(RuntimeError):
+    pass
+
+
+def sentinel_windows(seq, offsets, single_window, limit=SENTINEL_WINDOWS) -> np.ndarray:
+    """The first ``limit`` candidate windows of a packed contig buffer as (k, 6000) upper-cased, N-padded bytes
+    (nn_classification.py:68-72; the N-content rule is irrelevant for a parity sample)."""
+    starts, lens, _, _ = sequence.candidate_spans(np.asarray(offsets, np.int64), single_window)
+    k = int(min(len(starts), limit))
+    win = np.full((k, sequence.WINDOW), ord("N"), dtype=np.uint8)
+    for i in range(k):
+        w = np.asarray(seq[int(starts[i]):int(starts[i]) + int(lens[i])], dtype=np.uint8)
+        win[i, :len(w)] = np.where((w >= 97) & (w <= 122), w - 32, w)          # sequence.py:35-36 upper()
+    return win
+
+
+def parity_sentinel(eng, windows, precision, console=None):
+    """max |dscore| of the production arithmetic (after its range fallbacks) against GNN_PREC_F32 on ``windows``;
+    None when switched off, for the exact arithmetic itself, or without windows.  Logs one line."""
+    if os.environ.get("GENOMAD_AMD_NO_SENTINEL") == "1" or precision == "f32" or not len(windows):
+        return None
+    exact = eng.classify(windows, "f32")
+    got, _, used = _with_range_fallback(lambda a: (eng.classify(windows, a), None), precision, console)
+    d = float(np.abs(got.astype(np.float64) - exact).max()) if np.isfinite(got).all() and np.isfinite(exact).all() else float("inf")
+    (console.log if console is not None else print)(
+        f"Parity sentinel: max |dscore| of {used} against the exact-f32 path on the first {len(windows)} windows = {d:.2e} "
+        f"(tolerance {SENTINEL_TOL:.0e}).")
+    return d
+
+
+def sentinel_verdict(comm, d, console, precision):
+    """Every rank brings its own sentinel result (None = nothing to check); all ranks leave together if any failed."""
+    bad = d is not None and not d <= SENTINEL_TOL
+    if comm is not None:
+        bad = bool(np.asarray(comm.allgather_i64([int(bad)]))[:, 0].any())
+    if bad:
+        console.error(
+            f"Parity sentinel FAILED: the {precision} arithmetic differs from the exact-f32 device path by more than {SENTINEL_TOL:.0e} "
+            "on this run's first windows (weights whose activations leave the range the f16 limb arithmetic was validated for). "
+            "Re-run with GENOMAD_AMD_PRECISION=bf16x3 (f32 range) or GENOMAD_AMD_PRECISION=f32 (exact, slow); "
+            "GENOMAD_AMD_NO_SENTINEL=1 disables this check.")
+        sys.exit(1)
 
 
 class GpuBackend:
     """Scores windows and averages them per contig on the GPU (libgenomad_nn_hip.so)."""
 
-    def __init__(self, batch_size: int):
+    def __init__(self, batch_size: int, console=None):
         self.eng = _engine()
         self.chunk = max(int(batch_size), 4096)
         self.precision = configured_precision()
+        self.console = console
+        self.sentinel = None          # max |dscore| of the first windows this backend scored (parity_sentinel)
+        self._sentinel_done = False
 
     def score(self, windows: np.ndarray) -> np.ndarray:
+        if not self._sentinel_done:
+            self._sentinel_done = True
+            self.sentinel = parity_sentinel(self.eng, windows[:SENTINEL_WINDOWS], self.precision, self.console)
         out = []
         for a in range(0, len(windows), self.chunk):
-            s = self.eng.classify(windows[a:a + self.chunk], self.precision)
-            for nxt in RANGE_FALLBACKS.get(self.precision, ()):
-                if np.isfinite(s).all():
-                    break
-                _range_fallback(None, self.precision, nxt)
-                s = self.eng.classify(windows[a:a + self.chunk], nxt)
+            s, _, _ = _with_range_fallback(lambda p, a=a: (self.eng.classify(windows[a:a + self.chunk], p), None),
+                                           self.precision, self.console)
             out.append(s)
         return np.concatenate(out) if out else np.zeros((0, 3), np.float32)
 
@@ -393,6 +461,8 @@ def main(input_path, output_path, single_window, batch_size, restart, threads, v
             return
         state["gated"] = True
         if device_front_end and sharded_check:
+            if state["verdict"] is None:                         # gate() before the main stage ran fasta_verdict: a bug, not a bad FASTA
+                raise RuntimeError("internal error: gate() was reached before the sharded FASTA verdict was computed")
             fail_on_bad_fasta(state["verdict"])                  # decided by all ranks together in the main stage
         elif device_front_end:
             fail_on_bad_fasta(everywhere(check_future.result() if rank0 else True)[0])
@@ -443,8 +513,10 @@ def main(input_path, output_path, single_window, batch_size, restart, threads, v
             if not len(windows):                                                     # :297-299
                 console.error("No sequences were found. Please check your input FASTA.")
                 sys.exit(1)
-            backend = _backend if _backend is not None else GpuBackend(batch_size)
+            backend = _backend if _backend is not None else GpuBackend(batch_size, console)
             predictions = classify_windows(windows, ids, len(names), backend, comm)
+            if _backend is None:
+                sentinel_verdict(comm, getattr(backend, "sentinel", None), console, getattr(backend, "precision", "?"))
             console.log(f"{what.capitalize()}s classified.")
             if rank0:
                 np.savez_compressed(npz_path, **{names_key: names, "predictions": predictions})   # :326-330
@@ -474,6 +546,14 @@ def main(input_path, output_path, single_window, batch_size, restart, threads, v
             precision = configured_precision()
             eng = _engine()
             parts = []
+            sentinel = {"d": None, "done": False}
+
+            def classify(sq, off):
+                if not sentinel["done"] and len(off) > 1:           # this rank's first piece with a contig: the run's parity sample
+                    sentinel["done"] = True
+                    sentinel["d"] = parity_sentinel(eng, sentinel_windows(sq, off, single_window), precision, console)
+                return classify_contigs_safely(eng, sq, off, single_window, precision, console)
+
             validate = sharded_check and fasta is input_path        # the provirus FASTA is geNomad's own output: never validated
             seen = []                                               # accessions of ALL records of this rank's share (validate)
 
@@ -495,7 +575,7 @@ def main(input_path, output_path, single_window, batch_size, restart, threads, v
                         nm, sq, off = nxt.result()
                         if k + 1 < pieces:
                             nxt = pool.submit(read, k + 1)
-                        pr, wid = classify_contigs_safely(eng, sq, off, single_window, precision, console)
+                        pr, wid = classify(sq, off)
                         parts.append((rank * 64 + k, nm, pr, wid))
             else:
                 # compressed streams cannot be read by byte range: every rank decompresses the stream
@@ -504,10 +584,11 @@ def main(input_path, output_path, single_window, batch_size, restart, threads, v
                     if i % world != rank:
                         continue
                     nm, sq, off = pack(chunk)
-                    pr, wid = classify_contigs_safely(eng, sq, off, single_window, precision, console)
+                    pr, wid = classify(sq, off)
                     parts.append((i, nm, pr, wid))
             if validate:
                 state["verdict"] = sharding.fasta_verdict(comm, seen, lambda: sequence.check_fasta(input_path))
+            sentinel_verdict(comm, sentinel["d"], console, precision)      # before anything is written
             names, predictions, ids, n_windows = sharding.gather_contig_parts(comm, parts)
             gate()
             if not n_windows:                                                        # :297-299

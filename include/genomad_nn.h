@@ -54,16 +54,12 @@ typedef enum gnn_precision {
                                 what main() recomputes a batch with when an f16-operand mode returns non-finite scores */
     GNN_PREC_BF16 = 2,       /* fused path: single bf16 MFMA pass (fails the 1e-4 tolerance;
                                 for roofline experiments only)                                */
-    GNN_PREC_F16C8 = 3,      /* fused path: one f16 MFMA pass + MX-scaled fp8 (e4m3) MFMA corrections of
-                                both operands' f16 rounding residuals = 2.0 pass equivalents; inside the
-                                1e-4 tolerance on BASELINE config 2 with little head-room (DESIGN.md §2,
-                                profiles/history/r02_precision_study.json); needs |activation| < 65504 (f16 range) */
-    GNN_PREC_F16C6 = 5,      /* fused path: one f16 MFMA pass + MX-scaled fp6 (e2m3) MFMA corrections, both operands block
-                                scaled (activations per row and 32 channels at run time) = 1.5 pass equivalents; the
-                                accuracy class of F16C8 (config 2: 8.2e-5); the fastest mode, OPT-IN:
-                                no head-room under the tolerance (1.2e-4 on a few of 10^6 windows: bench.py exits non-zero
-                                with it); needs |activation| < 65504 (f16 range) and a 4-byte aligned window buffer (any
-                                gnn_dev_alloc / host staging buffer is)                                                 */
+    GNN_PREC_F16C8 = 3,      /* EXPERIMENTAL, not in the default build (see "experimental" below): gnn_classify* return
+                                GNN_ERR_STATE for it unless the library was built with GNN_EXPERIMENTAL=1                       */
+    GNN_PREC_F16C6 = 5,      /* FROZEN opt-in fast mode (gnn_fused_c6.hip, not tuned any more): one f16 MFMA pass + MX-scaled fp6
+                                (e2m3) correction MFMAs, both operands block scaled = 1.5 pass equivalents; 8.2e-5 on config 2,
+                                1.2e-4 on a few of 10^6 windows - NO head-room under the 1e-4 tolerance (bench.py exits non-zero
+                                with it), so it cannot be a default; needs |activation| < 65504 and a 4-byte aligned buffer   */
     GNN_PREC_F16X3TC = 6,    /* THE DEFAULT of main(), NNEngine and bench.py since round 4 (gnn_fused_tc.hip): the F16X3 arithmetic (split-f16
                                 hi + lo limbs, three MFMA products per operand pair, f32 accumulate) with conv2 / conv3 evaluated by
                                 Toom-Cook minimal filtering F(3,6) over the time axis - 0.444x their MFMAs, f32 transforms; y @ w_v direct,
@@ -71,13 +67,21 @@ typedef enum gnn_precision {
                                 2e-5 / 4e-5 of the exact-f32 path on every one of 10^6 windows for two weight sets
                                 (profiles/r04_tails.txt).  Needs |activation| < ~2000 (the transformed activations, up to 32x the
                                 activations, are f16 operands): beyond that the scores are non-finite, never silently wrong, and
-                                main() recomputes the batch with BF16X3.  A window buffer that is not 4-byte aligned is served by the
-                                direct F16X3 form                                                                            */
+                                main() recomputes the batch along the chain F16X3TC -> F16X3 (f16 range, 65504) -> BF16X3 (f32
+                                range), logging every hop with the arithmetic that failed.  A window buffer that is not 4-byte
+                                aligned is served by the direct F16X3 form (round-1 kernel gnn_fused.hip, byte loads)           */
     GNN_PREC_F16X3 = 4       /* the direct three-pass form (gnn_fused_x3.hip), the default of round 3: split-f16 (hi+lo, 11+11 significant
                                 bits), 3 MFMA passes, logits GEMM split-f16 x 3 on the matrix pipe, dense head exact f32: f32-class
                                 accuracy (within 2e-5 of the exact-f32 path on every one of 10^6 windows); needs |activation| < 65504
                                 (f16 range)                                   */
 } gnn_precision;
+
+/* ---- experimental -------------------------------------------------------------------
+ * GNN_PREC_F16C8 (gnn_fused_c8.hip): one f16 MFMA pass + MX-scaled fp8 (e4m3) correction MFMAs of both operands' f16
+ * rounding residuals = 2.0 pass equivalents.  Inside the 1e-4 tolerance on BASELINE config 2 (7.2e-5), outside it on 10^6
+ * windows (1.3e-4, profiles/history/r02c6_tails.txt): it cannot ship, is frozen, and is linked only by
+ * `GNN_EXPERIMENTAL=1 genomad_amd/csrc/build.sh`; the default library answers GNN_ERR_STATE.  1 = this build has it. */
+int gnn_has_experimental(void);
 
 typedef enum gnn_onehot_dtype { GNN_OH_U8 = 0, GNN_OH_BF16 = 1, GNN_OH_F32 = 2 } gnn_onehot_dtype;
 
@@ -179,7 +183,10 @@ int gnn_classify(gnn_ctx* ctx, const uint8_t* bases_host, int64_t n_windows, int
  * GNN_BACKEND_OVERLAP=1 also overlaps the chunks of a synchronous multi-chunk call (the policy of rounds 2-4, slower beside the
  * power-bound default kernel: profiles/r04/backend_overlap_ab.txt);
  * GNN_DEBUG_POISON=1 fills the workspaces with NaN patterns before every launch (a kernel reading what its launch has not
- * written turns the scores into NaN); GNN_X3_ROUND1=1 serves F16X3 / BF16X3 with the round-1 kernel (A/B measurements). */
+ * written turns the scores into NaN); GNN_X3_ROUND1=1 serves F16X3 / BF16X3 with the round-1 kernel (A/B measurements);
+ * GNN_NO_PAD_SKIP=1 / GNN_NO_TIME_SPLIT=1 start every ctx with the padding skip / the time split off (gnn_debug_set_*);
+ * GNN_LOGITS_F32=1 keeps the logits GEMM on the f32 FMA path.  Each switch is read once and announced on stderr.
+ * Memory: the asynchronous entry point alternates TWO workspaces (2 x 0.86 MB per window of a launch, see gnn_set_chunk). */
 int gnn_classify_dev_async(gnn_ctx* ctx, const uint8_t* bases_dev, int64_t n_windows, int precision, float* scores_dev);
 int gnn_classify_flush(gnn_ctx* ctx);
 
@@ -325,6 +332,8 @@ int gnn_debug_set_pad_skip(gnn_ctx* ctx, int on);
  * warm-up step (gnn_fused_x3.hip) - bit-identical to the one-workgroup launch by construction.  on = 0 launches one workgroup per
  * window whatever the batch size; the default is on (environment GNN_NO_TIME_SPLIT=1 turns it off at gnn_create). */
 int gnn_debug_set_time_split(gnn_ctx* ctx, int on);
+/* workgroups per window of the ctx's last launch of a streaming kernel (F16X3TC / F16X3 / BF16X3): 1, or 2..4 under the time split */
+int gnn_debug_last_split(gnn_ctx* ctx, int* workgroups_per_window);
 
 /* test aid, host only (no GPU, no ctx): the f16c6 weight stream of a row-major K x N matrix (K multiple of 128, N of 32) as
  * gnn_load_weights builds it — per (k32 step, 32-column block) 3584 B: the f16 fragments of the two k16 halves (2 x 1 KiB:
@@ -333,7 +342,13 @@ int gnn_debug_set_time_split(gnn_ctx* ctx, int on);
  * [k / 128][block][lane], byte (k / 32) % 4.  need_words receives the size in 32-bit words; out may be NULL to query it. */
 int gnn_debug_pack_c6(const float* w, int k, int n, uint32_t* out, size_t out_words, size_t* need_words);
 
-/* windows the ctx processes per launch of the fused front end (workspace sizing: 0.79 MB per window; default 16384) */
+/* Windows the ctx processes per launch of the fused front end.  Workspace: 0.86 MB per window of a launch (pair products, pooled
+ * y @ w_v rows, logits, attention weights, features) - 14 GB at the default ceiling of 16384, allocated on the first large call and
+ * TWICE that once gnn_classify_dev_async is used (two alternating workspaces).  Without a call to this function the library clamps
+ * the default to a quarter of the device memory that is free when the workspace first grows (shared / partitioned GPUs) and says so
+ * on stderr; with or without it, a failed workspace allocation is retried with half the launch size (down to 256 windows) before
+ * GNN_ERR_NOMEM is returned, and a second workspace that does not fit makes the asynchronous path run in order on one.
+ * 16384 vs 2048 windows per launch: +0.7 % throughput (profiles/r04/backend_overlap_ab.txt). */
 int gnn_set_chunk(gnn_ctx* ctx, int64_t windows_per_chunk);
 
 #ifdef __cplusplus

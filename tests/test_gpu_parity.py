@@ -172,6 +172,20 @@ def test_errors_are_reported_not_swallowed(engine):
 # opt-in fast mode (f16c6).  f16c8 and the round-1 kernel are frozen: one smoke test each
 # (test_frozen_f16c8_kernel_smoke, test_single_pass_bf16_is_outside_tolerance_but_sane).
 FUSED = ["f16c6", "f16x3", "f16x3tc", "bf16x3"]
+
+
+def _has_experimental() -> bool:
+    """the f16c8 kernel is linked only by GNN_EXPERIMENTAL=1 builds (include/genomad_nn.h, "experimental")"""
+    from genomad_amd import _lib
+    return bool(_lib.load().gnn_has_experimental())
+
+
+def _with_c8(precs):
+    """the list with "f16c8" only where this build has it"""
+    return [p for p in precs if p != "f16c8" or _has_experimental()]
+
+
+needs_experimental = pytest.mark.skipif(not _has_experimental(), reason="f16c8 is experimental: GNN_EXPERIMENTAL=1 genomad_amd/csrc/build.sh")
 # the contig front end is exercised with the default arithmetic first (what main() runs), then the fallback
 from genomad_amd._lib import DEFAULT_PRECISION  # noqa: E402
 CONTIG_PRECS = [DEFAULT_PRECISION, "bf16x3"]
@@ -230,6 +244,16 @@ def test_fused_edge_windows(engine, synth_weights, prec):
     assert engine.classify(bases[:0], prec).shape == (0, 3)
 
 
+def test_default_build_answers_f16c8_with_an_error(engine):
+    """the default library has no f16c8 kernel and says so instead of computing something else."""
+    from genomad_amd._lib import GnnError
+    if _has_experimental():
+        pytest.skip("experimental build")
+    with pytest.raises(GnnError, match="experimental"):
+        engine.classify(synthetic.synth_windows(0, 2), "f16c8")
+
+
+@needs_experimental
 def test_frozen_f16c8_kernel_smoke(engine, synth_weights):
     """f16c8 (gnn_fused_c8.hip) is frozen: kept buildable and inside the tolerance on a small batch, no longer in the matrix."""
     bases = synthetic.synth_windows(0, 64)
@@ -238,6 +262,7 @@ def test_frozen_f16c8_kernel_smoke(engine, synth_weights):
     assert np.array_equal(got[11:19], engine.classify(bases[11:19], "f16c8"))
 
 
+@needs_experimental
 def test_f16c8_large_activations_saturate_instead_of_nan(synth_weights):
     """The e4m3 images of the f16c8 operands are clamped at +-448 (v_cvt_pk_fp8_f32 returns NaN above 464):
     with conv1 weights scaled up until activations pass that bound the fused path must stay finite and
@@ -261,6 +286,108 @@ def test_f16c8_large_activations_saturate_instead_of_nan(synth_weights):
     assert np.isfinite(got6).all() and np.abs(got6 - exact).max() <= SCORE_TOL
 
 
+def _scaled_activations(synth_weights, f):
+    """The same network with ALL activations (x1, x2, x3) scaled by f, a power of two: conv1 (kernel and bias) and the conv2 / conv3
+    biases times f - LeakyReLU is positively homogeneous -, compensated only where the arithmetic is f32: the folded IGLOO weights
+    (w_mult / f: the pair products are unchanged) and the first dense layer (kernel / f: yp and the features are f times larger).
+    conv2, conv3 and w_v - the operands that become f16 limbs - keep their magnitude, so a mode's accuracy at that scale is a statement
+    about its ACTIVATION range only.  The exact-f32 path computes bit-identical scores for every power of two."""
+    w = dict(synth_weights)
+    for k, g in (("conv1_kernel", f), ("conv1_bias", f), ("conv2_bias", f), ("conv3_bias", f), ("iglooA_w_mult", 1 / f),
+                 ("iglooB_w_mult", 1 / f), ("enc_dense_kernel", 1 / f)):
+        w[k] = synth_weights[k] * np.float32(g)
+    return w
+
+
+def _write_weights_and_fasta(tmp_path, monkeypatch, w, n_contigs=3):
+    from genomad_amd import weights as W
+    rng = np.random.default_rng(3)
+    fa = tmp_path / "s.fna"
+    fa.write_text("".join(f">c{i}\n{''.join(rng.choice(list('ACGT'), 9000))}\n" for i in range(n_contigs)))
+    wpath = tmp_path / "w.npz"
+    W.save_npz(wpath, w)
+    monkeypatch.setenv("GENOMAD_AMD_WEIGHTS", str(wpath))
+    return fa
+
+
+def engine_scores_unscaled(synth_weights, bases):
+    from genomad_amd.engine import NNEngine
+    with NNEngine(0, synth_weights) as e0:
+        return e0.classify(bases, "f32")
+
+
+def test_toomcook_range_band_falls_back_to_the_direct_f16_form(synth_weights, tmp_path, monkeypatch):
+    """between |activation| ~4e3 and 65 504 only the Toom-Cook form's TRANSFORMED operands (up to 32x the activations)
+    leave the f16 range.  There f16x3tc must return non-finite scores (inf / -inf limb pairs -> NaN, NaN-propagating pool), never
+    finite wrong ones; the direct f16x3 form is still exact; and main() hops exactly once, f16x3tc -> f16x3."""
+    from genomad_amd import nn_classification as nnc
+    from genomad_amd.engine import NNEngine
+    w = _scaled_activations(synth_weights, 4096.0)
+    bases = synthetic.synth_windows(0, 8)
+    fa = _write_weights_and_fasta(tmp_path, monkeypatch, w)
+    with NNEngine(0, w) as e2:
+        _, taps = e2.debug_forward(bases, "f32", taps=("x1", "x3"))
+        peak = max(float(np.abs(taps[k]).max()) for k in ("x1", "x3"))
+        assert 4e3 < peak < 6.5e4, peak                     # inside the band
+        exact = e2.classify(bases, "f32")
+        assert np.array_equal(exact, engine_scores_unscaled(synth_weights, bases))       # a power of two: the same function, bit for bit
+        tc, direct = e2.classify(bases, "f16x3tc"), e2.classify(bases, "f16x3")
+        assert not np.isfinite(tc).all()
+        assert np.isfinite(direct).all() and np.abs(direct - exact).max() <= SCORE_TOL / 2
+        monkeypatch.delenv("GENOMAD_AMD_PRECISION", raising=False)
+        monkeypatch.setattr(nnc, "_ENGINE", e2)
+        nnc._WARNED.clear()
+        nnc.main(fa, tmp_path / "out", False, 128, False, 1, False, False)
+        z = np.load(tmp_path / "out" / "s_nn_classification" / "s_nn_classification.npz")
+        names, seq, off = sequence.read_fasta_packed(fa)
+        want, _ = e2.classify_contigs(seq, off, False, "f16x3")
+    assert np.isfinite(z["predictions"]).all() and np.array_equal(z["predictions"], want)
+    log = (tmp_path / "out" / "s_nn_classification.log").read_text()
+    assert log.count("recomputing") == 1 and "(f16x3tc)" in log and "with f16x3." in log
+    assert "Parity sentinel: max |dscore| of f16x3 against" in log      # the sentinel judged the arithmetic that served the run
+
+
+def test_parity_sentinel_trips_on_weights_outside_the_validated_range(synth_weights, tmp_path, monkeypatch, capsys):
+    """main() classifies its first <= 64 windows with GNN_PREC_F32 as well.  With the synthetic weights the
+    line reads ~1e-5; with the activations scaled DOWN into the f16 subnormals (x 2^-17: neither limb carries them any more, the
+    scores stay finite and are wrong) the run must stop with status 1 before it writes an output; the opt-out runs."""
+    import time
+    from genomad_amd import nn_classification as nnc
+    from genomad_amd.engine import NNEngine
+    monkeypatch.delenv("GENOMAD_AMD_PRECISION", raising=False)
+    fa = _write_weights_and_fasta(tmp_path, monkeypatch, synth_weights)
+    with NNEngine(0, synth_weights) as e1:
+        monkeypatch.setattr(nnc, "_ENGINE", e1)
+        nnc.main(fa, tmp_path / "ok", False, 128, False, 1, False, False)
+        log = (tmp_path / "ok" / "s_nn_classification.log").read_text()
+        line = [ln for ln in log.splitlines() if "Parity sentinel" in ln]
+        assert len(line) == 1 and "of f16x3tc against" in line[0]
+        d = float(line[0].split("= ")[1].split()[0])
+        assert d <= SCORE_TOL / 2, line
+        names, seq, off = sequence.read_fasta_packed(fa)
+        win = nnc.sentinel_windows(seq, off, False)
+        assert len(win) == 6                                  # 3 contigs x (6000 + 3000)
+        t = time.perf_counter()
+        nnc.parity_sentinel(e1, win, "f16x3tc", None)
+        cost = time.perf_counter() - t
+        print(f"parity sentinel: {d:.2e} on the synthetic weights, {cost * 1e3:.0f} ms per run (warm)")
+        assert cost < 1.0
+    tiny = _scaled_activations(synth_weights, 2.0 ** -17)
+    _write_weights_and_fasta(tmp_path, monkeypatch, tiny)
+    with NNEngine(0, tiny) as e2:
+        bases = synthetic.synth_windows(0, 8)
+        exact, got = e2.classify(bases, "f32"), e2.classify(bases, "f16x3tc")
+        assert np.isfinite(got).all() and np.abs(got - exact).max() > SCORE_TOL     # finite and wrong: what only the sentinel can see
+        monkeypatch.setattr(nnc, "_ENGINE", e2)
+        with pytest.raises(SystemExit) as ex:
+            nnc.main(fa, tmp_path / "bad", False, 128, False, 1, False, False)
+        assert ex.value.code == 1 and "Parity sentinel FAILED" in capsys.readouterr().err
+        assert not (tmp_path / "bad" / "s_nn_classification").exists()
+        monkeypatch.setenv("GENOMAD_AMD_NO_SENTINEL", "1")
+        nnc.main(fa, tmp_path / "optout", False, 128, False, 1, False, False)
+        assert (tmp_path / "optout" / "s_nn_classification" / "s_nn_classification.tsv").exists()
+
+
 def test_f16_modes_overflow_is_detected_and_main_falls_back_to_bf16x3(synth_weights, tmp_path, monkeypatch):
     """Activations beyond the f16 range (65504): the f16-operand modes return non-finite scores — never silently
     wrong finite ones — and main() recomputes the affected batch with the split-bf16 kernel (f32 range)."""
@@ -278,12 +405,12 @@ def test_f16_modes_overflow_is_detected_and_main_falls_back_to_bf16x3(synth_weig
     with NNEngine(0, w) as e2:
         exact, wide = e2.classify(bases, "f32"), e2.classify(bases, "bf16x3")
         assert np.isfinite(wide).all() and np.abs(wide - exact).max() <= 1e-3
-        for prec in ("f16c8", "f16c6", "f16x3", "f16x3tc"):
+        for prec in _with_c8(("f16c8", "f16c6", "f16x3", "f16x3tc")):
             assert not np.isfinite(e2.classify(bases, prec)).all(), prec
         wpath = tmp_path / "w.npz"
         W.save_npz(wpath, w)
         monkeypatch.setenv("GENOMAD_AMD_WEIGHTS", str(wpath))
-        monkeypatch.setenv("GENOMAD_AMD_PRECISION", "f16c8")
+        monkeypatch.setenv("GENOMAD_AMD_PRECISION", "f16c6")
         monkeypatch.setattr(nnc, "_ENGINE", e2)
         nnc.main(fa, tmp_path / "out", False, 128, False, 1, False, False)
         z = np.load(tmp_path / "out" / "s_nn_classification" / "s_nn_classification.npz")
@@ -489,7 +616,7 @@ def test_config2_10k_windows_vs_reference_graph_golden(engine, golden_dir):
     n = len(ref32)
     assert n == 10_000
     worst = {}
-    for prec, tol64 in (("f32", 2e-5), ("f16x3", 2e-5), ("f16x3tc", 2e-5), ("bf16x3", SCORE_TOL), ("f16c8", SCORE_TOL), ("f16c6", SCORE_TOL)):
+    for prec, tol64 in (("f32", 2e-5), ("f16x3", 2e-5), ("f16x3tc", 2e-5), ("bf16x3", SCORE_TOL), ("f16c6", SCORE_TOL)):
         got = _classify_resident(engine, 0, n, prec)
         assert np.isfinite(got).all() and np.allclose(got.sum(1), 1.0, atol=1e-5)
         e32, e64 = np.abs(got - ref32).max(), np.abs(got - truth).max()
@@ -531,7 +658,7 @@ def test_config3_1m_windows_sharding_determinism_and_accuracy(engine, golden_dir
     assert np.abs(one[sample[:512]] - exact).max() <= SCORE_TOL / 2
     # the opt-in fast modes on the same strided windows: inside the tolerance here or not, they must stay in its neighbourhood
     # (1.2e-4 was seen on 10^6 windows) - a regression to 1e-3 class errors fails
-    for fast in ("f16c6", "f16c8"):
+    for fast in ("f16c6",):
         got = np.concatenate([_classify_resident(engine, int(a), 1, fast) for a in idx[:256]])
         assert np.abs(got - g["scores_refgraph32"][:256]).max() <= 2 * SCORE_TOL, fast
 
@@ -774,14 +901,14 @@ def test_second_weight_set_and_engine(synth_weights):
     want = igloo_oracle.classify_windows(bases, w2, np.float32)
     with NNEngine(0, w2) as e2:
         got = e2.classify(bases, "bf16x3")
-        got8 = e2.classify(bases, "f16c8")
+        got8 = e2.classify(bases, "f16c8") if _has_experimental() else None
         got6 = e2.classify(bases, "f16c6")
         got16 = e2.classify(bases, "f16x3")
         exact = e2.classify(bases, "f32")
     assert np.abs(exact - want).max() <= 2e-5
     assert np.abs(got16 - want).max() <= 2e-5
     assert np.abs(got - want).max() <= SCORE_TOL
-    assert np.abs(got8 - want).max() <= SCORE_TOL
+    assert got8 is None or np.abs(got8 - want).max() <= SCORE_TOL
     assert np.abs(got6 - want).max() <= SCORE_TOL
     assert not np.array_equal(got, np.zeros_like(got))
     w3 = _calibrated_weights(43)
@@ -789,11 +916,11 @@ def test_second_weight_set_and_engine(synth_weights):
     with NNEngine(0, w3) as e3:
         exact = e3.classify(big, "f32")
         assert exact.std(axis=0).min() > 0.05, exact.std(axis=0)          # every class score varies: the check is not vacuous
-        err = {prec: float(np.abs(e3.classify(big, prec) - exact).max()) for prec in ("f16x3", "f16x3tc", "bf16x3", "f16c8", "f16c6")}
+        err = {prec: float(np.abs(e3.classify(big, prec) - exact).max()) for prec in _with_c8(("f16x3", "f16x3tc", "bf16x3", "f16c8", "f16c6"))}
     print("seed-43 weights (calibrated), 4096 windows, max |dscore| vs the exact-f32 path:", err)
     assert DEFAULT_PRECISION == "f16x3tc" and err["f16x3tc"] <= SCORE_TOL / 4 and err["f16x3"] <= SCORE_TOL / 4
     assert err["bf16x3"] <= SCORE_TOL
-    assert err["f16c8"] <= 2 * SCORE_TOL and err["f16c6"] <= 2 * SCORE_TOL
+    assert err.get("f16c8", 0.0) <= 2 * SCORE_TOL and err["f16c6"] <= 2 * SCORE_TOL
 
 
 @pytest.mark.parametrize("prec", ["f16c6", "f16x3", "f16x3tc", "bf16x3"])
@@ -844,11 +971,12 @@ def test_f16c6_rejects_a_misaligned_window_buffer(engine):
         buf.upload(np.concatenate([shifted, np.zeros(7, np.uint8)]))
         with pytest.raises(GnnError, match="4-byte aligned"):
             engine.classify_dev(buf.ptr + 1, 2, out.ptr, "f16c6")
-        engine.classify_dev(buf.ptr + 1, 2, out.ptr, "f16c8")
-        engine.sync()
-        got = out.download((2, 3), np.float32)
-        want = engine.classify(host[:2 * 6000].reshape(2, 6000), "f16c8")
-        assert np.array_equal(got, want)
+        if _has_experimental():
+            engine.classify_dev(buf.ptr + 1, 2, out.ptr, "f16c8")
+            engine.sync()
+            got = out.download((2, 3), np.float32)
+            want = engine.classify(host[:2 * 6000].reshape(2, 6000), "f16c8")
+            assert np.array_equal(got, want)
         # the three-pass modes take it too: the round-1 kernel (byte loads) serves such a buffer instead of the streaming
         # one; same arithmetic, sums in another order -> equal within f32 rounding, far inside the tolerance
         for prec in ("f16x3", "f16x3tc", "bf16x3"):
@@ -904,10 +1032,10 @@ def test_asynchronous_classification_is_bit_identical(engine):
         assert not report, "; ".join(report)
         assert np.isfinite(t3["feat"]).all() and np.abs(t3["feat"]).max() > 0
         # no explicit flush: a download orders the pending back end as well
-        engine.classify_dev_async(bases.ptr, 512, b.ptr, "f16c8")
-        engine.classify_dev_async(bases.ptr + 512 * 6000, 512, b.ptr + 512 * 12, "f16c8")
+        engine.classify_dev_async(bases.ptr, 512, b.ptr, "f16x3")
+        engine.classify_dev_async(bases.ptr + 512 * 6000, 512, b.ptr + 512 * 12, "f16x3")
         got8 = b.download((1024, 3), np.float32)
-        engine.classify_dev(bases.ptr, 1024, a.ptr, "f16c8")
+        engine.classify_dev(bases.ptr, 1024, a.ptr, "f16x3")
         engine.sync()
         assert np.array_equal(got8, a.download((1024, 3), np.float32))
     finally:
@@ -1009,16 +1137,20 @@ def test_time_split_small_batches_are_bit_identical(engine):
                     break                                  # the fallback: the small sizes are enough
         _lib.check(engine.lib.gnn_debug_set_pad_skip(engine.ctx, 1))
         # the point of it: one call of 128 windows through the host-buffer entry point
-        ms = {}
+        import ctypes
+        ms, split = {}, ctypes.c_int()
         for on in (0, 1):
             _lib.check(engine.lib.gnn_debug_set_time_split(engine.ctx, on))
             engine.classify(wins[:128])
+            _lib.check(engine.lib.gnn_debug_last_split(engine.ctx, ctypes.byref(split)))
+            # that the split happened is checked structurally (a wall-clock bound on a 1 ms launch fails on a shared
+            # or throttled GPU without any defect): 128 windows on 256 CUs = 2 workgroups per window, 1 with the switch off
+            assert split.value == (max(1, min(4, engine.device_info()["cus"] // 128)) if on else 1), (on, split.value)
             t = time.perf_counter()
             for _ in range(20):
                 engine.classify(wins[:128])
             ms[on] = (time.perf_counter() - t) / 20 * 1e3
-        print(f"gnn_classify of 128 windows: {ms[0]:.3f} ms one workgroup per window, {ms[1]:.3f} ms time split")
-        assert ms[1] < 0.9 * ms[0]          # measured 1.11-1.14 vs 1.50 ms; the bound only catches the split not happening at all
+        print(f"gnn_classify of 128 windows: {ms[0]:.3f} ms one workgroup per window, {ms[1]:.3f} ms time split (informational)")
     finally:
         _lib.check(engine.lib.gnn_debug_set_time_split(engine.ctx, 1))
         _lib.check(engine.lib.gnn_debug_set_pad_skip(engine.ctx, 1))

@@ -663,7 +663,7 @@ def test_install_rebinds_the_reference_entry_point_and_undoes_cuda_visible_devic
         os.environ["CUDA_VISIBLE_DEVICES"] = "-1"              # e.g. another module re-imported the reference one
         monkeypatch.setenv("GENOMAD_AMD_FRONT_END", "host")
         monkeypatch.delenv("WORLD_SIZE", raising=False)
-        monkeypatch.setattr(nnc, "GpuBackend", lambda batch_size: FakeBackend())
+        monkeypatch.setattr(nnc, "GpuBackend", lambda batch_size, console=None: FakeBackend())
 
         def cli_nn_classification(input, output, single_window, batch_size, restart, threads, verbose, cleanup):
             genomad.nn_classification.main(input, output, single_window, batch_size, restart, threads, verbose, cleanup)
@@ -953,6 +953,9 @@ def test_bench_n8_line_is_complete_over_the_fake_engine(tmp_path):
 class _FakeContigEngine:
     """classify_contigs of the device front end with a fixed function of the contig bytes in place of the network."""
 
+    def classify(self, windows, precision=None):          # the parity sentinel's two calls: the same function for every arithmetic
+        return FakeBackend().score(windows)
+
     def classify_contigs(self, seq, offsets, single_window=False, precision=None):
         offsets = np.asarray(offsets, np.int64)
         _, _, ids, _ = sequence.candidate_spans(offsets, single_window)
@@ -1107,3 +1110,126 @@ def test_range_fallback_chain_of_the_default_arithmetic():
     calls.clear()
     nnc.classify_contigs_safely(Eng(set()), None, None, False, "f32", console)       # exact f32: nothing to fall back to
     assert calls == ["f32"]
+
+
+# ------------------------------------------------------------------ runtime parity sentinel
+class _SentinelEngine(_FakeContigEngine):
+    """classify() = the fake score function, off by `delta` for every arithmetic but f32; non-finite for the arithmetics in `nan`."""
+
+    def __init__(self, delta=0.0, nan=()):
+        self.delta, self.nan, self.calls = delta, set(nan), []
+
+    def classify(self, windows, precision=None):
+        self.calls.append((precision, len(windows)))
+        s = FakeBackend().score(windows)
+        if precision in self.nan:
+            s = s.copy()
+            s[0, 0] = np.nan
+        elif precision != "f32":
+            s = s + np.float32(self.delta)
+        return s
+
+
+def test_sentinel_windows_are_the_first_candidate_windows_upper_cased_and_padded():
+    seq = np.frombuffer(b"acgtNNnn" * 1000 + b"ACGT" * 700, dtype=np.uint8)          # contigs of 8000 and 2800 bases
+    off = np.array([0, 8000, 10800], np.int64)
+    win = nnc.sentinel_windows(seq, off, False)
+    assert win.shape == (2, 6000) and win.dtype == np.uint8                          # 8000 -> one window (tail 2000 < 2500), 2800 -> window 0
+    assert bytes(win[0]) == (b"acgtNNnn" * 750).upper() and bytes(win[1][:2800]) == b"ACGT" * 700 and set(win[1][2800:]) == {ord("N")}
+    assert len(nnc.sentinel_windows(seq, off, False, limit=1)) == 1
+    assert nnc.sentinel_windows(seq, np.array([0], np.int64), False).shape == (0, 6000)
+
+
+def test_parity_sentinel_measures_logs_and_follows_the_range_fallbacks(monkeypatch):
+    logs = []
+    console = type("C", (), {"log": lambda self, m, **k: logs.append(m), "error": lambda self, m, **k: logs.append("E " + m)})()
+    win = np.frombuffer((b"ACGT" * 1500) * 3, dtype=np.uint8).reshape(3, 6000)
+    nnc._WARNED.clear()
+    e = _SentinelEngine(delta=2e-5)
+    d = nnc.parity_sentinel(e, win, "f16x3tc", console)
+    assert abs(d - 2e-5) < 1e-7 and e.calls == [("f32", 3), ("f16x3tc", 3)] and "f16x3tc" in logs[-1] and "2.00e-05" in logs[-1]
+    nnc.sentinel_verdict(None, d, console, "f16x3tc")                                 # inside the tolerance: returns
+    # non-finite production scores: the sentinel judges the arithmetic that will actually serve the run, and each hop's log line
+    # names the arithmetic that FAILED (ADVICE r04: the second hop used to print the configured one)
+    logs.clear()
+    e = _SentinelEngine(delta=1e-6, nan=("f16x3tc", "f16x3"))
+    d = nnc.parity_sentinel(e, win, "f16x3tc", console)
+    assert [c[0] for c in e.calls] == ["f32", "f16x3tc", "f16x3", "bf16x3"] and d < 1e-5
+    assert "(f16x3tc)" in logs[0] and "with f16x3." in logs[0] and "(f16x3)" in logs[1] and "with bf16x3." in logs[1] and "of bf16x3 " in logs[2]
+    # outside the tolerance: loud exit, status 1, with the way out in the message
+    logs.clear()
+    d = nnc.parity_sentinel(_SentinelEngine(delta=3e-4), win, "f16x3tc", console)
+    with pytest.raises(SystemExit) as ex:
+        nnc.sentinel_verdict(None, d, console, "f16x3tc")
+    assert ex.value.code == 1 and logs[-1].startswith("E Parity sentinel FAILED") and "GENOMAD_AMD_NO_SENTINEL" in logs[-1]
+    # every arithmetic non-finite: inf, fails
+    assert nnc.parity_sentinel(_SentinelEngine(nan=("f16x3tc", "f16x3", "bf16x3")), win, "f16x3tc", console) == float("inf")
+    # nothing to check: the exact arithmetic itself, no windows, or the opt-out
+    assert nnc.parity_sentinel(_SentinelEngine(delta=1.0), win, "f32", console) is None
+    assert nnc.parity_sentinel(_SentinelEngine(delta=1.0), win[:0], "f16x3tc", console) is None
+    monkeypatch.setenv("GENOMAD_AMD_NO_SENTINEL", "1")
+    assert nnc.parity_sentinel(_SentinelEngine(delta=1.0), win, "f16x3tc", console) is None
+
+
+def test_main_stops_before_writing_anything_when_the_sentinel_trips(tmp_path, monkeypatch, capsys):
+    fa = tmp_path / "s.fna"
+    _write_fasta(fa, [("c1", "ACGT" * 2000), ("c2", "GGCA" * 1800)])
+    monkeypatch.delenv("GENOMAD_AMD_FRONT_END", raising=False)
+    monkeypatch.delenv("WORLD_SIZE", raising=False)
+    monkeypatch.setattr(nnc, "_engine", lambda: _SentinelEngine(delta=5e-4))
+    with pytest.raises(SystemExit) as ex:
+        nnc.main(fa, tmp_path / "bad", False, 128, False, 1, False, False)
+    assert ex.value.code == 1 and "Parity sentinel FAILED" in capsys.readouterr().err
+    assert not (tmp_path / "bad" / "s_nn_classification").exists()
+    log = (tmp_path / "bad" / "s_nn_classification.log").read_text()
+    assert "Parity sentinel: max |dscore| of f16x3tc" in log and "5.00e-04" in log
+    good = _SentinelEngine(delta=1e-5)
+    monkeypatch.setattr(nnc, "_engine", lambda: good)
+    nnc.main(fa, tmp_path / "ok", False, 128, False, 1, False, False)
+    assert (tmp_path / "ok" / "s_nn_classification" / "s_nn_classification.tsv").exists()
+    assert good.calls == [("f32", 2), ("f16x3tc", 2)]                                 # once per run, on the first windows only
+    assert "Parity sentinel: max |dscore| of f16x3tc" in (tmp_path / "ok" / "s_nn_classification.log").read_text()
+    monkeypatch.setenv("GENOMAD_AMD_NO_SENTINEL", "1")
+    monkeypatch.setattr(nnc, "_engine", lambda: _SentinelEngine(delta=5e-4))
+    nnc.main(fa, tmp_path / "optout", False, 128, False, 1, False, False)             # opted out: runs through
+    assert (tmp_path / "optout" / "s_nn_classification" / "s_nn_classification.tsv").exists()
+
+
+def _sentinel_rank_worker(rank, world, port, fasta, out_dir, q, bad_rank):
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    os.environ.pop("GENOMAD_AMD_FRONT_END", None)
+    from tests.gloo_comm import GlooComm
+    nnc._engine = lambda: _SentinelEngine(delta=5e-4 if rank == bad_rank else 1e-6)
+    comm = GlooComm(rank, world, port)
+    code = 0
+    try:
+        nnc.main(fasta, out_dir, False, 128, False, 1, False, False, _comm=comm)
+    except SystemExit as e:
+        code = e.code
+    q.put((rank, code))
+    comm.close()
+
+
+def test_sentinel_failure_on_one_rank_stops_every_rank(tmp_path):
+    """A rank whose first windows leave the tolerance must not leave the others waiting in the gather: the verdict is collective."""
+    mp = pytest.importorskip("torch.multiprocessing")
+    import socket
+    rng = np.random.default_rng(9)
+    fa = tmp_path / "m.fna"
+    _write_fasta(fa, [(f"c{i}", "".join(rng.choice(list("ACGT"), 7000))) for i in range(8)])
+    for bad_rank, want in ((1, [1, 1]), (-1, [0, 0])):
+        with socket.socket() as s:
+            s.bind(("127.0.0.1", 0))
+            port = s.getsockname()[1]
+        ctx = mp.get_context("spawn")
+        q = ctx.Queue()
+        out = tmp_path / f"out{bad_rank}"
+        procs = [ctx.Process(target=_sentinel_rank_worker, args=(r, 2, port, str(fa), str(out), q, bad_rank)) for r in range(2)]
+        for p in procs:
+            p.start()
+        got = sorted(q.get(timeout=180) for _ in procs)
+        for p in procs:
+            p.join(timeout=180)
+            assert p.exitcode == 0
+        assert [g[1] for g in got] == want
+        assert (out / "m_nn_classification" / "m_nn_classification.npz").exists() == (bad_rank < 0)
