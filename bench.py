@@ -103,6 +103,76 @@ def cpu_baseline(weights, sample: int, batch: int = 128):
             np.concatenate(scores))
 
 
+def encoder_block(eng, rank: int, launches: int = 8, windows: int = 2048):
+    """The stand-alone byte -> one-hot encoder (model.py:9-11) for the three output dtypes: windows/s and
+    HBM GB/s of `onehot_kernel` from HIP events on the library's stream (algorithmic bytes = 6000 in + 5997 x 257 x itemsize out per
+    window: the kernel's WRITE_SIZE is 1.000 x that, profiles/hbm_traffic.json), against the 8 TB/s HBM3E peak.  Untimed part of the
+    classification line (< 0.2 s of GPU time); `bench.py --kernel encoder` is the stand-alone bench of the same kernel."""
+    from genomad_amd import _lib
+    bases = eng.alloc(windows * 6000)
+    out = eng.alloc(windows * 5997 * 257 * 4)
+    res = {"kernel": "gnn::onehot_kernel", "bound": "hbm", "peak": HBM_PEAK_GBS, "unit": "GB/s", "windows_per_launch": windows,
+           "launches": launches, "frac": {}, "achieved": {}, "windows_per_s": {}, "avg_launch_ms": {}, "bytes_per_window": dict(ENCODER_BYTES)}
+    try:
+        eng.synth_windows_dev(rank * windows, windows, bases.ptr)
+        for name, code in (("u8", _lib.OH_U8), ("bf16", _lib.OH_BF16), ("f32", _lib.OH_F32)):
+            for _ in range(2):
+                _lib.check(eng.lib.gnn_onehot_dev(eng.ctx, bases.ptr, windows, code, out.ptr))
+            eng.profile_enable(True)
+            eng.profile_reset()
+            for _ in range(launches):
+                _lib.check(eng.lib.gnn_onehot_dev(eng.ctx, bases.ptr, windows, code, out.ptr))
+            ms, n = eng.profile_get(_lib.K_ENCODER)
+            eng.profile_enable(False)
+            avg = ms / max(n, 1)
+            gbs = ENCODER_BYTES[name] * windows / (avg * 1e-3) / 1e9 if avg > 0 else 0.0
+            res["achieved"][name] = round(gbs, 1)
+            res["frac"][name] = round(gbs / HBM_PEAK_GBS, 4)
+            res["windows_per_s"][name] = round(windows / (avg * 1e-3), 1) if avg > 0 else 0.0
+            res["avg_launch_ms"][name] = round(avg, 5)
+    finally:
+        bases.free()
+        out.free()
+    return res
+
+
+def hbm_traffic(precision: str):
+    """(bytes per window, source text) of the dominant kernel's HBM-side traffic from the committed PMC passes
+    (profiles/hbm_traffic.json, regenerated from profiles/r05/rocprof/pmc_1.txt and pmc_2.txt by scripts/hbm_traffic_json.py)."""
+    tpath = os.path.join(ROOT, "profiles", "hbm_traffic.json")
+    if not os.path.exists(tpath):
+        return None, None
+    tj = json.load(open(tpath))
+    per_window = tj.get("bytes_per_window", {}).get(precision)
+    if per_window is None:
+        return None, None
+    return per_window, ("NOT measured by this run: 2*FETCH_SIZE + WRITE_SIZE per window from separate rocprofv3 --pmc passes of this "
+                        "command (" + tj.get("source", "profiles/README.md") + "), scaled to this run's windows per launch")
+
+
+def front_roofline(precision, windows_per_launch, avg_ms, launches, front_ms, back_ms):
+    """The `roofline` object of the dominant kernel (fused front end): algorithmic FLOP per launch / mean HIP-event launch duration."""
+    tflops = FLOP_PER_WINDOW * windows_per_launch / (avg_ms * 1e-3) / 1e12 if avg_ms > 0 else 0.0
+    per_window, source = hbm_traffic(precision)
+    traffic = int(per_window * windows_per_launch) if per_window is not None else None
+    alg = int(6012 * windows_per_launch)
+    return {
+        "bound": "mfma", "achieved": round(tflops, 2), "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+        "frac": round(tflops / MFMA_PEAK_TFLOPS, 4), "traffic": traffic, "traffic_source": source,
+        "algorithmic_bytes_per_launch": alg,
+        "traffic_over_algorithmic": round(traffic / alg, 1) if traffic and alg else None,
+        "traffic_note": "HBM is not the bound (traffic / launch time = 3 % of 8 TB/s); the excess over the algorithmic bytes is the f32 spill of the "
+                        "pooled y @ w_v rows (767 KB/window) and pair products (67 KB/window) from the front end to the back end, written once and "
+                        "read once: the softmax over the 749 pooled positions needs all of a window's 2 100 patches first (DESIGN.md section 3)",
+        "kernel": FRONT_KERNEL[precision],
+        "flop_per_launch": int(FLOP_PER_WINDOW * windows_per_launch), "avg_launch_ms": round(avg_ms, 4),
+        "launches": int(launches), "mfma_passes": MFMA_PASSES.get(precision),
+        "note": "achieved counts ALGORITHMIC flops (2.763 GFLOP/window) against the dense 16-bit MFMA peak; the "
+                "1e-4 tolerance needs more than one 16-bit pass per product (profiles/history/r02_precision_study.json): "
+                "mfma_passes bf16-pass equivalents are issued, which caps frac at 1/mfma_passes",
+        "backend_ms_total": round(back_ms, 2), "front_ms_total": round(front_ms, 2)}
+
+
 class PowerSampler:
     """`rocm-smi -d <gpu> --showpower` every ~0.4 s on a helper thread (a separate process: nothing is enqueued on the GPU)."""
 
@@ -239,6 +309,14 @@ def main():
     ap.add_argument("--power", action="store_true",
                     help="sample `rocm-smi --showpower` of this rank's GPU on a helper thread during the timed region: mean watts and "
                          "joules per window in the line")
+    ap.add_argument("--no-coalesce", action="store_true",
+                    help="strong scaling with several ranks: launch every step of a rank on its own (65536 / N windows: 8192 at N = 8 = 32 rounds "
+                         "of workgroups) instead of coalescing a rank's consecutive steps into launches of --chunk windows (the default: the "
+                         "job's K steps are still all classified inside the timed region, there is still ONE gather; VERDICT r04 item 7)")
+    ap.add_argument("--dump-scores", default=None, metavar="PATH.npy",
+                    help="rank 0 saves the gathered (total, 3) f32 scores of the timed steps (tests/test_multi_gpu.py compares a D-rank run "
+                         "with a 1-rank run of the same job bit for bit)")
+    ap.add_argument("--no-encoder", action="store_true", help="skip the encoder block of the classification line (untimed, < 0.2 s)")
     ap.add_argument("--share-devices", action="store_true",
                     help="testing aid for boxes with fewer GPUs than ranks: rank r uses device r mod (visible devices), so the "
                          "spawn and the RCCL bootstrap run as far as RCCL's own duplicate-device check")
@@ -260,8 +338,11 @@ def main():
     # the same run"), before the engine and the communicator exist: the other ranks wait for rank 0's RCCL unique id meanwhile
     # (RcclComm polls for up to 10 minutes), no GPU work is in flight and nothing timed has started.
     cpu_base, cpu_scores = None, None
-    if rank == 0 and args.cpu_sample > 0 and args.kernel == "classify" and args.workload == "windows":
+    if rank == 0 and args.cpu_sample > 0 and args.kernel == "classify":
         cpu_base, cpu_scores = cpu_baseline(weights, args.cpu_sample)
+        if args.workload == "metagenome":
+            cpu_base["sample"] += (" The metagenome's windows are cut from this same synthetic byte stream (read flat), so the sample is "
+                                   "a sample of its windows; the CPU side of contig cutting / the N rule / the per-contig mean is negligible next to it.")
     eng, _n_dev, local_rank = make_engine(local_rank, weights, args.chunk)
     info = eng.device_info()
     t_ci = time.perf_counter()
@@ -339,6 +420,8 @@ def main():
 
         for _ in range(min(args.warmup, 1)):
             run_chunk(my_chunks[0] if my_chunks else 0)
+        eng.profile_enable(True)
+        eng.profile_reset()
         barrier()
         t0 = time.perf_counter()
         parts, n_windows, n_bp = [], 0, 0
@@ -351,7 +434,18 @@ def main():
         barrier()
         dt = max_over_ranks(time.perf_counter() - t0)
         tot = comm.allgather_i64([n_bp]).sum()
+        front_ms, front_launches = eng.profile_get(_lib.K_F32_FRONT if args.precision == "f32" else _lib.K_FUSED)
+        back_ms, _ = eng.profile_get(_lib.K_BACKEND)
+        eng.profile_enable(False)
         if rank == 0:
+            extra = {}
+            if front_launches and args.precision != "f32":
+                extra["roofline"] = front_roofline(args.precision, n_windows / front_launches, front_ms / front_launches, front_launches,
+                                                   front_ms, back_ms)
+                extra["roofline"]["launch_note"] = (f"rank 0: {n_windows} windows in {front_launches} launches of the fused front end (a chunk's windows "
+                                                    f"in launches of at most {args.chunk}); achieved = mean over those launches")
+            if cpu_base is not None:
+                extra["cpu_baseline"] = cpu_base
             print(json.dumps({
                 "metric": "6 kbp windows classified/sec", "value": round(total_windows / dt, 1),
                 "unit": "windows/s", "n_gpus": world, "steps": len(my_chunks), "warmup": min(args.warmup, 1),
@@ -367,7 +461,7 @@ def main():
                                        f"{'' if args.gbp_total and args.gbp_total >= 60 else ' at reduced size'}); "
                                        f"5 kernels per {args.chunk}-window launch, launch overhead < 0.1 %, no hipGraph",
                            "precision": args.precision, "contigs": int(len(preds)),
-                           "mean_contig_score": [round(float(x), 6) for x in preds.mean(axis=0)]}}))
+                           "mean_contig_score": [round(float(x), 6) for x in preds.mean(axis=0)]}, **extra}))
         comm.close()
         return
 
@@ -391,19 +485,27 @@ def main():
     eng.sync()
 
     classify_step = eng.classify_dev_async if args.async_steps else eng.classify_dev
+    # Launch shape.  A rank's steps are contiguous in its shard, so with several ranks in strong mode (a step =
+    # 65536 / N windows per rank: 8192 at N = 8, half the tuned launch of 16384) consecutive steps are handed to the library together,
+    # `group` at a time, and it cuts them into launches of --chunk windows as it does with a 65536-window step at N = 1.  All K steps
+    # of the job are classified inside the timed region either way; --no-coalesce launches every step on its own.
+    group = 1 if (args.no_coalesce or wps_local >= args.chunk or wps_local == 0) else max(1, args.chunk // wps_local)
 
-    def step(k):
-        classify_step(bases.ptr + k * wps_local * 6000, wps_local, scores.ptr + k * wps_local * 12, args.precision)
+    def step(k, g=1):
+        classify_step(bases.ptr + k * wps_local * 6000, g * wps_local, scores.ptr + k * wps_local * 12, args.precision)
 
-    for i in range(args.warmup):
-        step(i % K)
+    def all_steps():
+        for k in range(0, K, group):
+            step(k, min(group, K - k))
+
+    for i in range(0, args.warmup, group):
+        step((i % K) if (i % K) + group <= K else 0, min(group, K))
     eng.profile_enable(True)
     eng.profile_reset()
     sampler = PowerSampler(local_rank) if args.power else None
     barrier()
     t0 = time.perf_counter()
-    for k in range(K):
-        step(k)
+    all_steps()
     eng.flush()
     eng.sync()
     t_own = time.perf_counter() - t0             # this rank's own K steps (reported per rank; `value` uses the max below)
@@ -510,36 +612,17 @@ def main():
                                    f"= {n_local} per GPU, synthetic weights of the reference shapes, HBM-resident input, "
                                    f"scores gathered to rank 0 with one ncclGather over {int(rccl_ranks.value)} RCCL rank(s) and "
                                    f"copied to its host (BASELINE.json configs[2]/[3]); 5 kernels per "
-                                   f"{min(args.chunk, wps_local)}-window launch, launch overhead < 0.1 %, no hipGraph",
-                       "precision": args.precision, "windows_per_launch": min(args.chunk, wps_local),
+                                   f"{min(args.chunk, group * wps_local)}-window launch, launch overhead < 0.1 %, no hipGraph"
+                                   + (f"; a rank's consecutive steps are handed to the library {group} at a time (one launch shape at every N)" if group > 1 else ""),
+                       "precision": args.precision, "windows_per_launch": min(args.chunk, group * wps_local), "steps_per_call": group,
                        "entry_point": "gnn_classify_dev_async" if args.async_steps else "gnn_classify_dev",
                        "device": info["name"].strip(), "cus": info["cus"]},
         }
         win_per_launch = n_local / max(front_launches, 1)
         avg_ms = front_ms / max(front_launches, 1)
         tflops = FLOP_PER_WINDOW * win_per_launch / (avg_ms * 1e-3) / 1e12 if avg_ms > 0 else 0.0
-        traffic, traffic_source = None, None
-        tpath = os.path.join(ROOT, "profiles", "hbm_traffic.json")
-        if os.path.exists(tpath):
-            tj = json.load(open(tpath))
-            per_window = tj.get("bytes_per_window", {}).get(args.precision)
-            if per_window is not None:
-                traffic = int(per_window * win_per_launch)
-                traffic_source = ("NOT measured by this run: 2*FETCH_SIZE + WRITE_SIZE per window from separate rocprofv3 "
-                                  "--pmc passes of this command (" + tj.get("source", "profiles/README.md") + "), "
-                                  "scaled to this run's windows per launch")
         passes = MFMA_PASSES.get(args.precision)
-        out["roofline"] = {
-            "bound": "mfma", "achieved": round(tflops, 2), "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-            "frac": round(tflops / MFMA_PEAK_TFLOPS, 4), "traffic": traffic, "traffic_source": traffic_source,
-            "algorithmic_bytes_per_launch": int(6012 * win_per_launch),
-            "kernel": FRONT_KERNEL[args.precision],
-            "flop_per_launch": int(FLOP_PER_WINDOW * win_per_launch), "avg_launch_ms": round(avg_ms, 4),
-            "launches": int(front_launches), "mfma_passes": passes,
-            "note": "achieved counts ALGORITHMIC flops (2.763 GFLOP/window) against the dense 16-bit MFMA peak; the "
-                    "1e-4 tolerance needs more than one 16-bit pass per product (profiles/history/r02_precision_study.json): "
-                    "mfma_passes bf16-pass equivalents are issued, which caps frac at 1/mfma_passes",
-            "backend_ms_total": round(back_ms, 2), "front_ms_total": round(front_ms, 2)}
+        out["roofline"] = front_roofline(args.precision, win_per_launch, avg_ms, front_launches, front_ms, back_ms)
         if args.precision != "f32":
             # context for `frac`: what this power-managed chip sustains on the bf16 MFMA with nothing else running
             # (outside the timed region, ~200 ms)
@@ -566,6 +649,8 @@ def main():
                 out["roofline"]["frac_ceiling_at_power_floor"] = round(same.value / passes / MFMA_PEAK_TFLOPS, 4)
         # parity of what was just timed: every window against the exact-f32 device path (above), and the first windows of
         # the job against the committed outputs of the reference's own graph (tests/golden/config2_golden.npz, windows 0..9999)
+        if not args.no_encoder and os.environ.get("GENOMAD_AMD_BENCH_FAKE_ENGINE") != "1":
+            out["encoder"] = encoder_block(eng, rank)
         if fast is not None:
             out["fast_mode"] = fast
         if watts:
@@ -590,6 +675,8 @@ def main():
             out["cpu_baseline"] = cpu_base
             if args.scaling == "strong" or world == 1:      # host_scores[:sample] are the job's first windows = the CPU sample
                 out["max_abs_dscore_vs_cpu_baseline"] = float(np.abs(host_scores[:args.cpu_sample] - cpu_scores).max())
+        if args.dump_scores:
+            np.save(args.dump_scores, host_scores)
         if os.environ.get("GENOMAD_AMD_BENCH_FAKE_ENGINE") == "1":
             out["fake_engine"] = True
             out["data"] = "FAKE ENGINE on the CPU (tests/fake_engine.py): a test of this file's multi-rank plumbing, not a measurement"

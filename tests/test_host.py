@@ -1233,3 +1233,28 @@ def test_sentinel_failure_on_one_rank_stops_every_rank(tmp_path):
             assert p.exitcode == 0
         assert [g[1] for g in got] == want
         assert (out / "m_nn_classification" / "m_nn_classification.npz").exists() == (bad_rank < 0)
+
+
+def test_bench_strong_scaling_keeps_the_tuned_launch_shape_at_every_n():
+    """at N ranks a step of the job is 65536 / N windows per rank (8192 at N = 8), half the tuned launch.  bench.py
+    hands a rank's consecutive steps to the library together so that it launches --chunk windows at every N; the job (K steps), the
+    shards and the scores are the same with and without it.  Scaled down 16x over the fake engine: 4096-window steps, chunk 1024."""
+    import subprocess
+    root = Path(__file__).resolve().parents[1]
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT")}
+    env["GENOMAD_AMD_BENCH_FAKE_ENGINE"] = "1"
+    env["OPENBLAS_NUM_THREADS"] = "2"
+    got = {}
+    for name, extra in (("n8", ["--gpus", "8"]), ("n8_single", ["--gpus", "8", "--no-coalesce"]), ("n1", ["--gpus", "1"])):
+        r = subprocess.run([sys.executable, str(root / "bench.py"), "--steps", "8", "--warmup", "3", "--windows-per-step", "4096", "--chunk", "1024",
+                            "--cpu-sample", "0"] + extra, env=env, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        got[name] = [json.loads(x) for x in r.stdout.splitlines() if x.startswith("{")][0]
+    n8, single, n1 = got["n8"], got["n8_single"], got["n1"]
+    assert n8["config"]["windows_per_launch"] == 1024 and n8["config"]["steps_per_call"] == 2          # 2 steps of 512 = one launch of --chunk
+    assert n8["roofline"]["launches"] == 4 and n8["roofline"]["flop_per_launch"] == 1024 * 2_762_901_136
+    assert single["config"]["windows_per_launch"] == 512 and single["config"]["steps_per_call"] == 1 and single["roofline"]["launches"] == 8
+    assert n1["config"]["windows_per_launch"] == 1024 and n1["config"]["steps_per_call"] == 1 and n1["roofline"]["launches"] == 32
+    for o in (n8, single, n1):
+        assert o["steps"] == 8 and o["parity"]["windows"] == 8 * 4096 and o["steps_verified"]["mismatching_windows_all_ranks"] == 0
+        assert o["max_abs_dscore"] == 0.0 and "failed" not in o
