@@ -145,7 +145,8 @@ __device__ __forceinline__ void load_xu(XU& f, const unsigned char* __restrict__
         f.l[mb] = *reinterpret_cast<const uint4*>(xh + OFF + LOX + mb * 32 * ROWX);
     }
 }
-template <bool LX, int OFFN>
+// DROPWL (pricing probe -DTC_WVA_DROP, round 5; changes results): the tile without its x_hi * w_lo product = w_v rounded to ONE f16 limb
+template <bool LX, int OFFN, bool DROPWL = false>
 __device__ __forceinline__ void wv_unit(const WU& wc, WU& wl, bool lw, const XU& xc, XU& xl, const unsigned char* __restrict__ xh, wrsrc_t wr,
                                         int wnext, uint32_t l16, f32x16 (&acc)[NMB]) {
     if constexpr (LX) load_xu<OFFN>(xl, xh);
@@ -153,17 +154,17 @@ __device__ __forceinline__ void wv_unit(const WU& wc, WU& wl, bool lw, const XU&
 #pragma unroll
     for (int mb = 0; mb < NMB; ++mb) {
         if (mb % 2 == 0) {
-            acc[mb] = mma(xc.h[mb], wc.l, acc[mb]);
+            if constexpr (!DROPWL) acc[mb] = mma(xc.h[mb], wc.l, acc[mb]);
             acc[mb] = mma(xc.h[mb], wc.h, acc[mb]);
             acc[mb] = mma(xc.l[mb], wc.h, acc[mb]);
         } else {
             acc[mb] = mma(xc.l[mb], wc.h, acc[mb]);
             acc[mb] = mma(xc.h[mb], wc.h, acc[mb]);
-            acc[mb] = mma(xc.h[mb], wc.l, acc[mb]);
+            if constexpr (!DROPWL) acc[mb] = mma(xc.h[mb], wc.l, acc[mb]);
         }
     }
 #pragma unroll
-    for (int i = 0; i < 3 * NMB; ++i) {
+    for (int i = 0; i < (DROPWL ? 2 : 3) * NMB; ++i) {
         __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
         if (LX && i < 2 * NMB) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
         if (i == 1 || i == 5) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
@@ -172,6 +173,7 @@ __device__ __forceinline__ void wv_unit(const WU& wc, WU& wl, bool lw, const XU&
 }
 // D = X W over the 96 rows that start at buffer row CARRY of `xoff`: a lane ends up with 16 rows of one channel per row block.
 // The ring's first RINGV - 1 units were requested by prime_wv.
+template <bool DROPWL = false>
 __device__ __forceinline__ void wv_tile(const unsigned char* __restrict__ smem, int xoff, wrsrc_t wr, int woff, WU (&ring)[RINGT],
                                         f32x16 (&acc)[NMB], int lane) {
 #ifdef TC_ABL_NOWV
@@ -189,9 +191,9 @@ __device__ __forceinline__ void wv_tile(const unsigned char* __restrict__ smem, 
         constexpr int OFFN = kn * 32;
         constexpr bool LX = kn < 8, LW = k + RINGV - 1 < 8;
         if constexpr (k % 2 == 0)
-            wv_unit<LX, OFFN>(ring[k % RINGV], ring[(k + RINGV - 1) % RINGV], LW, xa, xb, xh, wr, woff + (k + RINGV - 1) * WUNIT_B, l16, acc);
+            wv_unit<LX, OFFN, DROPWL>(ring[k % RINGV], ring[(k + RINGV - 1) % RINGV], LW, xa, xb, xh, wr, woff + (k + RINGV - 1) * WUNIT_B, l16, acc);
         else
-            wv_unit<LX, OFFN>(ring[k % RINGV], ring[(k + RINGV - 1) % RINGV], LW, xb, xa, xh, wr, woff + (k + RINGV - 1) * WUNIT_B, l16, acc);
+            wv_unit<LX, OFFN, DROPWL>(ring[k % RINGV], ring[(k + RINGV - 1) % RINGV], LW, xb, xa, xh, wr, woff + (k + RINGV - 1) * WUNIT_B, l16, acc);
     });
 }
 __device__ __forceinline__ void prime_wv(WU (&ring)[RINGT], wrsrc_t wr, int woff, int lane) {
@@ -288,6 +290,9 @@ template <bool F16>
 __device__ __forceinline__ void split2(f32x2 v, uint32_t& hi, uint32_t& lo) {
     hi = __builtin_bit_cast(uint32_t, __builtin_convertvector(v, f16x2));
     lo = __builtin_bit_cast(uint32_t, __builtin_convertvector(f32x2{sub_f16_lo(v[0], hi), sub_f16_hi(v[1], hi)}, f16x2));
+#ifdef TC_ALO_MASK     // energy probe (round 5): the low limbs of every activation operand with mantissa bits masked off (wrong results)
+    lo &= TC_ALO_MASK;
+#endif
 }
 
 // A^T of F(3,6) (oracle/toomcook.py) on TWO neighbouring accumulator registers of the 8 points at a time, then scale, bias,
@@ -678,7 +683,11 @@ __global__ __launch_bounds__(512, 2) void fused_front_tc_kernel(Args a) {
                 for (int mb = 0; mb < NMB; ++mb)
 #pragma unroll
                     for (int r = 0; r < 16; ++r) ac[mb][r] = 0.f;
+#ifdef TC_WVA_DROP
+                wv_tile<true>(smem, CARRY * ROWX, vw[0], woff, ring, ac, lane);
+#else
                 wv_tile(smem, CARRY * ROWX, vw[0], woff, ring, ac, lane);
+#endif
                 prime_tc(ring, cw[1], woff, lane);
                 if (store) wv_pool_store(ac, yp_w[0], t0, hw, lane);
             }
@@ -970,6 +979,13 @@ int pack_fused_tc_weights(gnn_ctx* ctx, const gnn_weights* w) {
                             frag[base + (size_t)l * 8 + e] = hi;
                             frag[base + 64 * 8 + (size_t)l * 8 + e] = lo;
                         }
+        // GNN_TC_WLO_MASK=<hex> (energy probe, round 5; wrong results): mantissa bits of the weights' low limbs masked off
+        static const bool wlo_probe = debug_switch("GNN_TC_WLO_MASK");
+        if (wlo_probe) {
+            const uint16_t mask = (uint16_t)std::strtoul(std::getenv("GNN_TC_WLO_MASK"), nullptr, 16);
+            for (size_t b0 = 0; b0 < frag.size(); b0 += 2 * 64 * 8)
+                for (size_t i = 0; i < 64 * 8; ++i) frag[b0 + 64 * 8 + i] &= mask;
+        }
         void* p = nullptr;
         GNN_HIP(hipMalloc(&p, frag.size() * 2));
         ctx->owned.push_back(p);

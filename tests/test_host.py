@@ -1258,3 +1258,15 @@ def test_bench_strong_scaling_keeps_the_tuned_launch_shape_at_every_n():
     for o in (n8, single, n1):
         assert o["steps"] == 8 and o["parity"]["windows"] == 8 * 4096 and o["steps_verified"]["mismatching_windows_all_ranks"] == 0
         assert o["max_abs_dscore"] == 0.0 and "failed" not in o
+
+
+def test_hbm_traffic_json_is_a_function_of_the_committed_pmc_passes():
+    """bench.py scales `roofline.traffic` from profiles/hbm_traffic.json; the file must be reproducible, to the
+    digit, from the pmc_1.txt / pmc_2.txt summaries committed under profiles/ (scripts/hbm_traffic_json.py --check)."""
+    import subprocess
+    root = Path(__file__).resolve().parents[1]
+    r = subprocess.run([sys.executable, str(root / "scripts" / "hbm_traffic_json.py"), "--check"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout + r.stderr
+    import bench
+    per_window, source = bench.hbm_traffic("f16x3tc")
+    assert per_window > 6012 and "pmc_1.txt" in source
