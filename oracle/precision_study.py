@@ -284,6 +284,75 @@ SCHEMES += [
     ConvScheme("toomcook F(3,6) on f16x3 limbs", 3.0 * 8 / 18, _tc_conv(3), "points 0, +-1, +-2, +-1/2, inf"),
     ConvScheme("toomcook F(4,6) on f16x3 limbs", 3.0 * 9 / 24, _tc_conv(4), "points 0, +-1, +-2, +-1/2, 1/4, inf"),
 ]
+
+
+# ------------------------------------------------------------------ f16 hi*hi + int8 cross terms
+# "one arithmetic not in this study": the hi*hi product on the f16 MFMA, BOTH cross products on v_mfma_i32_32x32x32_i8 (twice the
+# f16 rate) with block-scaled int8 images: 1 + 2 x 0.5 = 2.0 pass equivalents per product instead of 3.0.  conv2 / conv3 in the
+# Toom-Cook domain (scales per (point, tile) and per (point, output channel): no conv taps to mix, K = 128), y @ w_v direct with
+# scales per row and per column.  What the LDS would hold for the pair products: the f16 hi + lo limbs as today.
+def _i8_x(x):
+    from oracle import toomcook
+    x = np.asarray(x, np.float64)
+    hi = rnd(x, "fp16")
+    q, a = toomcook.q8_rows(x, axis=-1)
+    ql, _ = toomcook.q8_rows(x - hi, axis=-1, tied_to=a)
+    return [hi, q * a, ql * a * 2.0 ** -11, rnd(x - hi, "fp16")]
+
+
+def _i8_w(w):
+    from oracle import toomcook
+    w = np.asarray(w, np.float64)
+    hi = rnd(w, "fp16")
+    q, b = toomcook.q8_rows(w, axis=0)
+    ql, _ = toomcook.q8_rows(w - hi, axis=0, tied_to=b)
+    return [hi, q * b, ql * b * 2.0 ** -11]
+
+
+class ConvSchemeI8(Scheme):
+    def __init__(self, name, cost, conv_fn, note=""):
+        super().__init__(name, cost, _i8_x, _i8_w, [(0, 0), (1, 2), (2, 1)], note, stored=lambda l: l[0] + l[3])
+        self.conv_fn = conv_fn
+
+
+def _tc_conv_i8(m):
+    from oracle import toomcook
+    packs = {}
+
+    def fn(x, kernel, bias, key):
+        if key not in packs:
+            packs[key] = toomcook.pack_weights(kernel, m)
+        return toomcook.conv_emulated_i8cross(x, packs[key], bias, stats=TC_STATS.setdefault(f"F({m},6) i8 cross", {}))
+    return fn
+
+
+SCHEMES += [
+    ConvSchemeI8("toomcook F(3,6): f16 hi*hi + int8 x int8 cross terms (block scaled); w_v the same, direct", 2.0 * (0.8535 * 8 / 18 + 0.1465) / (0.8535 * 8 / 18 + 0.1465) * 1.0,
+                 _tc_conv_i8(3), "2.0 pass equivalents per product; needs a second (i32) accumulator set beside Toom-Cook's 128 f32 registers"),
+]
+
+
+# ------------------------------------------------------------------ shorter low limbs (round 5 energy probe: MFMA power depends on the operand bits)
+def _masked_split(bits):
+    from oracle import toomcook
+    return lambda v: [rnd(v, "fp16"), toomcook.mask16(rnd(np.asarray(v, np.float64) - rnd(v, "fp16"), "fp16"), bits)]
+
+
+class ConvSchemeMasked(Scheme):
+    def __init__(self, bits):
+        super().__init__(f"toomcook F(3,6) on f16x3 limbs, low limbs cut by {bits} mantissa bits (weights and activations, w_v too)", 3.0 * 8 / 18,
+                         _masked_split(bits), _masked_split(bits), [HH, HL, LH], "energy probe: same MFMAs, fewer operand bits toggling")
+        from oracle import toomcook
+        packs = {}
+
+        def fn(x, kernel, bias, key):
+            if key not in packs:
+                packs[key] = toomcook.pack_weights(kernel, 3)
+            return toomcook.conv_emulated(x, packs[key], bias, lo_mask_bits=bits)
+        self.conv_fn = fn
+
+
+SCHEMES += [ConvSchemeMasked(b) for b in (3, 4, 5, 6)]
 BY_NAME = {s.name: s for s in SCHEMES}
 EXACT = SCHEMES[0]
 

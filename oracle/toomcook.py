@@ -98,7 +98,15 @@ def pack_weights(kernel, m: int, points=None, prescale=True):
             "max_U": np.abs(U).max(axis=(1, 2)), "m": m, "n": n}
 
 
-def conv_emulated(x, pk, bias, kunit=16, stats=None):
+def mask16(lo, bits):
+    """f16 low limb with its `bits` lowest mantissa bits cleared (what `lo & mask` does to the f16 word: truncation towards zero)."""
+    if not bits:
+        return lo
+    h = np.asarray(lo, np.float64).astype(np.float16)
+    return (h.view(np.uint16) & np.uint16((0xFFFF << bits) & 0xFFFF)).view(np.float16).astype(np.float64)
+
+
+def conv_emulated(x, pk, bias, kunit=16, stats=None, lo_mask_bits=0):
     """Causal conv of x (B, T, C) (f32-representable values) with packed weights `pk`, emulating the kernel:
 
       * B^T d in f32 (every operation rounded to f32), V split into f16 hi / lo;
@@ -125,6 +133,7 @@ def conv_emulated(x, pk, bias, kunit=16, stats=None):
         V.append(acc)
     V = np.stack(V)                                                  # (n, B, nt, C)
     Vh, Vl = split16(V)
+    Vl, Ulo = mask16(Vl, lo_mask_bits), mask16(pk["U_lo"], lo_mask_bits)       # round 5 energy probe: shorter low limbs
     if stats is not None:
         stats["max_V"] = max(stats.get("max_V", 0.0), float(np.abs(V).max()))
     Vh, Vl = Vh.reshape(n, B * nt, C), Vl.reshape(n, B * nt, C)
@@ -132,7 +141,7 @@ def conv_emulated(x, pk, bias, kunit=16, stats=None):
     M = np.zeros((n, B * nt, N))
     for u in range(0, C, kunit):
         sl = slice(u, u + kunit)
-        for a, w in ((Vh, pk["U_lo"]), (Vh, pk["U_hi"]), (Vl, pk["U_hi"])):
+        for a, w in ((Vh, Ulo), (Vh, pk["U_hi"]), (Vl, pk["U_hi"])):
             M = _f32(M + np.matmul(a[:, :, sl], w[:, sl, :]))
     if stats is not None:
         stats["max_M"] = max(stats.get("max_M", 0.0), float(np.abs(M).max()))
@@ -167,3 +176,73 @@ def conv_direct_x3(x, kernel, bias, kunit=16):
             for a, w in ((xh, wl), (xh, wh), (xl, wh)):
                 acc = _f32(acc + np.matmul(a[:, k:k + T, sl], w[k, sl, :]))
     return acc
+
+
+# ------------------------------------------------------------------ f16 hi*hi + int8 cross terms (emulation only)
+def q8_rows(v, axis, tied_to=None):
+    """Block-scaled int8 image of v: integers in [-127, 127] times a scale shared along `axis` (the MFMA's K axis: an i32
+    accumulator cannot mix scales inside one dot product).  tied_to = the scale array of the operand's HIGH part: the image of a
+    residual then uses that scale * 2^-11, so that x8 * wl8 and xl8 * w8 share ONE product scale and ONE i32 accumulator."""
+    v = np.asarray(v, np.float64)
+    if tied_to is None:
+        amax = np.abs(v).max(axis=axis, keepdims=True)
+        scale = np.where(amax > 0, amax, 1.0) / 127.0
+    else:
+        scale = tied_to * 2.0 ** -11
+    q = np.clip(np.rint(v / scale), -127, 127)
+    return q, scale
+
+
+def conv_emulated_i8cross(x, pk, bias, kunit=16, stats=None):
+    """conv_emulated with the two CROSS products (V_hi U_lo + V_lo U_hi) replaced by int8 MFMAs: v_mfma_i32_32x32x32_i8 runs at
+    twice the f16 rate, so the arithmetic costs 1 + 2 x 0.5 = 2.0 pass equivalents instead of 3.0.  V is quantised per (point,
+    tile) over its 128 channels, U per (point, output channel) over its 128 input channels; the residual images use the tied
+    scales of q8_rows, the integer dot products over K = 128 are exact (|sum| < 2^22), one f32 multiply by the product scale and one
+    f32 add bring them into the f32 accumulator of the hi*hi MFMAs."""
+    m, n = pk["m"], pk["n"]
+    B, T, C = x.shape
+    nt = -(-T // m)
+    xp = np.zeros((B, (nt - 1) * m + n, C))
+    xp[:, R - 1:R - 1 + T] = x
+    d = [xp[:, j:j + (nt - 1) * m + 1:m] for j in range(n)]
+    bt = pk["bt"]
+    V = []
+    for xi in range(n):
+        acc = None
+        for j in range(n):
+            c = bt[xi, j]
+            if c == 0:
+                continue
+            term = _f32(c * d[j])
+            acc = term if acc is None else _f32(acc + term)
+        V.append(acc)
+    V = np.stack(V).reshape(n, B * nt, C)
+    Vh = _f16(V)
+    Us = pk["U_hi"] + pk["U_lo"]                  # s U to 22 bits: what the packer holds before it chooses the limb formats
+    Uh = pk["U_hi"]
+    qV, aV = q8_rows(V, axis=2)                   # (n, tiles, C), scale (n, tiles, 1)
+    qVl, _ = q8_rows(V - Vh, axis=2, tied_to=aV)
+    qU, bU = q8_rows(Us, axis=1)                  # (n, C, N), scale (n, 1, N)
+    qUl, _ = q8_rows(Us - Uh, axis=1, tied_to=bU)
+    N = Uh.shape[2]
+    M = np.zeros((n, B * nt, N))
+    for u in range(0, C, kunit):
+        sl = slice(u, u + kunit)
+        M = _f32(M + np.matmul(Vh[:, :, sl], Uh[:, sl, :]))
+    cross = np.matmul(qV, qUl) + np.matmul(qVl, qU)                       # exact integers
+    M = _f32(M + _f32(cross * _f32(aV * bU * 2.0 ** -11)))
+    if stats is not None:
+        stats["max_abs_i32"] = max(stats.get("max_abs_i32", 0.0), float(np.abs(cross).max()))
+    at = pk["at"]
+    y = np.zeros((B, nt * m, N))
+    Mr = M.reshape(n, B, nt, N)
+    for i in range(m):
+        acc = None
+        for xi in range(n):
+            c = at[i, xi]
+            if c == 0:
+                continue
+            term = _f32(c * Mr[xi])
+            acc = term if acc is None else _f32(acc + term)
+        y[:, i::m] = acc
+    return _f32(y[:, :T] + bias)

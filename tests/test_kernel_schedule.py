@@ -181,3 +181,44 @@ def test_toomcook_model_notices_a_dropped_barrier_and_a_ring_overrun():
     assert any("ring" in msg for _, msg in check(list(tc_schedule(3, ahead=3))))
     # one chunk ahead is too little: the matrix waves fetch the first fragment of chunk c + 1 while they finish chunk c
     assert any("ring" in msg for _, msg in check(list(tc_schedule(3, ahead=1))))
+
+
+# ------------------------------------------------------------------ the model against the source: barrier count and order parsed from the .hip
+def _tc_source():
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    return open(os.path.join(root, "genomad_amd", "csrc", "gnn_fused_tc.hip")).read()
+
+
+def _loop_body(src, start):
+    """text of the `for (int step = ...) {` loop that starts at or after `start` (brace matched)"""
+    i = src.index("for (int step = s_begin; step < s_hi; ++step) {", start)
+    depth, j = 0, src.index("{", i)
+    while True:
+        depth += {"{": 1, "}": -1}.get(src[j], 0)
+        if depth == 0:
+            return src[i:j + 1], j
+        j += 1
+
+
+def test_toomcook_model_has_the_barriers_the_source_has():
+    """The hand-written model above can drift from the kernel.  This parses gnn_fused_tc.hip: both roles of a workgroup must pass the
+    same number of workgroup barriers per step, that number must be the number of phases the model yields per step, and the helpers'
+    barriers must come in the order the model assumes (b_0 .. b_7, B1, b'_0 .. b'_7, B0 - the labels in the source's comments)."""
+    import re
+    src = _tc_source()
+    matrix, end = _loop_body(src, src.index("if (!helper) {"))
+    helper, _ = _loop_body(src, end)
+    # matrix waves: two conv loops (each: one barrier in front of unit 0 + one per further unit) + B1 + B0
+    conv = src[src.index("__device__ __forceinline__ void conv_tc("):src.index("template <bool F16>")]
+    assert len(re.findall(r"\bTC_BARRIER\(\);", conv)) == 2 and "k % 8 == 0 && k > 0" in conv and "make_integer_sequence<int, 64>" in conv
+    per_conv = 1 + (64 // 8 - 1)
+    n_matrix = matrix.count("conv_tc(") * per_conv + len(re.findall(r"\bTC_BARRIER_W\(\);", matrix)) + len(re.findall(r"\bTC_BARRIER\(\);", matrix))
+    assert matrix.count("conv_tc(") == 2
+    # helper waves: every barrier is an HBAR / HBAR_W macro call with its label in the trailing comment
+    calls = re.findall(r"\bHBAR(?:_W)?\(\d+, \d+\);\s*//\s*(?:-+\s*)?([bB]'?_?\d)", helper)
+    assert len(re.findall(r"\bHBAR(?:_W)?\(", helper)) == len(calls), "a helper barrier without a label comment"
+    want = [f"b_{c}" for c in range(8)] + ["B1"] + [f"b'_{c}" for c in range(8)] + ["B0"]
+    assert calls == want, calls
+    per_step_model = len(list(tc_schedule(2))) - len(list(tc_schedule(1)))
+    assert n_matrix == len(calls) == per_step_model == 18
