@@ -96,6 +96,7 @@ SIGNATURES = {
     "gnn_crc32c": (C.c_uint32, [_vp, _sz]),
     "gnn_fasta_scan": (_int, [_vp, _i64, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_int)]),
     "gnn_fasta_pack": (_int, [_vp, _i64, _int, _vp, _vp, _vp, _vp, _i64, C.POINTER(C.c_int64)]),
+    "gnn_fasta_accession_digests": (_int, [_vp, _i64, _vp, _i64, C.POINTER(C.c_int64), C.POINTER(C.c_int)]),
     "gnn_comm_unique_id": (_int, [_vp]),
     "gnn_comm_init": (_int, [_vp, _int, _int, _vp]),
     "gnn_comm_destroy": (_int, [_vp]),

@@ -102,3 +102,69 @@ extern "C" int gnn_fasta_pack(const uint8_t* text, int64_t n, int strip_n, uint8
     *n_records = nrec;
     return GNN_OK;
 }
+
+// 64-bit digests of the ACCESSIONS (header.split()[0], genomad/sequence.py:24-25) of every record with a non-empty raw sequence -
+// what the reference's check_fasta counts (sequence.py:124-131) - in ONE pass over the text, for the sharded validation of
+// genomad_amd/sharding.py (the Python side used to scan the text twice and decode + hash every header in a loop).
+// The accession is the first run of bytes outside Python's ASCII whitespace (\t \n \v \f \r, 0x1c-0x1f, space).  Python's
+// str.split() also splits at non-ASCII white space (U+0085, U+00A0, U+2028 ...), all of which are encoded with bytes >= 0x80: a
+// header with such a byte before the end of its first token - or an empty accession, on which the reference raises - sets
+// *needs_python, and the caller recomputes THAT piece with the Python mirror of this hash (genomad_amd/sequence.py).
+// digest = FNV-1a 64 of the accession bytes, finished with the splitmix64 mixer.
+static inline bool py_ascii_space(uint8_t b) { return (b >= 0x09 && b <= 0x0d) || (b >= 0x1c && b <= 0x20); }
+
+extern "C" int gnn_fasta_accession_digests(const uint8_t* text, int64_t n, uint64_t* digests, int64_t capacity, int64_t* n_records,
+                                           int* needs_python) {
+    if ((!text && n > 0) || n < 0 || (!digests && capacity > 0) || capacity < 0 || !n_records || !needs_python) {
+        set_error("bad argument to gnn_fasta_accession_digests");
+        return GNN_ERR_ARG;
+    }
+    int64_t p = 0, nrec = 0, seq_len = 0;
+    bool in_rec = false, odd = false;
+    uint64_t cur = 0;
+    auto finish = [&]() -> bool {
+        if (in_rec && seq_len > 0) {
+            if (nrec >= capacity) return false;
+            digests[nrec++] = cur;
+        }
+        return true;
+    };
+    while (p < n) {
+        const uint8_t* q = static_cast<const uint8_t*>(memchr(text + p, '\n', (size_t)(n - p)));
+        const int64_t le = q ? q - text : n;
+        if (text[p] == '>') {
+            if (!finish()) {
+                set_error("gnn_fasta_accession_digests: more records than capacity (size it with gnn_fasta_scan)");
+                return GNN_ERR_ARG;
+            }
+            in_rec = true;
+            seq_len = 0;
+            int64_t a = p + 1;
+            while (a < le && py_ascii_space(text[a])) ++a;
+            int64_t b = a;
+            uint64_t h = 0xcbf29ce484222325ull;
+            while (b < le && !py_ascii_space(text[b])) {
+                odd |= text[b] >= 0x80;
+                h = (h ^ text[b]) * 0x100000001b3ull;
+                ++b;
+            }
+            odd |= b == a;
+            h ^= h >> 30;
+            h *= 0xbf58476d1ce4e5b9ull;
+            h ^= h >> 27;
+            h *= 0x94d049bb133111ebull;
+            h ^= h >> 31;
+            cur = h;
+        } else if (in_rec) {
+            seq_len += le - p;
+        }
+        p = le + 1;
+    }
+    if (!finish()) {
+        set_error("gnn_fasta_accession_digests: more records than capacity (size it with gnn_fasta_scan)");
+        return GNN_ERR_ARG;
+    }
+    *n_records = nrec;
+    *needs_python = odd ? 1 : 0;
+    return GNN_OK;
+}

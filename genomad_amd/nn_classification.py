@@ -555,11 +555,11 @@ def main(input_path, output_path, single_window, batch_size, restart, threads, v
                 return classify_contigs_safely(eng, sq, off, single_window, precision, console)
 
             validate = sharded_check and fasta is input_path        # the provirus FASTA is geNomad's own output: never validated
-            seen = []                                               # accessions of ALL records of this rank's share (validate)
+            seen = []                                               # digests of the accessions of ALL records of this rank's share (validate)
 
             def pack(text):
-                if validate:
-                    seen.extend(sequence.index_accessions(text))    # before the in-place pack consumes the text
+                if validate:                                        # one native pass, before the in-place pack consumes the text
+                    seen.append(sequence.accession_digests_of_text(text))
                 return sequence.pack_text(text, strip_n=True)
 
             if sequence.compression_of(fasta) == "uncompressed":
@@ -587,7 +587,8 @@ def main(input_path, output_path, single_window, batch_size, restart, threads, v
                     pr, wid = classify(sq, off)
                     parts.append((i, nm, pr, wid))
             if validate:
-                state["verdict"] = sharding.fasta_verdict(comm, seen, lambda: sequence.check_fasta(input_path))
+                digests = np.concatenate(seen) if seen else np.zeros(0, dtype="<u8")
+                state["verdict"] = sharding.fasta_verdict(comm, digests, lambda: sequence.check_fasta(input_path))
             sentinel_verdict(comm, sentinel["d"], console, precision)      # before anything is written
             names, predictions, ids, n_windows = sharding.gather_contig_parts(comm, parts)
             gate()

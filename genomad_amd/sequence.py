@@ -297,6 +297,37 @@ def index_accessions(text: np.ndarray):
     return acc
 
 
+def _digest_of_accession(acc: str) -> int:
+    """Python mirror of gnn_fasta_accession_digests' hash (FNV-1a 64 of the accession's bytes + the splitmix64 mixer)."""
+    h, m = 0xcbf29ce484222325, (1 << 64) - 1
+    for b in acc.encode("utf-8", "surrogateescape"):
+        h = ((h ^ b) * 0x100000001b3) & m
+    h ^= h >> 30
+    h = (h * 0xbf58476d1ce4e5b9) & m
+    h ^= h >> 27
+    h = (h * 0x94d049bb133111eb) & m
+    return h ^ (h >> 31)
+
+
+def accession_digests_of_text(text: np.ndarray) -> np.ndarray:
+    """uint64 digests of the accessions of ALL records of a text array with a non-empty raw sequence (what check_fasta counts,
+    genomad/sequence.py:124-131), without consuming it: one native pass (``gnn_fasta_accession_digests``).  A text with a
+    non-ASCII byte inside a first header token (Python's ``split()`` knows non-ASCII white space) takes the Python route -
+    the same digests, computed from :func:`index_accessions`."""
+    import ctypes as C
+    from . import _lib
+    lib = _lib.load()
+    nh, hb, cr = C.c_int64(), C.c_int64(), C.c_int()
+    _lib.check(lib.gnn_fasta_scan(text.ctypes.data, len(text), C.byref(nh), C.byref(hb), C.byref(cr)))
+    if not cr.value:
+        out = np.empty(max(nh.value, 1), dtype="<u8")
+        nrec, odd = C.c_int64(), C.c_int()
+        _lib.check(lib.gnn_fasta_accession_digests(text.ctypes.data, len(text), out.ctypes.data, nh.value, C.byref(nrec), C.byref(odd)))
+        if not odd.value:
+            return out[:nrec.value].copy()
+    return np.array([_digest_of_accession(a) for a in index_accessions(text)], dtype="<u8")
+
+
 def pack_text(text: np.ndarray, strip_n: bool = True):
     """(names, seq, offsets) of the records in a writable text array (consumed: packed in place)."""
     names, seq, offsets = _pack(text, strip_n)

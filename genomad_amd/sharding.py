@@ -170,30 +170,33 @@ def broadcast_flags(comm, flags, root: int = 0):
 
 
 def accession_digests(accessions) -> np.ndarray:
-    """64-bit digests (blake2b) of record accessions, as a uint64 array: what travels instead of the strings."""
-    import hashlib
-    out = np.empty(len(accessions), dtype="<u8")
-    for i, a in enumerate(accessions):
-        out[i] = int.from_bytes(hashlib.blake2b(a.encode("utf-8", "surrogateescape"), digest_size=8).digest(), "little")
-    return out
+    """64-bit digests of record accessions, as a uint64 array: what travels instead of the strings (the same function as the
+    native one-pass :func:`genomad_amd.sequence.accession_digests_of_text`)."""
+    from .sequence import _digest_of_accession
+    return np.array([_digest_of_accession(a) for a in accessions], dtype="<u8")
 
 
 def fasta_verdict(comm, accessions, exact_check, root: int = 0) -> bool:
     """check_fasta (genomad/sequence.py:124-131: False for a file without records or with two records of one accession) when
     every rank has seen only ITS records: ``accessions`` = the accessions of all records of this rank's share of the file (no N
-    stripping: records that the classification pass drops count).  Duplicates inside a share are found locally; across shares
-    by ONE gather of 64-bit digests to ``root``.  Equal digests on different ranks are either a true duplicate or a collision
-    (about 1e-7 for a million records): ``exact_check()`` - the sequential whole-file check - decides, on ``root`` only.  Every
-    rank returns the same verdict."""
+    stripping: records that the classification pass drops count) - or, as the product path passes them, their uint64 digests
+    already (``sequence.accession_digests_of_text``).  ONE gather of 64-bit digests to ``root``; equal digests, inside a share or
+    across shares, are either a true duplicate or a collision (about 1e-7 for a million records): ``exact_check()`` - the
+    sequential whole-file check - decides, on ``root`` only.  Every rank returns the same verdict."""
     comm = comm or LocalComm()
-    acc = list(accessions)
-    local_dup = len(set(acc)) != len(acc)
-    meta = comm.allgather_i64([len(acc), int(local_dup)])
-    blobs = gather_bytes(comm, accession_digests(acc).tobytes() if not meta[:, 1].any() else b"", root)
+    if isinstance(accessions, np.ndarray) and accessions.dtype.kind == "u":
+        mine = np.ascontiguousarray(accessions, dtype="<u8")        # digests already (sequence.accession_digests_of_text: one native pass)
+    else:
+        mine = accession_digests(list(accessions))
+    local_dup = len(np.unique(mine)) != len(mine)                   # equal digests inside a share: a duplicate, or a collision
+    meta = comm.allgather_i64([len(mine), int(local_dup)])
+    blobs = gather_bytes(comm, mine.tobytes() if not meta[:, 1].any() else b"", root)
     ok = True
     if comm.rank == root:
-        if int(meta[:, 0].sum()) == 0 or meta[:, 1].any():
+        if int(meta[:, 0].sum()) == 0:
             ok = False
+        elif meta[:, 1].any():
+            ok = bool(exact_check())
         else:
             d = np.sort(np.concatenate([np.frombuffer(b, dtype="<u8") for b in blobs]))
             if len(d) > 1 and bool((d[1:] == d[:-1]).any()):

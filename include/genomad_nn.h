@@ -243,6 +243,13 @@ int gnn_classify_contigs(gnn_ctx* ctx, const uint8_t* seq, int seq_on_host, int6
 int gnn_fasta_scan(const uint8_t* text, int64_t n, int64_t* n_headers, int64_t* header_bytes, int* has_cr);
 int gnn_fasta_pack(const uint8_t* text, int64_t n, int strip_n, uint8_t* seq_out, int64_t* offsets,
                    uint8_t* headers_out, int64_t* header_offsets, int64_t capacity, int64_t* n_records);
+/* replaces, for a multi-rank run, the accession bookkeeping of sequence.check_fasta (genomad/sequence.py:124-131: no record /
+ * two records with one accession = header.split()[0], sequence.py:24-25): 64-bit digests of the accessions of every record of
+ * `text` whose raw sequence is non-empty, in file order, in ONE pass (capacity from gnn_fasta_scan).  *needs_python = 1 when a
+ * header has a byte >= 0x80 before the end of its first token (Python's split() knows non-ASCII white space) or an empty
+ * accession: the caller then recomputes this text with the Python mirror of the hash (genomad_amd/sequence.py).  Host only. */
+int gnn_fasta_accession_digests(const uint8_t* text, int64_t n, uint64_t* digests, int64_t capacity, int64_t* n_records,
+                                int* needs_python);
 
 /* ---- downstream score consumers as a device epilogue, float64 like the
  * reference's numpy ------------------------------------------------------------------------------ */

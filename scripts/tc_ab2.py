@@ -96,12 +96,22 @@ if len(sys.argv) > 1 and sys.argv[1] == "--child":
     h.update(sc.tobytes())
     for k in ("m_a", "m_b", "yp_a", "yp_b"):
         h.update(taps[k].tobytes())
+    # per-phase cycle counters of the instrumented build of THIS library (every variant carries fused_front_tc_kernel<true>): the
+    # critical path C of a 96-row step on both roles - what the time model T ~ C^a W^(1-a) needs beside the launch time
+    import ctypes as C_
+    _lib.check(eng.lib.gnn_phase_cycles(eng.ctx, 1, None))
+    eng.classify_dev(b.ptr, 4096, s.ptr, "f16x3tc")
+    eng.sync()
+    out = (C_.c_uint64 * 16)()
+    _lib.check(eng.lib.gnn_phase_cycles(eng.ctx, 0, out))
+    per = [v / (4096 * 63) for v in out]
+    cyc = f"cycles/step matrix {sum(per[:8]):6.0f} [{' '.join(f'{v:.0f}' for v in per[:8])}] helper {sum(per[8:]):6.0f} [{' '.join(f'{v:.0f}' for v in per[8:])}]"
     w = sm.watts[len(sm.watts) // 5:] or [float("nan")]          # drop the ramp
     f = sm.mhz[len(sm.mhz) // 5:] or [float("nan")]
     wm, fm = sum(w) / len(w), sum(f) / len(f)
     wi = sum(si.watts) / len(si.watts) if si.watts else float("nan")
     print(f"{ms / l / (N // 4096):8.3f} ms/4096   {wm:7.1f} W ({len(w)} samples, idle after {wi:6.1f})  {fm:6.0f} MHz   "
-          f"{wm * (ms / l * 1e-3) / N * 1e3:6.3f} mJ/window   front/wall {ms / 1e3 / wall:5.3f}   dscore {np.abs(sc - exact).max():.2e}   bits {h.hexdigest()[:12]}")
+          f"{wm * (ms / l * 1e-3) / N * 1e3:6.3f} mJ/window   front/wall {ms / 1e3 / wall:5.3f}   dscore {np.abs(sc - exact).max():.2e}   bits {h.hexdigest()[:12]}   {cyc}")
     sys.exit(0)
 
 args = sys.argv[1:]

@@ -976,7 +976,8 @@ def _sharded_check_worker(rank, world, port, fasta, out_dir, q, collide):
     real_check = sequence.check_fasta
     sequence.check_fasta = lambda p, *a, **k: (calls.append(rank), real_check(p, *a, **k))[1]
     if collide:                                      # every accession gets the same digest: the exact check has to decide
-        sharding.accession_digests = lambda acc: np.zeros(len(acc), dtype="<u8")
+        real = sequence.accession_digests_of_text
+        sequence.accession_digests_of_text = lambda text: np.full(len(real(text)), rank, dtype="<u8")   # equal inside every share
     comm = GlooComm(rank, world, port)
     code = 0
     try:
@@ -1270,3 +1271,33 @@ def test_hbm_traffic_json_is_a_function_of_the_committed_pmc_passes():
     import bench
     per_window, source = bench.hbm_traffic("f16x3tc")
     assert per_window > 6012 and "pmc_1.txt" in source
+
+
+def test_native_accession_digests_equal_the_python_mirror():
+    """the sharded validation hashes accessions in ONE native pass (gnn_fasta_accession_digests).  Same records (every
+    record with a non-empty raw sequence, all-N ones included), same accession rule as header.split()[0] (genomad/sequence.py:24-25)
+    - and a header whose first token has a non-ASCII byte (Python knows non-ASCII white space) or a text with '\\r' takes the Python
+    route and still gives the digests the other ranks would compute natively."""
+    def arr(b):
+        return np.frombuffer(bytearray(b), dtype=np.uint8)
+
+    text = (b"junk before\n>c1 desc\nACGT\nAC\n>  lead\tx\nNNNN\n>empty_seq\n>tab\tsep\nA\n>fs\x1cx\nG\n>c1\nT\n>last")
+    want_acc = ["c1", "lead", "tab", "fs", "c1"]                    # ">empty_seq" and ">last" have no sequence: not counted (index mode)
+    assert sequence.index_accessions(arr(text)) == want_acc
+    got = sequence.accession_digests_of_text(arr(text))
+    assert got.dtype == np.dtype("<u8") and list(got) == [sequence._digest_of_accession(a) for a in want_acc]
+    assert got[0] == got[4] and len(set(got.tolist())) == 4
+    assert list(sharding.accession_digests(want_acc)) == list(got)
+    # non-ASCII white space inside the first token: Python splits there, bytes >= 0x80 send the piece down the Python route
+    nb = ">a b rest\nACGT\n>café x\nAC\n".encode()
+    assert sequence.index_accessions(arr(nb)) == ["a", "café"]
+    assert list(sequence.accession_digests_of_text(arr(nb))) == [sequence._digest_of_accession("a"), sequence._digest_of_accession("café")]
+    # universal newlines
+    cr = b">x y\r\nAC\r\n>z\rGG\r"
+    assert list(sequence.accession_digests_of_text(arr(cr))) == [sequence._digest_of_accession("x"), sequence._digest_of_accession("z")]
+    assert len(sequence.accession_digests_of_text(arr(b""))) == 0 and len(sequence.accession_digests_of_text(arr(b"no records\n"))) == 0
+    # fasta_verdict takes the digests as they are; equal digests inside a share go to the exact check
+    calls = []
+    assert sharding.fasta_verdict(None, got[:4], lambda: calls.append(1) or True) and not calls
+    assert not sharding.fasta_verdict(None, got, lambda: calls.append(1) or False) and calls == [1]
+    assert not sharding.fasta_verdict(None, got[:0], lambda: True)
