@@ -15,7 +15,11 @@
 // measured chip-wide L2 ceiling of 56 B/clk/CU (MI355X_MICROARCH.md, L2: 34.5 TB/s).  Flags switch the weight stream, the
 // LDS reads and a stand-in for the helpers' input transform (+ one workgroup barrier per k16 unit: the V ring) on and off.
 //
-// Build: hipcc --offload-arch=gfx950 -O3 -std=c++17 -o build_variants/probe_tc_loop scripts/probe_tc_loop.hip ; run on the GPU box.
+// Round 5: -DNXI=9 prices F(4,6) (9 points, 4 rows per tile, 128-row steps, 47 steps, a V ring slot of 18 KB, 144 accumulator
+// registers; -DRINGT_SLOTS=6 leaves the weight ring the 16 registers the ninth accumulator takes) with the same loops: the one design
+// candidate the round-5 time model (profiles/r05/MODEL.md) ranks above the shipped kernel.
+//
+// Build: hipcc --offload-arch=gfx950 -O3 -std=c++17 [-DNXI=9 -DRINGT_SLOTS=6] -o build_variants/probe_tc_loop scripts/probe_tc_loop.hip ; run on the GPU box.
 #include <hip/hip_runtime.h>
 
 #include <cstdio>
@@ -122,8 +126,15 @@ __device__ __forceinline__ void conv_direct(const unsigned char* smem, rsrc_t wr
 
 // ---------------------------------------------------------------- Toom-Cook form
 // V ring in LDS: slot = one k16 unit: [xi 8][hi | lo][lane 64] x 16 B = 16 KB; 3 slots.  Weights: [unit 8][xi 8][nblk 4][hi | lo] x 1 KiB.
-constexpr int RINGT = 8;                 // weight ring slots of one (unit, xi): 7 in flight ahead of the MFMAs
-constexpr int VSLOT = 16384, VRING = 3;
+#ifndef NXI
+#define NXI 8                            // transform points: 8 = F(3,6) (3 rows per tile, 96-row steps), 9 = F(4,6) (4 rows per tile, 128-row steps)
+#endif
+constexpr int TROWS = NXI - 5;           // output rows per tile
+#ifndef RINGT_SLOTS
+#define RINGT_SLOTS 8
+#endif
+constexpr int RINGT = RINGT_SLOTS;       // weight ring slots of one (unit, xi): RINGT - 1 in flight ahead of the MFMAs
+constexpr int VSLOT = NXI * 2048, VRING = 3;
 constexpr int VOFF = SMEM - VRING * VSLOT;
 struct XV {
     uint4 h, l;
@@ -157,19 +168,19 @@ __device__ __forceinline__ void xi_tc(const WU& wc, WU& wl, const XV& vc, XV& vl
 // lane): 8 input rows x 2 channels (hi | lo planes) -> f32, the 8-point transform B^T of the points {0, +-1, +-2, +-1/2, inf}
 // (26 VALU per channel), split into f16 hi | lo, 16 ds_write_b32 into the ring slot.  Same instruction mix as the real thing.
 struct HRaw {
-    uint32_t h[8], l[8];
+    uint32_t h[NXI], l[NXI];
 };
 __device__ __forceinline__ void helper_load(HRaw& r, const unsigned char* smem, int unit, int hw, int lane) {
 #ifdef HELP_NOLDS        // measurement variant: barriers only on the helper side
-    for (int j = 0; j < 8; ++j) r.h[j] = r.l[j] = (uint32_t)(unit + lane + j);
+    for (int j = 0; j < NXI; ++j) r.h[j] = r.l[j] = (uint32_t)(unit + lane + j);
     return;
 #endif
     // lane -> (tile, k half, channel pair) so that both the row reads and the fragment stores are bank-conflict free: the 4 lanes
     // of a (tile, half) cover its 8 channels = 16 consecutive bytes; a wave covers 16 (tile, half) combinations
     const int pr = lane & 3, th = hw * 16 + (lane >> 2), tile = th & 31, half = th >> 5;
-    const unsigned char* xr = smem + (3 * tile) * ROWX + (unit * 16 + half * 8 + pr * 2) * 2;
+    const unsigned char* xr = smem + (TROWS * tile) * ROWX + (unit * 16 + half * 8 + pr * 2) * 2;
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
+    for (int j = 0; j < NXI; ++j) {
         r.h[j] = *reinterpret_cast<const uint32_t*>(xr + j * ROWX);
         r.l[j] = *reinterpret_cast<const uint32_t*>(xr + j * ROWX + 256);
     }
@@ -183,16 +194,16 @@ __device__ __forceinline__ void helper_transform(const HRaw& r, unsigned char* s
     {
         unsigned char* vo = smem + VOFF + slot * VSLOT + (hw * 64 + lane) * 4;
 #pragma unroll
-        for (int xi = 0; xi < 8; ++xi) {
+        for (int xi = 0; xi < NXI; ++xi) {
             *reinterpret_cast<uint32_t*>(vo + xi * 2048) = r.h[xi];
             *reinterpret_cast<uint32_t*>(vo + xi * 2048 + 1024) = r.l[xi];
         }
         return;
     }
 #endif
-    float d[8][2];
+    float d[NXI][2];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
+    for (int j = 0; j < NXI; ++j) {
         const f16x2 hh = __builtin_bit_cast(f16x2, r.h[j]), ll = __builtin_bit_cast(f16x2, r.l[j]);
         d[j][0] = (float)hh[0] + (float)ll[0];
         d[j][1] = (float)hh[1] + (float)ll[1];
@@ -200,7 +211,7 @@ __device__ __forceinline__ void helper_transform(const HRaw& r, unsigned char* s
     unsigned char* vo = smem + VOFF + slot * VSLOT + (hw * 64 + lane) * 4;     // fragment lane th = hw * 16 + (lane >> 2), its dword lane & 3
 #pragma unroll
     for (int c = 0; c < 2; ++c) {
-        float v[8];
+        float v[NXI];
         const float d0 = d[0][c], d1 = d[1][c], d2 = d[2][c], d3 = d[3][c], d4 = d[4][c], d5 = d[5][c], d6 = d[6][c], d7 = d[7][c];
         v[0] = fmaf(d4 - d2, 5.25f, d0 - d6);
         const float t1 = fmaf(d4, -4.25f, d2 + d6), t2 = fmaf(d3, -4.25f, d1 + d5);
@@ -213,11 +224,20 @@ __device__ __forceinline__ void helper_transform(const HRaw& r, unsigned char* s
         v[5] = t5 + t6;
         v[6] = t5 - t6;
         v[7] = fmaf(d3 - d5, 5.25f, d7 - d1);
+#if NXI == 9      // stand-in for the ninth point of F(4,6) (1/4: the densest row of B^T) and the ninth input row: same instruction classes
+        {
+            const float d8 = d[8][c];
+            const float t7 = fmaf(d4, -5.3125f, fmaf(d2, 1.0625f, d6)), t8 = fmaf(d5, 4.25f, fmaf(d3, -21.25f, d1 * 4.f));
+            v[8] = fmaf(d7, 0.25f, t7 + t8) + d8;
+            v[0] = fmaf(d8, 0.0625f, v[0]);
+            v[7] = fmaf(d8, -0.25f, v[7]);
+        }
+#endif
 #pragma unroll
-        for (int i = 0; i < 8; ++i) d[i][c] = v[i];
+        for (int i = 0; i < NXI; ++i) d[i][c] = v[i];
     }
 #pragma unroll
-    for (int xi = 0; xi < 8; ++xi) {
+    for (int xi = 0; xi < NXI; ++xi) {
         const f32x2 v = {d[xi][0], d[xi][1]};
         const f16x2 hi = __builtin_convertvector(v, f16x2);
         const f32x2 back = {(float)hi[0], (float)hi[1]};
@@ -232,7 +252,7 @@ __device__ __forceinline__ void helper_transform(const HRaw& r, unsigned char* s
 }
 
 template <bool LW, bool LX, bool HELP>
-__device__ __forceinline__ void conv_tc(unsigned char* smem, rsrc_t wr, int woff, WU (&ring)[RINGT], f32x16 (&acc)[8], int lane) {
+__device__ __forceinline__ void conv_tc(unsigned char* smem, rsrc_t wr, int woff, WU (&ring)[RINGT], f32x16 (&acc)[NXI], int lane) {
     const uint32_t l16 = (uint32_t)lane * 16u;
     uint32_t voff = (uint32_t)VOFF + l16;
     asm volatile("" : "+v"(voff));
@@ -242,17 +262,17 @@ __device__ __forceinline__ void conv_tc(unsigned char* smem, rsrc_t wr, int woff
     va.l = *reinterpret_cast<const uint4*>(vb + 1024);
     vc = va;
     REGION_END();
-    static_for(std::make_integer_sequence<int, 64>{}, [&](auto kc) {
-        constexpr int k = decltype(kc)::value, kn = (k + 1) % 64;          // k = unit * 8 + xi
-        constexpr int VOFFN = ((kn / 8) % VRING) * VSLOT + (kn % 8) * 2048;
-        constexpr int kw = (k + RINGT - 1) % 64;
+    static_for(std::make_integer_sequence<int, 8 * NXI>{}, [&](auto kc) {
+        constexpr int k = decltype(kc)::value, kn = (k + 1) % (8 * NXI);          // k = unit * NXI + xi
+        constexpr int VOFFN = ((kn / NXI) % VRING) * VSLOT + (kn % NXI) * 2048;
+        constexpr int kw = (k + RINGT - 1) % (8 * NXI);
         // the V ring's hand-over: one barrier per k16 unit.  A bare s_barrier: __syncthreads() would also drain this wave's weight
         // loads in flight (s_waitcnt vmcnt(0)) and expose an L2 round trip per unit; the matrix waves wait for nothing of their own
-        if constexpr (HELP && k % 8 == 0 && k > 0) __builtin_amdgcn_s_barrier();
+        if constexpr (HELP && k % NXI == 0 && k > 0) __builtin_amdgcn_s_barrier();
         if constexpr (k % 2 == 0)
-            xi_tc<LW, LX, VOFFN>(ring[k % RINGT], ring[(k + RINGT - 1) % RINGT], va, vc, vb, wr, woff + kw * 8192, l16, acc[k % 8]);
+            xi_tc<LW, LX, VOFFN>(ring[k % RINGT], ring[(k + RINGT - 1) % RINGT], va, vc, vb, wr, woff + kw * 8192, l16, acc[k % NXI]);
         else
-            xi_tc<LW, LX, VOFFN>(ring[k % RINGT], ring[(k + RINGT - 1) % RINGT], vc, va, vb, wr, woff + kw * 8192, l16, acc[k % 8]);
+            xi_tc<LW, LX, VOFFN>(ring[k % RINGT], ring[(k + RINGT - 1) % RINGT], vc, va, vb, wr, woff + kw * 8192, l16, acc[k % NXI]);
     });
 }
 
@@ -303,15 +323,15 @@ __global__ __launch_bounds__(512, 2) void probe_kernel(const unsigned char* wts,
             for (int step = 0; step < steps; ++step) {
 #pragma unroll 1
                 for (int cv = 0; cv < 2; ++cv) {
-                    f32x16 acc[8];
+                    f32x16 acc[NXI];
 #pragma unroll
-                    for (int xi = 0; xi < 8; ++xi)
+                    for (int xi = 0; xi < NXI; ++xi)
 #pragma unroll
                         for (int r = 0; r < 16; ++r) acc[xi][r] = 0.f;
                     if constexpr (HELP) __builtin_amdgcn_s_barrier();
-                    conv_tc<LW, LX, HELP>(smem, wr, woff + cv * 64 * 8192, ring, acc, lane);
+                    conv_tc<LW, LX, HELP>(smem, wr, woff + cv * 8 * NXI * 8192, ring, acc, lane);
 #pragma unroll
-                    for (int xi = 0; xi < 8; ++xi) s += acc[xi][0] + acc[xi][7];
+                    for (int xi = 0; xi < NXI; ++xi) s += acc[xi][0] + acc[xi][7];
                 }
             }
         }
@@ -322,17 +342,17 @@ __global__ __launch_bounds__(512, 2) void probe_kernel(const unsigned char* wts,
 #pragma unroll 1
             for (int cv = 0; cv < 2; ++cv) {
                 HRaw ra, rb;
-                helper_load(ra, smem + cv * 48 * 1024, 1, hw, lane);
+                helper_load(ra, smem + cv * 16 * 1024, 1, hw, lane);
                 __builtin_amdgcn_s_barrier();
 #pragma unroll 1
                 for (int u = 0; u < 8; u += 2) {
                     // while the matrix waves consume unit u (slot u % 3) the helpers fill the slot of unit u + 1; the rows of the
                     // unit after that are requested before the transform (software pipeline: no LDS round trip per barrier interval)
-                    helper_load(rb, smem + cv * 48 * 1024, (u + 2) & 7, hw, lane);
+                    helper_load(rb, smem + cv * 16 * 1024, (u + 2) & 7, hw, lane);
                     helper_transform(ra, smem, (u + 1) % VRING, hw, lane);
-                    asm volatile("s_waitcnt lgkmcnt(8)" ::: "memory");      // the 16 stores are out; the 16 loads of the next unit may still fly
+                    asm volatile("s_waitcnt lgkmcnt(8)" ::: "memory");      // the stores are out; (most of) the loads of the next unit may still fly
                     __builtin_amdgcn_s_barrier();
-                    helper_load(ra, smem + cv * 48 * 1024, (u + 3) & 7, hw, lane);
+                    helper_load(ra, smem + cv * 16 * 1024, (u + 3) & 7, hw, lane);
                     helper_transform(rb, smem, (u + 2) % VRING, hw, lane);
                     if (u < 6) {
                         asm volatile("s_waitcnt lgkmcnt(8)" ::: "memory");
@@ -393,18 +413,20 @@ static void run(const char* name, int windows, int steps, int wbytes, double row
 
 int main(int argc, char** argv) {
     const int windows = argc > 1 ? atoi(argv[1]) : 4096;
-    const int WD = 2 * 48 * 8192, WT = 2 * 64 * 8192;
+    const int WD = 2 * 48 * 8192, WT = 2 * 8 * NXI * 8192;
+    const int TSTEPS = NXI == 8 ? 63 : 47;
+    const double TR = 32.0 * TROWS;
     printf("conv2 + conv3 loops only (no w_v, no epilogues, no conv1 / pair products); weights %d KB direct, %d KB Toom-Cook per step\n", WD / 1024, WT / 1024);
     if (argc <= 2) {
         run<0, true, true, false>("direct: weights + LDS reads + MFMAs", windows, 47, WD, 128);
         run<0, false, true, false>("direct: no weight stream", windows, 47, WD, 128);
         run<0, false, false, false>("direct: MFMAs only", windows, 47, WD, 128);
-        run<1, true, true, false>("tc F(3,6): weights + LDS reads + MFMAs", windows, 63, WT, 96);
-        run<1, false, true, false>("tc F(3,6): no weight stream", windows, 63, WT, 96);
-        run<1, true, false, false>("tc F(3,6): no LDS reads", windows, 63, WT, 96);
-        run<1, false, false, false>("tc F(3,6): MFMAs only", windows, 63, WT, 96);
+        run<1, true, true, false>(NXI == 8 ? "tc F(3,6): weights + LDS reads + MFMAs" : "tc F(4,6): weights + LDS reads + MFMAs", windows, TSTEPS, WT, TR);
+        run<1, false, true, false>(NXI == 8 ? "tc F(3,6): no weight stream" : "tc F(4,6): no weight stream", windows, TSTEPS, WT, TR);
+        run<1, true, false, false>(NXI == 8 ? "tc F(3,6): no LDS reads" : "tc F(4,6): no LDS reads", windows, TSTEPS, WT, TR);
+        run<1, false, false, false>(NXI == 8 ? "tc F(3,6): MFMAs only" : "tc F(4,6): MFMAs only", windows, TSTEPS, WT, TR);
     }
-    run<1, true, true, true>("tc F(3,6): all + helper transform + barriers", windows, 63, WT, 96);
-    run<1, false, true, true>("tc F(3,6): helpers + barriers, no weights", windows, 63, WT, 96);
+    run<1, true, true, true>(NXI == 8 ? "tc F(3,6): all + helper transform + barriers" : "tc F(4,6): all + helper transform + barriers", windows, TSTEPS, WT, TR);
+    run<1, false, true, true>(NXI == 8 ? "tc F(3,6): helpers + barriers, no weights" : "tc F(4,6): helpers + barriers, no weights", windows, TSTEPS, WT, TR);
     return 0;
 }
