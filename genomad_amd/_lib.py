@@ -63,6 +63,7 @@ SIGNATURES = {
     "gnn_destroy": (_int, [_vp]),
     "gnn_sync": (_int, [_vp]),
     "gnn_device_info": (_int, [_vp, C.c_char_p, _sz, C.POINTER(_int), C.POINTER(_i64)]),
+    "gnn_device_mem_info": (_int, [_vp, C.POINTER(_i64), C.POINTER(_i64)]),
     "gnn_load_weights": (_int, [_vp, C.POINTER(Weights)]),
     "gnn_dev_alloc": (_int, [_vp, _sz, C.POINTER(_vp)]),
     "gnn_dev_free": (_int, [_vp, _vp]),

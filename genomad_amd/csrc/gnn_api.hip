@@ -631,6 +631,16 @@ int gnn_device_info(gnn_ctx* ctx, char* name, size_t name_len, int* cus, int64_t
     return GNN_OK;
 }
 
+int gnn_device_mem_info(gnn_ctx* ctx, int64_t* free_bytes, int64_t* total_bytes) {
+    int rc = check_ctx(ctx);
+    if (rc) return rc;
+    size_t f = 0, t = 0;
+    GNN_HIP(hipMemGetInfo(&f, &t));
+    if (free_bytes) *free_bytes = (int64_t)f;
+    if (total_bytes) *total_bytes = (int64_t)t;
+    return GNN_OK;
+}
+
 int gnn_set_chunk(gnn_ctx* ctx, int64_t windows_per_chunk) {
     if (!ctx || windows_per_chunk < 1) {
         set_error("bad chunk");

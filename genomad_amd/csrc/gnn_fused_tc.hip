@@ -289,7 +289,15 @@ __device__ __forceinline__ void conv_tc(const unsigned char* __restrict__ smem, 
 template <bool F16>
 __device__ __forceinline__ void split2(f32x2 v, uint32_t& hi, uint32_t& lo) {
     hi = __builtin_bit_cast(uint32_t, __builtin_convertvector(v, f16x2));
+#ifndef TC_SPLIT_MIX
     lo = __builtin_bit_cast(uint32_t, __builtin_convertvector(f32x2{sub_f16_lo(v[0], hi), sub_f16_hi(v[1], hi)}, f16x2));
+#else
+    // A/B of round 5 (-DTC_SPLIT_MIX), measured NEGATIVE: residual and conversion in one instruction per value (v_fma_mixlo / mixhi_f16:
+    // the same bits, 3 instructions per pair instead of 4, 246 instead of 256 VGPRs) is 0.6 % SLOWER (20.73 vs 20.60 ms per 4096 windows,
+    // three alternating rounds on one box, cycles per step -0.15 %): the two partial-register writes form a dependent pair
+    asm("v_fma_mixlo_f16 %0, %1, -1.0, %2 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=v"(lo) : "v"(hi), "v"(v[0]));
+    asm("v_fma_mixhi_f16 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(lo) : "v"(hi), "v"(v[1]));
+#endif
 #ifdef TC_ALO_MASK     // energy probe (round 5): the low limbs of every activation operand with mantissa bits masked off (wrong results)
     lo &= TC_ALO_MASK;
 #endif

@@ -75,6 +75,12 @@ class NNEngine:
         check(self.lib.gnn_device_info(self.ctx, name, 256, C.byref(cus), C.byref(mem)))
         return {"name": name.value.decode(), "cus": cus.value, "hbm_bytes": mem.value}
 
+    def mem_info(self):
+        """(free, total) bytes of the engine's device."""
+        f, t = C.c_int64(), C.c_int64()
+        check(self.lib.gnn_device_mem_info(self.ctx, C.byref(f), C.byref(t)))
+        return f.value, t.value
+
     def load_weights(self, weights: dict):
         w = _weights.validate(weights)
         s, keep = _weights.to_struct(w)

@@ -147,6 +147,7 @@ int gnn_create(int device, gnn_ctx** out);
 int gnn_destroy(gnn_ctx* ctx);
 int gnn_sync(gnn_ctx* ctx);                      /* hipStreamSynchronize on the ctx stream */
 int gnn_device_info(gnn_ctx* ctx, char* name, size_t name_len, int* cus, int64_t* hbm_bytes);
+int gnn_device_mem_info(gnn_ctx* ctx, int64_t* free_bytes, int64_t* total_bytes);   /* hipMemGetInfo of the ctx's device (what the default launch size is clamped against) */
 
 /* replaces nn_model.load_weights(GenomadData.nn_model_file), nn_classification.py:310 */
 int gnn_load_weights(gnn_ctx* ctx, const gnn_weights* w);

@@ -3,8 +3,9 @@
 TEST INFRASTRUCTURE ONLY — see oracle/__init__.py.  Run in the build container (needs /root/reference):
 
     python -m oracle.make_golden_config2 [--n 10000] [--chunk 50] [--threads 4]
-    python -m oracle.make_golden_config2 --n 2048 --stride 512 --out tests/golden/config3_strided_golden.npz \
-        --scratch /tmp/config3_golden        # BASELINE config 3: every 512th of its 1 048 576 windows
+    python -m oracle.make_golden_config2 --n 16384 --stride 64 --chunk 64 --out tests/golden/config3_strided_golden.npz \
+        --scratch /tmp/config3_golden        # BASELINE config 3: every 64th of its 1 048 576 windows (round 5; 80 CPU-minutes on
+                                             # 4 threads; rounds 3-4 held every 512th: --n 2048 --stride 512)
 
 For synthetic windows 0 … n-1 (seed 1234) and the seed-42 synthetic weights it stores
 
