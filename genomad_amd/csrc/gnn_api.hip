@@ -71,6 +71,8 @@ static int dev_buffer(gnn_ctx* ctx, size_t bytes, void** out) {
     void* p = nullptr;
     hipError_t e = hipMalloc(&p, bytes);
     if (e != hipSuccess) {
+        (void)hipGetLastError();      // the runtime keeps the failure as its "last error": a caller that retries with a smaller size would
+                                      // otherwise read THIS out-of-memory behind its next, successful kernel launch
         set_error("hipMalloc of " + std::to_string(bytes) + " bytes failed: " + hipGetErrorString(e));
         return GNN_ERR_NOMEM;
     }
