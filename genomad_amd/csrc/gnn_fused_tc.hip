@@ -698,6 +698,9 @@ __global__ __launch_bounds__(512, 2) void fused_front_tc_kernel(Args a) {
 #endif
                 prime_tc(ring, cw[1], woff, lane);
                 if (store) wv_pool_store(ac, yp_w[0], t0, hw, lane);
+#ifdef TC_EMU_ONEBUF   // timing emulation of a single row buffer (round 5, MODEL.md): nothing overlaps the helpers' V3 chunks 0, 1
+                TC_BARRIER();
+#endif
             }
             GNN_TICK(3)
 #pragma unroll
@@ -723,6 +726,10 @@ __global__ __launch_bounds__(512, 2) void fused_front_tc_kernel(Args a) {
                 wv_tile(smem, BUF_BYTES + CARRY * ROWX, vw[1], woff, ring, ac, lane);
                 prime_tc(ring, cw[0], woff, lane);
                 if (store) wv_pool_store(ac, yp_w[1], t0, hw, lane);
+#ifdef TC_EMU_ONEBUF   // ... and x1(s+1) is stored between two barriers behind w_v B
+                TC_BARRIER();
+                TC_BARRIER();
+#endif
             }
         }
     } else {
@@ -803,6 +810,22 @@ __global__ __launch_bounds__(512, 2) void fused_front_tc_kernel(Args a) {
             pass_compute(p0, jbp, 2, hw, lane);                                  // head B's last pass of step s-1 (requested behind B0(s-1)):
             pass_rest(p0, jbp, 3, hw, lane);                                     // bufY holds x3(s-1) until the conv2 epilogue behind b_7
             pass_issue(p0, ja, 1, hw, lane);
+#ifdef TC_EMU_ONEBUF   // every reader of x1 is done before the conv2 epilogue (which would overwrite it): all of head A's passes before b_7
+            pass_compute(p1, ja, 0, hw, lane);
+            pass_issue(p1, ja, 2, hw, lane);
+            pass_compute(p0, ja, 1, hw, lane);
+            if (ht < CARRY * ROW_U4) carry = *reinterpret_cast<const uint4*>(bufX + (FTT + cr) * ROWX + cc * 16);
+            pass_compute(p1, ja, 2, hw, lane);
+            pass_rest(p1, ja, 3, hw, lane);
+            HBAR(8, 9);                                                          // b_7
+            grow_compute(o0, ga);
+            grow_issue(ga, prow, a.conv1_k, grow0 + 32, gpq);
+            HBAR(8, 10);                                                         // ---- B1
+            TC_BARRIER();                                                        // behind the matrix waves' w_v A
+            TC_HPRIO_LOW();
+            load_x2(ra, h2, 0);
+            load_x2(rb, h2, 1);
+#else
             HBAR(8, 9);                                                          // b_7
             pass_compute(p1, ja, 0, hw, lane);
             pass_issue(p1, ja, 2, hw, lane);
@@ -817,6 +840,7 @@ __global__ __launch_bounds__(512, 2) void fused_front_tc_kernel(Args a) {
             load_x2(rb, h2, 1);
             pass_compute(p1, ja, 2, hw, lane);
             pass_rest(p1, ja, 3, hw, lane);
+#endif
             transform_store<false>(ra, h2, 0);
             load_x2(ra, h2, 2);
             transform_store<false>(rb, h2, 1);
@@ -881,6 +905,11 @@ __global__ __launch_bounds__(512, 2) void fused_front_tc_kernel(Args a) {
             transform_store<true>(ra, h1, 0);
             load_x1(ra, h1, 2);
             transform_store<true>(rb, h1, 1);
+#ifdef TC_EMU_ONEBUF
+            TC_BARRIER_W();
+            __builtin_amdgcn_s_sleep(6);                                         // ~400 cycles: 16 x ds_write_b128 per helper lane
+            TC_BARRIER();
+#endif
             GNN_TICK(15)
         }
         if (s_hi > s_lo) {                                  // head B's last pass of this run's last step

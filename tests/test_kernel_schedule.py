@@ -185,9 +185,28 @@ def test_toomcook_model_notices_a_dropped_barrier_and_a_ring_overrun():
 
 # ------------------------------------------------------------------ the model against the source: barrier count and order parsed from the .hip
 def _tc_source():
+    """gnn_fused_tc.hip as the shipped library compiles it: the branches of the measurement switches (#ifdef TC_... / #if defined
+    TC_..., all undefined in the product build) are dropped, their #else branches kept."""
     import os
+    import re
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    return open(os.path.join(root, "genomad_amd", "csrc", "gnn_fused_tc.hip")).read()
+    out, stack = [], []          # stack of (keep this branch?, is a TC_ switch?)
+    for line in open(os.path.join(root, "genomad_amd", "csrc", "gnn_fused_tc.hip")):
+        m = re.match(r"\s*#\s*(ifdef|ifndef|else|endif|if)\b\s*(\w*)", line)
+        if m and m.group(1) in ("ifdef", "ifndef") and m.group(2).startswith("TC_"):
+            stack.append([m.group(1) == "ifndef", True])
+            continue
+        if m and m.group(1) in ("ifdef", "ifndef", "if"):
+            stack.append([True, False])
+        elif m and m.group(1) == "else" and stack and stack[-1][1]:
+            stack[-1][0] = not stack[-1][0]
+            continue
+        elif m and m.group(1) == "endif" and stack:
+            if stack.pop()[1]:
+                continue
+        if all(keep for keep, _ in stack):
+            out.append(line)
+    return "".join(out)
 
 
 def _loop_body(src, start):
