@@ -207,8 +207,9 @@ def test_fused_intermediates(engine, oracle16, prec):
 
 @pytest.fixture(scope="module")
 def oracle256(synth_weights):
-    """fp32 oracle scores of 256 synthetic windows, computed once for all arithmetics (11 s of numpy)"""
-    bases = synthetic.synth_windows(0, 256)
+    """fp32 oracle scores of 128 synthetic windows, computed once for all arithmetics (5 s of numpy; 256 until round 5 - the
+    10 000-window and 16 384-window reference-graph goldens cover the sizes)"""
+    bases = synthetic.synth_windows(0, 128)
     return bases, igloo_oracle.classify_windows(bases, synth_weights, np.float32)
 
 
@@ -1065,17 +1066,11 @@ def test_default_launch_size_follows_the_free_device_memory(synth_weights):
     """the library default of 16 384 windows per launch means 14 GB of workspace (28 GB on the asynchronous
     path); an integrator on a shared or partitioned GPU never asked for that.  With most of the device memory taken the default is
     clamped to a quarter of what is free (and says so), an explicit gnn_set_chunk that cannot be allocated is halved until it
-    fits, the asynchronous path runs in order when its second workspace does not fit - and the scores do not move by a bit."""
+    fits (the failed hipMalloc must not stay behind as HIP's last error), the asynchronous path runs in order when its second
+    workspace does not fit - and the scores do not move by a bit (scores do not depend on the launch size)."""
     from genomad_amd import _lib
     from genomad_amd.engine import NNEngine
     n = 12288
-    with NNEngine(0, synth_weights, chunk=2048) as ref:
-        rb, rs = ref.alloc(n * 6000), ref.alloc(n * 12)
-        ref.synth_windows_dev(5000, n, rb.ptr)
-        ref.classify_dev(rb.ptr, n, rs.ptr)
-        ref.sync()
-        want = rs.download((n, 3), np.float32)
-    per_window = (2 * 8400 + 2 * 2100 + 2 * 749 * 128 + 4 * 749 + 256) * 4          # WS_BYTES_PER_WINDOW of gnn_api.hip
 
     def launches_of(eng, fn):
         eng.profile_enable(True)
@@ -1093,8 +1088,9 @@ def test_default_launch_size_follows_the_free_device_memory(synth_weights):
         hog = eng.alloc(eng.mem_info()[0] - (16 << 30))          # leave 16 GB free: a quarter of it = ~4 k windows of workspace
         try:
             l = launches_of(eng, lambda: eng.classify_dev(b.ptr, n, s.ptr))
-            assert np.array_equal(s.download((n, 3), np.float32), want)
+            want = s.download((n, 3), np.float32)
             assert 3 <= l <= 48, l                               # 12 288 windows in launches of 256 .. 4 096, not ONE launch of 12 288
+            assert np.isfinite(want).all() and want.std(axis=0).min() > 0.05
             # asynchronous path: the second workspace is tried, and whatever happens the scores are the same
             eng.classify_dev_async(b.ptr, n // 2, s.ptr)
             eng.classify_dev_async(b.ptr + (n // 2) * 6000, n // 2, s.ptr + (n // 2) * 12)
@@ -1103,17 +1099,26 @@ def test_default_launch_size_follows_the_free_device_memory(synth_weights):
             assert np.array_equal(s.download((n, 3), np.float32), want)
         finally:
             hog.free()
-    with NNEngine(0, synth_weights, chunk=16384) as eng:         # explicit size: no clamp, halve-and-retry on allocation failure
-        b, s = eng.alloc(n * 6000), eng.alloc(n * 12)
-        eng.synth_windows_dev(5000, n, b.ptr)
-        eng.sync()
-        hog = eng.alloc(eng.mem_info()[0] - (8 << 30))           # 12 288 windows x 0.86 MB = 10.6 GB do not fit into 8 GB
+        # explicit size: no clamp, halve-and-retry on allocation failure: 12 288 windows x 0.86 MB = 10.6 GB do not fit into the 4 GB
+        # left free plus the ~4 GB the clamped workspace gives back; 6 144 windows (5.3 GB) do
+        _lib.check(eng.lib.gnn_set_chunk(eng.ctx, 16384))
+        hog = eng.alloc(eng.mem_info()[0] - (4 << 30))
         try:
             l = launches_of(eng, lambda: eng.classify_dev(b.ptr, n, s.ptr))
+            assert l >= 2
             assert np.array_equal(s.download((n, 3), np.float32), want)
-            assert l >= 2 and n * per_window > (8 << 30)
         finally:
             hog.free()
+        # with the memory back and the launch size the halving left behind: one more pass, the same bits
+        eng.classify_dev(b.ptr, n, s.ptr)
+        eng.sync()
+        assert np.array_equal(s.download((n, 3), np.float32), want)
+    with NNEngine(0, synth_weights, chunk=2048) as ref:          # an engine that never saw a short device
+        rb, rs = ref.alloc(n * 6000), ref.alloc(n * 12)
+        ref.synth_windows_dev(5000, n, rb.ptr)
+        ref.classify_dev(rb.ptr, n, rs.ptr)
+        ref.sync()
+        assert np.array_equal(rs.download((n, 3), np.float32), want)
 
 
 def test_bench_command_line_prints_one_complete_json_line(tmp_path):
