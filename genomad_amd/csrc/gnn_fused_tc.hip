@@ -133,6 +133,78 @@ __device__ __forceinline__ void load_wu(WU& w, wrsrc_t r, uint32_t l16, int soff
     w.l = make_uint4(b[0], b[1], b[2], b[3]);
 }
 
+// ---------------------------------------------------------------- IGLOO pair products: the 16 FMAs of one 16-byte slice
+// (hi + lo) * w as two v_fma_mix_f32 per value (the f16 halves are read in place: no conversion, no addition; hi * w and lo * w are exact
+// in f32 up to one rounding each, like (hi + lo) * w).  Four independent accumulators; slice i of a lane's 32-channel block uses the
+// weights w[2 i], w[2 i + 1].  Shared by the helpers' PairCompute::run and the matrix waves' staged form below: the same instructions on
+// the same operands in the same order per accumulator, so who computes an entry does not change a bit of it.
+__device__ __forceinline__ void pair_fma16(const uint4& hx, const uint4& lx, const float4& wlo, const float4& whi, float& s0, float& s1, float& s2, float& s3) {
+    const uint32_t hv[4] = {hx.x, hx.y, hx.z, hx.w}, lv[4] = {lx.x, lx.y, lx.z, lx.w};
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const float4 w0 = (k >> 1) ? whi : wlo;
+        const float wa = (k & 1) ? w0.z : w0.x, wb = (k & 1) ? w0.w : w0.y;
+        asm("v_fma_mix_f32 %0, %1, %2, %0 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "+v"(s0) : "v"(hv[k]), "v"(wa));
+        asm("v_fma_mix_f32 %0, %1, %2, %0 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "+v"(s1) : "v"(lv[k]), "v"(wa));
+        asm("v_fma_mix_f32 %0, %1, %2, %0 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(s2) : "v"(hv[k]), "v"(wb));
+        asm("v_fma_mix_f32 %0, %1, %2, %0 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(s3) : "v"(lv[k]), "v"(wb));
+    }
+}
+
+#ifdef TC_PAIRS_MATRIX
+// Round 5: the first two passes (128 of a step's ~134 entries per head) of the pair products run on the MATRIX waves, as fillers inside
+// their y @ w_v tiles: head A's beside w_v A (x1 in bufX), head B's beside w_v B (x3 in bufY) - the tiles read the same rows.  On the
+// helper waves they were 3.8 k cycles of the conv2 loop's critical path (profiles/r05/MODEL.md: NOPAIRS C -10 %); the matrix waves have
+// ~70 free registers in a w_v tile (48 + 64 + 48 of 256) and ~5 issue slots per MFMA gap.  One pass = 4 stages of 16 FMAs, one stage
+// per k16 unit of the tile, the stage's two 16-byte row reads requested a unit ahead; the weights of both passes are requested before
+// the preceding epilogue.  Same lane -> entry mapping, same instruction sequence per entry as on the helpers: bit-identical.
+struct MPair {
+    PairW w;
+    uint32_t xoff;          // LDS offset of the lane's 64-byte block (hi plane) of its row
+    int e;                  // entry, -1: none (the lane computes on a valid dummy and stores nothing)
+    float s0, s1, s2, s3;
+    uint4 hx, lx;
+};
+__device__ __forceinline__ void mpair_issue(MPair& q, const PairJob& jb, int buf_off, int k, int wave, int lane) {
+    const int e = jb.e + wave * 16 + (lane >> 2) + 64 * k;
+    const bool act = e < jb.e_end;
+    const int ec = min(e, NPAIR - 1);                      // inactive lanes read a valid entry's weights and row CARRY of the buffer
+    const int u = act ? jb.pos[ec] : jb.t0;
+    pair_load_w(q.w, jb, ec, lane & 3);
+    q.e = act ? e : -1;
+    q.xoff = (uint32_t)(buf_off + (CARRY + u - jb.t0) * ROWX + (lane & 3) * 64);
+    q.s0 = q.s1 = q.s2 = q.s3 = 0.f;
+}
+template <int I>
+__device__ __forceinline__ void mpair_load_x(MPair& q, const unsigned char* __restrict__ smem) {
+    q.hx = *reinterpret_cast<const uint4*>(smem + q.xoff + I * 16);
+    q.lx = *reinterpret_cast<const uint4*>(smem + q.xoff + LOX + I * 16);
+}
+template <int I>
+__device__ __forceinline__ void mpair_fma(MPair& q) {
+    pair_fma16(q.hx, q.lx, q.w.w[2 * I], q.w.w[2 * I + 1], q.s0, q.s1, q.s2, q.s3);
+}
+__device__ __forceinline__ void mpair_finish(const MPair& q, float* __restrict__ mp, int lane) {
+    float s = (q.s0 + q.s2) + (q.s1 + q.s3);
+    s += dpp_xor1(s);
+    s += dpp_xor2(s);
+    if (q.e >= 0 && (lane & 3) == 0) mp[q.e] = s;
+}
+// stage k (= k16 unit k of the tile): pass 0 in units 0 .. 3, pass 1 in units 4 .. 7; every stage requests the next stage's row slice
+template <int K>
+__device__ __forceinline__ void mpair_stage(MPair& q0, MPair& q1, const unsigned char* __restrict__ smem, float* __restrict__ mp, int lane) {
+    if constexpr (K < 4) {
+        mpair_fma<K>(q0);
+        if constexpr (K < 3) mpair_load_x<K + 1>(q0, smem);
+        else mpair_load_x<0>(q1, smem);
+    } else {
+        if constexpr (K == 4) mpair_finish(q0, mp, lane);
+        mpair_fma<K - 4>(q1);
+        if constexpr (K < 7) mpair_load_x<K - 3>(q1, smem);
+    }
+}
+#endif
+
 // ---------------------------------------------------------------- y @ w_v tiles (direct, 3 row blocks, as gnn_fused_x3.hip)
 struct XU {
     uint4 h[NMB], l[NMB];
@@ -146,9 +218,9 @@ __device__ __forceinline__ void load_xu(XU& f, const unsigned char* __restrict__
     }
 }
 // DROPWL (pricing probe -DTC_WVA_DROP, round 5; changes results): the tile without its x_hi * w_lo product = w_v rounded to ONE f16 limb
-template <bool LX, int OFFN, bool DROPWL = false>
+template <bool LX, int OFFN, bool DROPWL = false, bool FILL = false, class Stage>
 __device__ __forceinline__ void wv_unit(const WU& wc, WU& wl, bool lw, const XU& xc, XU& xl, const unsigned char* __restrict__ xh, wrsrc_t wr,
-                                        int wnext, uint32_t l16, f32x16 (&acc)[NMB]) {
+                                        int wnext, uint32_t l16, f32x16 (&acc)[NMB], Stage&& stage) {
     if constexpr (LX) load_xu<OFFN>(xl, xh);
     if (lw) load_wu(wl, wr, l16, wnext);
 #pragma unroll
@@ -163,19 +235,45 @@ __device__ __forceinline__ void wv_unit(const WU& wc, WU& wl, bool lw, const XU&
             if constexpr (!DROPWL) acc[mb] = mma(xc.h[mb], wc.l, acc[mb]);
         }
     }
+#ifdef TC_PROBE_WV_FILLERS   // pricing probe (round 5): TC_PROBE_WV_FILLERS v_fma_mix_f32 per k16 unit in the matrix waves' w_v tiles - what
+                             // the IGLOO pair products would cost there as fillers beside the MFMAs (with -DTC_ABL_NOPAIRS on the helpers)
+    {
+        float f0 = __uint_as_float(xc.h[0].x), f1 = __uint_as_float(xc.h[0].y), f2 = __uint_as_float(xc.l[0].x), f3 = __uint_as_float(xc.l[0].y);
+#pragma unroll
+        for (int i = 0; i < TC_PROBE_WV_FILLERS / 4; ++i) {
+            asm volatile("v_fma_mix_f32 %0, %1, %2, %0 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "+v"(f0) : "v"(wc.h.x), "v"(f1));
+            asm volatile("v_fma_mix_f32 %0, %1, %2, %0 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(f1) : "v"(wc.h.y), "v"(f2));
+            asm volatile("v_fma_mix_f32 %0, %1, %2, %0 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "+v"(f2) : "v"(wc.l.x), "v"(f3));
+            asm volatile("v_fma_mix_f32 %0, %1, %2, %0 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(f3) : "v"(wc.l.y), "v"(f0));
+        }
+        asm volatile("" ::"v"(f0), "v"(f1), "v"(f2), "v"(f3));
+    }
 #pragma unroll
     for (int i = 0; i < (DROPWL ? 2 : 3) * NMB; ++i) {
         __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x002, TC_PROBE_WV_FILLERS / 9, 0);
         if (LX && i < 2 * NMB) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
         if (i == 1 || i == 5) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
     }
     GNN_REGION_END();
 }
+#else
+    stage();                 // TC_PAIRS_MATRIX: this unit's slice of the pair products (16 FMAs + the next slice's two row reads); else empty
+#pragma unroll
+    for (int i = 0; i < (DROPWL ? 2 : 3) * NMB; ++i) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        if (FILL) __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);
+        if ((LX && i < 2 * NMB) || (FILL && i >= 2 * NMB && i < 2 * NMB + 2)) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+        if (i == 1 || i == 5) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+    }
+    GNN_REGION_END();
+}
+#endif
 // D = X W over the 96 rows that start at buffer row CARRY of `xoff`: a lane ends up with 16 rows of one channel per row block.
 // The ring's first RINGV - 1 units were requested by prime_wv.
-template <bool DROPWL = false>
+template <bool DROPWL = false, bool FILL = false, class StageFn>
 __device__ __forceinline__ void wv_tile(const unsigned char* __restrict__ smem, int xoff, wrsrc_t wr, int woff, WU (&ring)[RINGT],
-                                        f32x16 (&acc)[NMB], int lane) {
+                                        f32x16 (&acc)[NMB], int lane, StageFn&& stagefn) {
 #ifdef TC_ABL_NOWV
     return;
 #endif
@@ -191,9 +289,11 @@ __device__ __forceinline__ void wv_tile(const unsigned char* __restrict__ smem, 
         constexpr int OFFN = kn * 32;
         constexpr bool LX = kn < 8, LW = k + RINGV - 1 < 8;
         if constexpr (k % 2 == 0)
-            wv_unit<LX, OFFN, DROPWL>(ring[k % RINGV], ring[(k + RINGV - 1) % RINGV], LW, xa, xb, xh, wr, woff + (k + RINGV - 1) * WUNIT_B, l16, acc);
+            wv_unit<LX, OFFN, DROPWL, FILL>(ring[k % RINGV], ring[(k + RINGV - 1) % RINGV], LW, xa, xb, xh, wr, woff + (k + RINGV - 1) * WUNIT_B, l16, acc,
+                                            [&]() { stagefn(kc); });
         else
-            wv_unit<LX, OFFN, DROPWL>(ring[k % RINGV], ring[(k + RINGV - 1) % RINGV], LW, xb, xa, xh, wr, woff + (k + RINGV - 1) * WUNIT_B, l16, acc);
+            wv_unit<LX, OFFN, DROPWL, FILL>(ring[k % RINGV], ring[(k + RINGV - 1) % RINGV], LW, xb, xa, xh, wr, woff + (k + RINGV - 1) * WUNIT_B, l16, acc,
+                                            [&]() { stagefn(kc); });
     });
 }
 __device__ __forceinline__ void prime_wv(WU (&ring)[RINGT], wrsrc_t wr, int woff, int lane) {
@@ -542,23 +642,10 @@ struct PairCompute {
             hx[i] = *reinterpret_cast<const uint4*>(xr + i * 16);
             lx[i] = *reinterpret_cast<const uint4*>(xr + LOX + i * 16);
         }
-        // (hi + lo) * w as two v_fma_mix_f32 per value (the f16 halves are read in place: no conversion, no addition; hi * w and lo * w
-        // are exact in f32 up to one rounding each, like (hi + lo) * w).  Four independent accumulators: one chain of 64 dependent
-        // FMAs is latency-bound on a wave that has the SIMD's leftover issue slots
+        // four independent accumulators: one chain of 64 dependent FMAs is latency-bound on a wave that has the SIMD's leftover issue slots
         float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const uint32_t hv[4] = {hx[i].x, hx[i].y, hx[i].z, hx[i].w}, lv[4] = {lx[i].x, lx[i].y, lx[i].z, lx[i].w};
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                const float4 w0 = w.w[2 * i + (k >> 1)];
-                const float wa = (k & 1) ? w0.z : w0.x, wb = (k & 1) ? w0.w : w0.y;
-                asm("v_fma_mix_f32 %0, %1, %2, %0 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "+v"(s0) : "v"(hv[k]), "v"(wa));
-                asm("v_fma_mix_f32 %0, %1, %2, %0 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "+v"(s1) : "v"(lv[k]), "v"(wa));
-                asm("v_fma_mix_f32 %0, %1, %2, %0 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(s2) : "v"(hv[k]), "v"(wb));
-                asm("v_fma_mix_f32 %0, %1, %2, %0 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(s3) : "v"(lv[k]), "v"(wb));
-            }
-        }
+        for (int i = 0; i < 4; ++i) pair_fma16(hx[i], lx[i], w.w[2 * i], w.w[2 * i + 1], s0, s1, s2, s3);
         float s = (s0 + s2) + (s1 + s3);
         s += dpp_xor1(s);
         s += dpp_xor2(s);
@@ -681,6 +768,14 @@ __global__ __launch_bounds__(512, 2) void fused_front_tc_kernel(Args a) {
             conv_tc(smem, cw[0], woff, ring, acc, lane, jitter_state);                         // b_0 .. b_7, conv2
             GNN_TICK(0)
             prime_wv(ring, vw[0], woff, lane);
+#ifdef TC_PAIRS_MATRIX   // head A's first two passes (x1(s) stays in bufX until the gather behind b'_0): weights and positions requested here, used in w_v A
+            MPair qa0, qa1;
+            {
+                const PairJob ja = {bufX, a.weff[0], a.pos_sorted[0], mp_w[0], t0, store ? a.bucket_ptr[0][step] : 0, store ? a.bucket_ptr[0][step + 1] : 0};
+                mpair_issue(qa0, ja, 0, 0, hw, lane);
+                mpair_issue(qa1, ja, 0, 1, hw, lane);
+            }
+#endif
             epilogue_f32(bufY, acc, a.inv_s[0], bias_s, hw, lane);
             GNN_TICK(1)
             TC_BARRIER_W();                                                      // ---- B1: x2 is in bufY
@@ -691,10 +786,14 @@ __global__ __launch_bounds__(512, 2) void fused_front_tc_kernel(Args a) {
                 for (int mb = 0; mb < NMB; ++mb)
 #pragma unroll
                     for (int r = 0; r < 16; ++r) ac[mb][r] = 0.f;
-#ifdef TC_WVA_DROP
-                wv_tile<true>(smem, CARRY * ROWX, vw[0], woff, ring, ac, lane);
+#if defined(TC_WVA_DROP)
+                wv_tile<true>(smem, CARRY * ROWX, vw[0], woff, ring, ac, lane, [](auto) {});
+#elif defined(TC_PAIRS_MATRIX)
+                mpair_load_x<0>(qa0, smem);
+                wv_tile<false, true>(smem, CARRY * ROWX, vw[0], woff, ring, ac, lane, [&](auto kc) { mpair_stage<decltype(kc)::value>(qa0, qa1, smem, mp_w[0], lane); });
+                mpair_finish(qa1, mp_w[0], lane);
 #else
-                wv_tile(smem, CARRY * ROWX, vw[0], woff, ring, ac, lane);
+                wv_tile(smem, CARRY * ROWX, vw[0], woff, ring, ac, lane, [](auto) {});
 #endif
                 prime_tc(ring, cw[1], woff, lane);
                 if (store) wv_pool_store(ac, yp_w[0], t0, hw, lane);
@@ -710,6 +809,14 @@ __global__ __launch_bounds__(512, 2) void fused_front_tc_kernel(Args a) {
             conv_tc(smem, cw[1], woff, ring, acc, lane, jitter_state);                         // b'_0 .. b'_7, conv3
             GNN_TICK(4)
             prime_wv(ring, vw[1], woff, lane);
+#ifdef TC_PAIRS_MATRIX   // head B's first two passes (x3(s) in bufY from B0 to the next conv2 epilogue), used in w_v B
+            MPair qb0, qb1;
+            {
+                const PairJob jb = {bufY, a.weff[1], a.pos_sorted[1], mp_w[1], t0, store ? a.bucket_ptr[1][step] : 0, store ? a.bucket_ptr[1][step + 1] : 0};
+                mpair_issue(qb0, jb, BUF_BYTES, 0, hw, lane);
+                mpair_issue(qb1, jb, BUF_BYTES, 1, hw, lane);
+            }
+#endif
             epilogue_x3(bufY, acc, a.inv_s[1], bias_s + C, hw, lane);
             GNN_TICK(5)
             TC_BARRIER_W();                                                      // ---- B0: x3 is in bufY
@@ -723,7 +830,13 @@ __global__ __launch_bounds__(512, 2) void fused_front_tc_kernel(Args a) {
                 for (int mb = 0; mb < NMB; ++mb)
 #pragma unroll
                     for (int r = 0; r < 16; ++r) ac[mb][r] = 0.f;
-                wv_tile(smem, BUF_BYTES + CARRY * ROWX, vw[1], woff, ring, ac, lane);
+#ifdef TC_PAIRS_MATRIX
+                mpair_load_x<0>(qb0, smem);
+                wv_tile<false, true>(smem, BUF_BYTES + CARRY * ROWX, vw[1], woff, ring, ac, lane, [&](auto kc) { mpair_stage<decltype(kc)::value>(qb0, qb1, smem, mp_w[1], lane); });
+                mpair_finish(qb1, mp_w[1], lane);
+#else
+                wv_tile(smem, BUF_BYTES + CARRY * ROWX, vw[1], woff, ring, ac, lane, [](auto) {});
+#endif
                 prime_tc(ring, cw[0], woff, lane);
                 if (store) wv_pool_store(ac, yp_w[1], t0, hw, lane);
 #ifdef TC_EMU_ONEBUF   // ... and x1(s+1) is stored between two barriers behind w_v B
@@ -804,12 +917,16 @@ __global__ __launch_bounds__(512, 2) void fused_front_tc_kernel(Args a) {
             // slack, and wait in 16 registers each for b'_0, behind which bufX may be written; round 2 runs beside conv3.
             GRow ga;
             GOut o0, o1;
+#ifndef TC_PAIRS_MATRIX
             pass_issue(p1, ja, 0, hw, lane);
+#endif
             grow_issue(ga, prow, a.conv1_k, grow0, gpq);
             HBAR_W(8, 9);                                                        // b_6
             pass_compute(p0, jbp, 2, hw, lane);                                  // head B's last pass of step s-1 (requested behind B0(s-1)):
             pass_rest(p0, jbp, 3, hw, lane);                                     // bufY holds x3(s-1) until the conv2 epilogue behind b_7
+#ifndef TC_PAIRS_MATRIX
             pass_issue(p0, ja, 1, hw, lane);
+#endif
 #ifdef TC_EMU_ONEBUF   // every reader of x1 is done before the conv2 epilogue (which would overwrite it): all of head A's passes before b_7
             pass_compute(p1, ja, 0, hw, lane);
             pass_issue(p1, ja, 2, hw, lane);
@@ -827,9 +944,13 @@ __global__ __launch_bounds__(512, 2) void fused_front_tc_kernel(Args a) {
             load_x2(rb, h2, 1);
 #else
             HBAR(8, 9);                                                          // b_7
+#ifdef TC_PAIRS_MATRIX   // passes 0, 1 run on the matrix waves (beside w_v A); the helpers keep the remainder of a step's entries (pass 2 ..)
+            pass_issue(p1, ja, 2, hw, lane);
+#else
             pass_compute(p1, ja, 0, hw, lane);
             pass_issue(p1, ja, 2, hw, lane);
             pass_compute(p0, ja, 1, hw, lane);
+#endif
             if (ht < CARRY * ROW_U4) carry = *reinterpret_cast<const uint4*>(bufX + (FTT + cr) * ROWX + cc * 16);
             grow_compute(o0, ga);
             grow_issue(ga, prow, a.conv1_k, grow0 + 32, gpq);
@@ -888,8 +1009,10 @@ __global__ __launch_bounds__(512, 2) void fused_front_tc_kernel(Args a) {
             // head B's pair products of this step (x3 in bufY from B0 to the next conv2 epilogue): the first two passes requested
             // beside the conv3 epilogue; behind B0, beside the matrix waves' w_v B: pass 0, the third pass's request, pass 1, V2 chunks
             // 0, 1 of the next step, pass 2
+#ifndef TC_PAIRS_MATRIX
             pass_issue(p0, jb, 0, hw, lane);
             pass_issue(p1, jb, 1, hw, lane);
+#endif
             GNN_TICK(13)
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             HBAR(13, 11);                                                        // ---- B0: x3 is in bufY, x1(s+1) in bufX
@@ -899,9 +1022,13 @@ __global__ __launch_bounds__(512, 2) void fused_front_tc_kernel(Args a) {
             TC_HPRIO_LOW();
             load_x1(ra, h1, 0);
             load_x1(rb, h1, 1);
+#ifdef TC_PAIRS_MATRIX
+            pass_issue(p0, jb, 2, hw, lane);
+#else
             pass_compute(p0, jb, 0, hw, lane);
             pass_issue(p0, jb, 2, hw, lane);
             pass_compute(p1, jb, 1, hw, lane);
+#endif
             transform_store<true>(ra, h1, 0);
             load_x1(ra, h1, 2);
             transform_store<true>(rb, h1, 1);

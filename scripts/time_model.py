@@ -138,8 +138,9 @@ def main():
     # bit-identical results; head A's pair products before b_7, the helpers' V3 chunks 0, 1 only behind the matrix waves' w_v A, two
     # extra barriers with the x1 store between them; profiles/r05/batch4/ab_emu_onebuf.txt): C 37 862 -> 41 333 (+9.2 %), T 20.92 ->
     # 21.66 ms (+3.5 %; the model: 1.092^0.39 = +3.5 %).  Per 128-row step the same bubbles are amortised over 4/3 the rows: +6.9 %.
-    add("F(4,6), ONE row buffer (x1 -> x2 -> x3 in place)", (conv + wts * 8 / 9 + vread) * (1 - 27 / 32), 0.092 * 0.75,
-        "serialisation measured by the timing emulation TC_EMU_ONEBUF (+9.2 % cycles per 96-row step), conv phases by the probe")
+    add("F(4,6), ONE row buffer (x1 -> x2 -> x3 in place)", (conv + wts * 8 / 9 + vread) * (1 - 27 / 32), 0.092 * 0.75 + 2500 * 0.75 / C0,
+        "serialisation measured by TC_EMU_ONEBUF (+9.2 % cycles per 96-row step) + the conv1 gather exposed between the end-of-step barriers "
+        "(~2.5 k cycles: its results have nowhere to wait - helpers 256 / 256 VGPRs, matrix waves 228); conv phases by the probe")
     add("64 tiles in flight (two MFMA blocks per weight fragment)", wts * 8 / 9 * 0.5, 0, "needs 256 accumulator registers per matrix wave: does not fit")
     add("f16 hi*hi + int8 cross terms (2.0 pass eq.)", (conv + wv * 0.6) * (1 / 3) * 0.5, 0, "fails the accuracy gate in emulation; needs a second (i32) accumulator set: does not fit")
     add("low limbs cut by 5 mantissa bits (measured)", 1 - w_ratio(R["tc_alo5,GNN_TC_WLO_MASK=FFE0"])[0] if "tc_alo5,GNN_TC_WLO_MASK=FFE0" in R else 0, 0, "4.9e-5 on 600 windows: no margin")
