@@ -26,12 +26,9 @@ echo "built $(pwd)/libgenomad_nn_hip.so ($C8)"
 # Test variant (tests/test_gpu_parity.py::test_toomcook_kernel_is_bit_identical_under_delay_injection): the same library with random
 # sleeps behind every barrier of the default kernel.  Never loaded by the product; built with the main library so that it travels
 # to the GPU box.
-stale=0
-for o in $OBJS; do
-  [ $o -nt libgenomad_nn_hip_jitter.so ] && stale=1
-done
-if [ ! -f libgenomad_nn_hip_jitter.so ] || [ $stale = 1 ]; then
+if [ ! -f obj/gnn_fused_tc_jitter.o ] || [ gnn_fused_tc.hip -nt obj/gnn_fused_tc_jitter.o ] || [ gnn_common.h -nt obj/gnn_fused_tc_jitter.o ] || [ gnn_fused_common.h -nt obj/gnn_fused_tc_jitter.o ] || [ gnn_fused_helpers.h -nt obj/gnn_fused_tc_jitter.o ] || [ ../../include/genomad_nn.h -nt obj/gnn_fused_tc_jitter.o ]; then
   $HIPCC $FLAGS -fno-slp-vectorize -DTC_JITTER -c gnn_fused_tc.hip -o obj/gnn_fused_tc_jitter.o
-  $HIPCC --offload-arch=gfx950 -shared -fPIC -o libgenomad_nn_hip_jitter.so ${OBJS/obj\/gnn_fused_tc.o/obj\/gnn_fused_tc_jitter.o} -ldl
-  echo "built $(pwd)/libgenomad_nn_hip_jitter.so"
 fi
+# always relinked (one second): the same objects as the main library, whichever f16c8 file that is
+$HIPCC --offload-arch=gfx950 -shared -fPIC -o libgenomad_nn_hip_jitter.so ${OBJS/obj\/gnn_fused_tc.o/obj\/gnn_fused_tc_jitter.o} -ldl
+echo "built $(pwd)/libgenomad_nn_hip_jitter.so"
