@@ -285,8 +285,8 @@ def classify_contigs_safely(eng, seq, offsets, single_window, precision, console
 # checkout).  So every run of main() classifies its first windows a second time with the exact-f32 device path (GNN_PREC_F32:
 # unfused f32 FMA kernels, the parity anchor of tests/ and bench.py) and compares: the only parity evidence a user with the real
 # weights ever gets, and what turns the range / precision assumptions of the f16 limb arithmetic (activations neither beyond
-# ~2 000 nor so small that the low limbs go subnormal) into checked ones.  Cost: one 64-window launch of the f32 path, ~0.1 s
-# including its 0.6 GB activation workspace (scripts/sentinel_cost.py).  GENOMAD_AMD_NO_SENTINEL=1 opts out.
+# ~2 000 nor so small that the low limbs go subnormal) into checked ones.  Cost: one 64-window launch of the f32 path, 6 ms
+# including its 0.6 GB activation workspace (tests/test_gpu_parity.py::test_parity_sentinel_... prints it).  GENOMAD_AMD_NO_SENTINEL=1 opts out.
 SENTINEL_WINDOWS = 64
 SENTINEL_TOL = 1e-4            # BASELINE.json north_star: per-class scores within 1e-4 absolute of the reference path
 

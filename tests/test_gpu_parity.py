@@ -371,8 +371,16 @@ def test_parity_sentinel_trips_on_weights_outside_the_validated_range(synth_weig
         t = time.perf_counter()
         nnc.parity_sentinel(e1, win, "f16x3tc", None)
         cost = time.perf_counter() - t
-        print(f"parity sentinel: {d:.2e} on the synthetic weights, {cost * 1e3:.0f} ms per run (warm)")
-        assert cost < 1.0
+    with NNEngine(0, synth_weights) as e0:                    # a fresh engine: the first call also allocates the f32 path's workspace
+        big = synthetic.synth_windows(0, nnc.SENTINEL_WINDOWS)
+        e0.classify(big[:1], "f16x3tc")
+        t = time.perf_counter()
+        nnc.parity_sentinel(e0, big, "f16x3tc", None)
+        cold = time.perf_counter() - t
+    with capsys.disabled():
+        print(f"\nparity sentinel: {d:.2e} on the synthetic weights; {cost * 1e3:.0f} ms per run warm (6 windows), "
+              f"{cold * 1e3:.0f} ms cold with the full {nnc.SENTINEL_WINDOWS} windows (first f32 launch of the engine)")
+    assert cost < 1.0 and cold < 2.0
     tiny = _scaled_activations(synth_weights, 2.0 ** -17)
     _write_weights_and_fasta(tmp_path, monkeypatch, tiny)
     with NNEngine(0, tiny) as e2:
