@@ -1301,3 +1301,52 @@ def test_native_accession_digests_equal_the_python_mirror():
     assert sharding.fasta_verdict(None, got[:4], lambda: calls.append(1) or True) and not calls
     assert not sharding.fasta_verdict(None, got, lambda: calls.append(1) or False) and calls == [1]
     assert not sharding.fasta_verdict(None, got[:0], lambda: True)
+
+
+def test_cpu_baseline_is_not_throttled_by_the_launcher_and_keeps_its_budget():
+    """`python -m torch.distributed.run --nproc-per-node N` (N > 1) exports OMP_NUM_THREADS=1, which OpenBLAS honours: rank 0's
+    1 024-window CPU baseline would run on ONE thread (~25 minutes) while the other ranks wait for its RCCL id - the driver's
+    scaling run would be the first to notice.  bench.cpu_baseline raises the BLAS pool to the cores the process may use whatever
+    the environment says, and cuts the sample to its time budget."""
+    import subprocess
+    root = Path(__file__).resolve().parents[1]
+    code = ("import sys, json; sys.path.insert(0, %r); import bench; from genomad_amd import synthetic\n"
+            "b, s = bench.cpu_baseline(synthetic.synth_weights(), 8, batch=2, budget_s=%s)\n"
+            "print(json.dumps({'cores': b['cores'], 'env': b['omp_num_threads_env'], 'n': len(s), 'sample': b['sample'], 'visible': b['host_cpus_visible']}))")
+    env = dict(os.environ, OMP_NUM_THREADS="1")
+    r = subprocess.run([sys.executable, "-c", code % (str(root), "600")], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    o = json.loads(r.stdout.strip().splitlines()[-1])
+    assert o["env"] == "1" and o["n"] == 8
+    assert o["cores"] == o["visible"] or o["visible"] == 1, o           # not the launcher's single thread
+    r = subprocess.run([sys.executable, "-c", code % (str(root), "0.001")], env=env, capture_output=True, text=True, timeout=600)
+    o = json.loads(r.stdout.strip().splitlines()[-1])
+    assert o["n"] == 2 and "cut from 8" in o["sample"]                   # one batch, then the budget is gone: said in the line
+
+
+def test_bench_under_the_drivers_launcher_with_two_ranks_over_the_fake_engine():
+    """The driver's N > 1 command verbatim - `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1
+    --master-port P bench.py --gpus N --steps K --warmup W` - on the CPU over tests/fake_engine.py: the launcher's environment
+    (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_PORT, and its OMP_NUM_THREADS=1) reaches bench.py, the ranks find each other through
+    the rendezvous file keyed on the launcher's identity, rank 0 prints ONE JSON line with a CPU baseline that was not throttled to
+    one thread, and every rank exits 0."""
+    import socket
+    import subprocess
+    pytest.importorskip("torch")
+    root = Path(__file__).resolve().parents[1]
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT", "OMP_NUM_THREADS")}
+    env["GENOMAD_AMD_BENCH_FAKE_ENGINE"] = "1"
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                        "--master-port", str(port), str(root / "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "1",
+                        "--windows-per-step", "512", "--cpu-sample", "4"], env=env, capture_output=True, text=True, timeout=900, cwd=str(root))
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [json.loads(x) for x in r.stdout.splitlines() if x.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    o = lines[0]
+    assert o["n_gpus"] == 2 and o["rccl_ranks"] == 2 and o["steps"] == 4 and o["fake_engine"] is True
+    assert o["cpu_baseline"]["omp_num_threads_env"] == "1"                      # the launcher did export it ...
+    assert o["cpu_baseline"]["cores"] == o["cpu_baseline"]["host_cpus_visible"] or o["cpu_baseline"]["host_cpus_visible"] == 1   # ... and it did not bind
+    assert o["steps_verified"]["mismatching_windows_all_ranks"] == 0 and o["parity"]["ok"] and "failed" not in o
