@@ -173,10 +173,8 @@ int gnn_comm_gather_dev(gnn_ctx* ctx, const void* send_dev, void* recv_dev, size
         return GNN_ERR_ARG;
     }
     if (!bytes_per_rank) return GNN_OK;
-    // a rank that is not the root receives nothing; it may pass NULL here, and the collective is handed a valid pointer it never writes
-    // (an argument check on recvbuff must not be what the first multi-rank run trips over)
-    void* recv = recv_dev ? recv_dev : const_cast<void*>(send_dev);
-    GNN_NCCL(g_rccl.Gather(send_dev, recv, bytes_per_rank, ncclUint8, root, static_cast<ncclComm_t>(ctx->comm), ctx->stream));
+    // rccl.h:735: "recvbuff may be NULL on ranks other than root"
+    GNN_NCCL(g_rccl.Gather(send_dev, recv_dev, bytes_per_rank, ncclUint8, root, static_cast<ncclComm_t>(ctx->comm), ctx->stream));
     return GNN_OK;
 }
 
