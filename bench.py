@@ -363,7 +363,7 @@ def main():
     eng, _n_dev, local_rank = make_engine(local_rank, weights, args.chunk)
     info = eng.device_info()
     t_ci = time.perf_counter()
-    comm = rccl.RcclComm(eng, rank, world, timeout=600.0)   # always: the N = 1 line takes the same RCCL path as N = 8
+    comm = rccl.RcclComm(eng, rank, world, timeout=float(os.environ.get('GENOMAD_AMD_RDZV_TIMEOUT', '600')))   # always: the N = 1 line takes the same RCCL path as N = 8
     comm_init_s = time.perf_counter() - t_ci
     rccl_ranks, rccl_rank = ctypes.c_int(), ctypes.c_int()
     _lib.check(eng.lib.gnn_comm_info(eng.ctx, ctypes.byref(rccl_ranks), ctypes.byref(rccl_rank)))

@@ -62,7 +62,19 @@ class _FakeLib:
     bench.py calls on `eng.lib` directly."""
 
     def __init__(self):
-        self.dir = Path(os.environ.get("GENOMAD_AMD_RDZV_DIR", "/tmp"))
+        # One directory per LAUNCH: bench.py's own spawner exports a private GENOMAD_AMD_RDZV_DIR; under another launcher
+        # (torch.distributed.run) the directory is named after what identifies the launch - the same tag genomad_amd/rccl.py keys the
+        # real unique id on -, so that the files of an earlier run can never stand in for a rank that has not arrived yet (they
+        # did, in /tmp: a rank "joined" at once, rank 0 removed the id file, the other rank waited for it until its time-out)
+        explicit = os.environ.get("GENOMAD_AMD_RDZV_DIR")
+        if explicit:
+            self.dir = Path(explicit)
+        else:
+            import tempfile
+            from genomad_amd import rccl
+            self.dir = Path(tempfile.gettempdir()) / f"genomad_amd_fake_comm_{os.getuid()}_{rccl._run_tag(0).hex()}"
+            self.dir.mkdir(mode=0o700, exist_ok=True)
+        self.own_dir = not explicit
         self.seq, self.world, self.rank = 0, 1, 0
 
     # -- bootstrap
@@ -76,6 +88,12 @@ class _FakeLib:
         return 0
 
     def gnn_comm_destroy(self, ctx):
+        if self.world > 1 and self.own_dir:
+            self._exchange(np.zeros(1, np.uint8))         # every rank is done reading
+            if self.rank == 0:
+                import shutil
+                time.sleep(0.3)
+                shutil.rmtree(self.dir, ignore_errors=True)
         return 0
 
     def gnn_comm_info(self, ctx, ranks, rank):
