@@ -708,7 +708,12 @@ __global__ __launch_bounds__(512, 2) void fused_front_tc_kernel(Args a) {
     const int part = blockIdx.x % a.split;
     const uint8_t* bases = a.bases + wi * W;
     float* mp_w[2] = {a.mp + (wi * 2 + 0) * NPAIR, a.mp + (wi * 2 + 1) * NPAIR};
+#ifdef TC_PROBE_SAME_NBLK   // pricing probe (round 5; wrong results): all four matrix waves stream the SAME weight fragments (n-block 0), so three of
+                           // four requests hit the CU's vector L1 - how much of the weight stream's cost is L2 -> L1, how much L1 -> VGPR
+    const int woff = 0;
+#else
     const int woff = hw * WNBLK_B;
+#endif
 
     for (int i = tid; i < CARRY * ROW_U4; i += 512) {            // carry rows of the first step = the causal zero padding
         reinterpret_cast<uint4*>(bufX)[i] = make_uint4(0, 0, 0, 0);
