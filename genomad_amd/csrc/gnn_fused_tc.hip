@@ -33,9 +33,10 @@
 // LDS: bufX 101 rows x 528 B (x1: hi | lo planes), bufY 101 x 528 (x2 as f32 rows, then x3 as hi | lo planes), ring 3 x 16 KB,
 // pair rows, biases: 157.3 KB.
 //
-// Compile-time switches, all off in the shipped library: -DTC_JITTER (libgenomad_nn_hip_jitter.so: random sleeps behind every barrier,
-// results must not move), -DTC_ABL_* (parts compiled out, wrong results: what the launch is made of, profiles/r04/tc_ablation.txt),
-// -DTC_SLEEP_B0=n, -DTC_WAUX=n, -DTC_HPRIO_STATIC (A/B knobs of the same file).
+// Compile-time switches: -DTC_JITTER only (libgenomad_nn_hip_jitter.so, a test build: random sleeps behind every barrier, results
+// must not move).  The ablation / probe / emulation switches of rounds 4 and 5 (TC_ABL_*, TC_PROBE_*, TC_EMU_ONEBUF, TC_PAIRS_MATRIX,
+// ..., several of them wrong by construction) were removed from this file in round 6 (scripts/strip_switches.py; the device code of
+// the default build did not change by a byte); the builds behind profiles/r04 and profiles/r05 are those of commit ad410a6.
 #include <algorithm>
 #include <cmath>
 #include <cstdlib>
@@ -106,14 +107,9 @@ __device__ __forceinline__ void tc_jitter(unsigned& state) {
 #endif
 #define TC_BARRIER() asm volatile("s_barrier" ::: "memory"); TC_JITTER_HERE()
 // The helpers outrank the matrix waves (priority 2) while the conv loops wait for their chunks, and yield beside the w_v tiles,
-// where the matrix waves are the critical path and the helpers have time to spare.  -DTC_HPRIO_STATIC keeps them at 3 throughout.
-#ifdef TC_HPRIO_STATIC
-#define TC_HPRIO_LOW()
-#define TC_HPRIO_HIGH()
-#else
+// where the matrix waves are the critical path and the helpers have time to spare.
 #define TC_HPRIO_LOW() __builtin_amdgcn_s_setprio(1)
 #define TC_HPRIO_HIGH() __builtin_amdgcn_s_setprio(3)
-#endif
 // helper-side barrier with the PROF counters around it: `work` collects the time since the last tick, `wait` the time in the barrier
 #define HBAR_W(work, wait) GNN_TICK(work) TC_BARRIER_W(); GNN_TICK(wait)
 #define HBAR(work, wait) GNN_TICK(work) TC_BARRIER(); GNN_TICK(wait)
@@ -151,59 +147,6 @@ __device__ __forceinline__ void pair_fma16(const uint4& hx, const uint4& lx, con
     }
 }
 
-#ifdef TC_PAIRS_MATRIX
-// Round 5: the first two passes (128 of a step's ~134 entries per head) of the pair products run on the MATRIX waves, as fillers inside
-// their y @ w_v tiles: head A's beside w_v A (x1 in bufX), head B's beside w_v B (x3 in bufY) - the tiles read the same rows.  On the
-// helper waves they were 3.8 k cycles of the conv2 loop's critical path (profiles/r05/MODEL.md: NOPAIRS C -10 %); the matrix waves have
-// ~70 free registers in a w_v tile (48 + 64 + 48 of 256) and ~5 issue slots per MFMA gap.  One pass = 4 stages of 16 FMAs, one stage
-// per k16 unit of the tile, the stage's two 16-byte row reads requested a unit ahead; the weights of both passes are requested before
-// the preceding epilogue.  Same lane -> entry mapping, same instruction sequence per entry as on the helpers: bit-identical.
-struct MPair {
-    PairW w;
-    uint32_t xoff;          // LDS offset of the lane's 64-byte block (hi plane) of its row
-    int e;                  // entry, -1: none (the lane computes on a valid dummy and stores nothing)
-    float s0, s1, s2, s3;
-    uint4 hx, lx;
-};
-__device__ __forceinline__ void mpair_issue(MPair& q, const PairJob& jb, int buf_off, int k, int wave, int lane) {
-    const int e = jb.e + wave * 16 + (lane >> 2) + 64 * k;
-    const bool act = e < jb.e_end;
-    const int ec = min(e, NPAIR - 1);                      // inactive lanes read a valid entry's weights and row CARRY of the buffer
-    const int u = act ? jb.pos[ec] : jb.t0;
-    pair_load_w(q.w, jb, ec, lane & 3);
-    q.e = act ? e : -1;
-    q.xoff = (uint32_t)(buf_off + (CARRY + u - jb.t0) * ROWX + (lane & 3) * 64);
-    q.s0 = q.s1 = q.s2 = q.s3 = 0.f;
-}
-template <int I>
-__device__ __forceinline__ void mpair_load_x(MPair& q, const unsigned char* __restrict__ smem) {
-    q.hx = *reinterpret_cast<const uint4*>(smem + q.xoff + I * 16);
-    q.lx = *reinterpret_cast<const uint4*>(smem + q.xoff + LOX + I * 16);
-}
-template <int I>
-__device__ __forceinline__ void mpair_fma(MPair& q) {
-    pair_fma16(q.hx, q.lx, q.w.w[2 * I], q.w.w[2 * I + 1], q.s0, q.s1, q.s2, q.s3);
-}
-__device__ __forceinline__ void mpair_finish(const MPair& q, float* __restrict__ mp, int lane) {
-    float s = (q.s0 + q.s2) + (q.s1 + q.s3);
-    s += dpp_xor1(s);
-    s += dpp_xor2(s);
-    if (q.e >= 0 && (lane & 3) == 0) mp[q.e] = s;
-}
-// stage k (= k16 unit k of the tile): pass 0 in units 0 .. 3, pass 1 in units 4 .. 7; every stage requests the next stage's row slice
-template <int K>
-__device__ __forceinline__ void mpair_stage(MPair& q0, MPair& q1, const unsigned char* __restrict__ smem, float* __restrict__ mp, int lane) {
-    if constexpr (K < 4) {
-        mpair_fma<K>(q0);
-        if constexpr (K < 3) mpair_load_x<K + 1>(q0, smem);
-        else mpair_load_x<0>(q1, smem);
-    } else {
-        if constexpr (K == 4) mpair_finish(q0, mp, lane);
-        mpair_fma<K - 4>(q1);
-        if constexpr (K < 7) mpair_load_x<K - 3>(q1, smem);
-    }
-}
-#endif
 
 // ---------------------------------------------------------------- y @ w_v tiles (direct, 3 row blocks, as gnn_fused_x3.hip)
 struct XU {
@@ -235,29 +178,6 @@ __device__ __forceinline__ void wv_unit(const WU& wc, WU& wl, bool lw, const XU&
             if constexpr (!DROPWL) acc[mb] = mma(xc.h[mb], wc.l, acc[mb]);
         }
     }
-#ifdef TC_PROBE_WV_FILLERS   // pricing probe (round 5): TC_PROBE_WV_FILLERS v_fma_mix_f32 per k16 unit in the matrix waves' w_v tiles - what
-                             // the IGLOO pair products would cost there as fillers beside the MFMAs (with -DTC_ABL_NOPAIRS on the helpers)
-    {
-        float f0 = __uint_as_float(xc.h[0].x), f1 = __uint_as_float(xc.h[0].y), f2 = __uint_as_float(xc.l[0].x), f3 = __uint_as_float(xc.l[0].y);
-#pragma unroll
-        for (int i = 0; i < TC_PROBE_WV_FILLERS / 4; ++i) {
-            asm volatile("v_fma_mix_f32 %0, %1, %2, %0 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "+v"(f0) : "v"(wc.h.x), "v"(f1));
-            asm volatile("v_fma_mix_f32 %0, %1, %2, %0 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(f1) : "v"(wc.h.y), "v"(f2));
-            asm volatile("v_fma_mix_f32 %0, %1, %2, %0 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "+v"(f2) : "v"(wc.l.x), "v"(f3));
-            asm volatile("v_fma_mix_f32 %0, %1, %2, %0 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(f3) : "v"(wc.l.y), "v"(f0));
-        }
-        asm volatile("" ::"v"(f0), "v"(f1), "v"(f2), "v"(f3));
-    }
-#pragma unroll
-    for (int i = 0; i < (DROPWL ? 2 : 3) * NMB; ++i) {
-        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-        __builtin_amdgcn_sched_group_barrier(0x002, TC_PROBE_WV_FILLERS / 9, 0);
-        if (LX && i < 2 * NMB) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-        if (i == 1 || i == 5) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
-    }
-    GNN_REGION_END();
-}
-#else
     stage();                 // TC_PAIRS_MATRIX: this unit's slice of the pair products (16 FMAs + the next slice's two row reads); else empty
 #pragma unroll
     for (int i = 0; i < (DROPWL ? 2 : 3) * NMB; ++i) {
@@ -268,15 +188,11 @@ __device__ __forceinline__ void wv_unit(const WU& wc, WU& wl, bool lw, const XU&
     }
     GNN_REGION_END();
 }
-#endif
 // D = X W over the 96 rows that start at buffer row CARRY of `xoff`: a lane ends up with 16 rows of one channel per row block.
 // The ring's first RINGV - 1 units were requested by prime_wv.
 template <bool DROPWL = false, bool FILL = false, class StageFn>
 __device__ __forceinline__ void wv_tile(const unsigned char* __restrict__ smem, int xoff, wrsrc_t wr, int woff, WU (&ring)[RINGT],
                                         f32x16 (&acc)[NMB], int lane, StageFn&& stagefn) {
-#ifdef TC_ABL_NOWV
-    return;
-#endif
     uint32_t rowoff = (uint32_t)xoff + (uint32_t)(lane & 31) * ROWX + (uint32_t)(lane >> 5) * 16u;
     asm volatile("" : "+v"(rowoff));
     const unsigned char* xh = smem + rowoff;
@@ -331,20 +247,12 @@ struct XV {
 template <int VOFFN>
 __device__ __forceinline__ void xi_mma(const WU& wc, WU& wl, const XV& vc, XV& vl, const unsigned char* __restrict__ vb, wrsrc_t wr, int wnext,
                                        uint32_t l16, f32x16& acc) {
-#ifndef TC_ABL_NOVREAD
     vl.h = *reinterpret_cast<const uint4*>(vb + VOFFN);
     vl.l = *reinterpret_cast<const uint4*>(vb + VOFFN + 1024);
-#endif
-#ifndef TC_ABL_NOWEIGHTS
     load_wu(wl, wr, l16, wnext);
-#endif
-#ifndef TC_ABL_NOCONVMMA
     acc = mma(wc.l, vc.h, acc);            // D = U^T V: a lane ends up with 16 channels of one tile
     acc = mma(wc.h, vc.h, acc);
     acc = mma(wc.h, vc.l, acc);
-#else
-    asm volatile("" ::"v"(wc.l.x), "v"(wc.l.w), "v"(wc.h.x), "v"(wc.h.w), "v"(vc.h.x), "v"(vc.h.w), "v"(vc.l.x), "v"(vc.l.w));
-#endif
     __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
     __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
     __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
@@ -389,18 +297,7 @@ __device__ __forceinline__ void conv_tc(const unsigned char* __restrict__ smem, 
 template <bool F16>
 __device__ __forceinline__ void split2(f32x2 v, uint32_t& hi, uint32_t& lo) {
     hi = __builtin_bit_cast(uint32_t, __builtin_convertvector(v, f16x2));
-#ifndef TC_SPLIT_MIX
     lo = __builtin_bit_cast(uint32_t, __builtin_convertvector(f32x2{sub_f16_lo(v[0], hi), sub_f16_hi(v[1], hi)}, f16x2));
-#else
-    // A/B of round 5 (-DTC_SPLIT_MIX), measured NEGATIVE: residual and conversion in one instruction per value (v_fma_mixlo / mixhi_f16:
-    // the same bits, 3 instructions per pair instead of 4, 246 instead of 256 VGPRs) is 0.6 % SLOWER (20.73 vs 20.60 ms per 4096 windows,
-    // three alternating rounds on one box, cycles per step -0.15 %): the two partial-register writes form a dependent pair
-    asm("v_fma_mixlo_f16 %0, %1, -1.0, %2 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=v"(lo) : "v"(hi), "v"(v[0]));
-    asm("v_fma_mixhi_f16 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(lo) : "v"(hi), "v"(v[1]));
-#endif
-#ifdef TC_ALO_MASK     // energy probe (round 5): the low limbs of every activation operand with mantissa bits masked off (wrong results)
-    lo &= TC_ALO_MASK;
-#endif
 }
 
 // A^T of F(3,6) (oracle/toomcook.py) on TWO neighbouring accumulator registers of the 8 points at a time, then scale, bias,
@@ -412,19 +309,6 @@ __device__ __forceinline__ void split2(f32x2 v, uint32_t& hi, uint32_t& lo) {
 // runs beside the MFMA stream, where packed f32 is an anti-lever -, so the pairs are spelled out with 2-vectors here).
 __device__ __forceinline__ f32x2 pair_of(const f32x16& a, int r) { return f32x2{a[r], a[r + 1]}; }
 __device__ __forceinline__ void inverse3(const f32x16 (&acc)[NXI], int r, float inv_s, f32x2 bias, f32x2 (&y)[3]) {
-#ifdef TC_ABL_NOEPI            // the sums of A^T left out; scale, bias, LeakyReLU kept (magnitudes stay realistic), every accumulator kept alive
-    {
-#pragma unroll
-        for (int xi = 3; xi < NXI; ++xi) asm volatile("" ::"v"(acc[xi][r]), "v"(acc[xi][r + 1]));
-        const f32x2 sc = {inv_s, inv_s}, lr = {LRELU, LRELU};
-#pragma unroll
-        for (int i = 0; i < 3; ++i) {
-            const f32x2 v = __builtin_elementwise_fma(pair_of(acc[i], r), sc, bias), w = v * lr;
-            y[i] = f32x2{vmax_raw(v[0], w[0]), vmax_raw(v[1], w[1])};
-        }
-        return;
-    }
-#endif
     const f32x2 m0 = pair_of(acc[0], r), m1 = pair_of(acc[1], r), m2 = pair_of(acc[2], r), m3 = pair_of(acc[3], r);
     const f32x2 m4 = pair_of(acc[4], r), m5 = pair_of(acc[5], r), m6 = pair_of(acc[6], r), m7 = pair_of(acc[7], r);
     const f32x2 s12 = m1 + m2, d12 = m1 - m2, s34 = m3 + m4, d34 = m3 - m4, s56 = m5 + m6, d56 = m5 - m6;
@@ -525,24 +409,6 @@ __device__ __forceinline__ void bt8(const float (&d)[8], float (&v)[8]) {
 }
 template <bool X1>
 __device__ __forceinline__ void transform_store(const Raw16& r, const HLane& h, int slot) {
-#ifdef TC_ABL_NOTRANSFORM      // loads and stores only, data of a realistic magnitude
-    {
-        unsigned char* o = h.frag + slot * VSLOT;
-#pragma unroll
-        for (int xi = 0; xi < NXI; ++xi) {
-            uint32_t hi, lo;
-            if constexpr (X1) {
-                hi = r.a[xi], lo = r.b[xi];
-            } else {
-                hi = __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_pkrtz(__uint_as_float(r.a[xi]), __uint_as_float(r.b[xi])));
-                lo = hi & 0x83ff83ffu;
-            }
-            *reinterpret_cast<uint32_t*>(o + xi * 2048) = hi;
-            *reinterpret_cast<uint32_t*>(o + xi * 2048 + 1024) = lo;
-        }
-        return;
-    }
-#endif
     float d0[8], d1[8], v0[8], v1[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
@@ -574,20 +440,6 @@ struct GRow {
     f32x4 v[3][4];      // [table][i]: channels 16 pq + 4 i ..
 };
 __device__ __forceinline__ void grow_issue(GRow& g, const uint16_t* __restrict__ prow, const float* __restrict__ pt, int row, int pq) {
-#ifdef TC_ABL_NOGATHER
-    return;
-#endif
-#ifdef TC_ABL_GATHER_ONE       // one table row instead of three (a third of the gather's L2 traffic), data still window-dependent
-    {
-        const uint32_t r = prow[row];
-        const float* src = pt + (size_t)r * C + pq * 4;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) g.v[0][i] = *reinterpret_cast<const f32x4*>(src + i * 32);
-#pragma unroll
-        for (int i = 0; i < 4; ++i) g.v[1][i] = g.v[2][i] = g.v[0][i] * 0.5f;
-        return;
-    }
-#endif
 #pragma unroll
     for (int j = 0; j < 3; ++j) {
         const uint32_t r = prow[row + 2 * j];
@@ -600,11 +452,6 @@ struct GOut {         // a finished item: 16 channels as f16 hi | lo limbs, wait
     uint4 h0, h1, l0, l1;
 };
 __device__ __forceinline__ void grow_compute(GOut& o, const GRow& g) {
-#ifdef TC_ABL_NOGATHER
-    o.h0 = o.h1 = make_uint4(0x3c003800u, 0xb8003c00u, 0x38003a00u, 0xbc003400u);
-    o.l0 = o.l1 = make_uint4(0x10001100u, 0x90001200u, 0x11009000u, 0x12001000u);
-    return;
-#endif
     uint32_t hi[8], lo[8];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
@@ -661,9 +508,6 @@ struct PairPass {
     int u;
 };
 __device__ __forceinline__ void pass_issue(PairPass& pp, const PairJob& jb, int k, int wave, int lane) {
-#ifdef TC_ABL_NOPAIRS
-    return;
-#endif
     const int e = jb.e + wave * 16 + (lane >> 2) + 64 * k;
     pp.u = jb.t0;
     if (e < jb.e_end) {
@@ -672,18 +516,12 @@ __device__ __forceinline__ void pass_issue(PairPass& pp, const PairJob& jb, int 
     }
 }
 __device__ __forceinline__ void pass_compute(const PairPass& pp, const PairJob& jb, int k, int wave, int lane) {
-#ifdef TC_ABL_NOPAIRS
-    return;
-#endif
     const int e = jb.e + wave * 16 + (lane >> 2) + 64 * k;
     if (e < jb.e_end) PairCompute::run(pp.w, jb, e, pp.u, lane & 3);
     GNN_REGION_END();        // keeps the scheduler from hoisting the next pass's 8 row reads (32 registers) above this pass
 }
 // a crowded step (more than 3 passes; rare): the remaining passes one by one, loads not hidden
 __device__ __forceinline__ void pass_rest(PairPass& pp, const PairJob& jb, int k0, int wave, int lane) {
-#ifdef TC_ABL_NOPAIRS
-    return;
-#endif
     for (int e = jb.e + wave * 16 + (lane >> 2) + 64 * k0; e < jb.e_end; e += 64) {
         pair_load_w(pp.w, jb, e, lane & 3);
         PairCompute::run(pp.w, jb, e, jb.pos[e], lane & 3);
@@ -708,12 +546,7 @@ __global__ __launch_bounds__(512, 2) void fused_front_tc_kernel(Args a) {
     const int part = blockIdx.x % a.split;
     const uint8_t* bases = a.bases + wi * W;
     float* mp_w[2] = {a.mp + (wi * 2 + 0) * NPAIR, a.mp + (wi * 2 + 1) * NPAIR};
-#ifdef TC_PROBE_SAME_NBLK   // pricing probe (round 5; wrong results): all four matrix waves stream the SAME weight fragments (n-block 0), so three of
-                           // four requests hit the CU's vector L1 - how much of the weight stream's cost is L2 -> L1, how much L1 -> VGPR
-    const int woff = 0;
-#else
     const int woff = hw * WNBLK_B;
-#endif
 
     for (int i = tid; i < CARRY * ROW_U4; i += 512) {            // carry rows of the first step = the causal zero padding
         reinterpret_cast<uint4*>(bufX)[i] = make_uint4(0, 0, 0, 0);
@@ -773,14 +606,6 @@ __global__ __launch_bounds__(512, 2) void fused_front_tc_kernel(Args a) {
             conv_tc(smem, cw[0], woff, ring, acc, lane, jitter_state);                         // b_0 .. b_7, conv2
             GNN_TICK(0)
             prime_wv(ring, vw[0], woff, lane);
-#ifdef TC_PAIRS_MATRIX   // head A's first two passes (x1(s) stays in bufX until the gather behind b'_0): weights and positions requested here, used in w_v A
-            MPair qa0, qa1;
-            {
-                const PairJob ja = {bufX, a.weff[0], a.pos_sorted[0], mp_w[0], t0, store ? a.bucket_ptr[0][step] : 0, store ? a.bucket_ptr[0][step + 1] : 0};
-                mpair_issue(qa0, ja, 0, 0, hw, lane);
-                mpair_issue(qa1, ja, 0, 1, hw, lane);
-            }
-#endif
             epilogue_f32(bufY, acc, a.inv_s[0], bias_s, hw, lane);
             GNN_TICK(1)
             TC_BARRIER_W();                                                      // ---- B1: x2 is in bufY
@@ -791,20 +616,9 @@ __global__ __launch_bounds__(512, 2) void fused_front_tc_kernel(Args a) {
                 for (int mb = 0; mb < NMB; ++mb)
 #pragma unroll
                     for (int r = 0; r < 16; ++r) ac[mb][r] = 0.f;
-#if defined(TC_WVA_DROP)
-                wv_tile<true>(smem, CARRY * ROWX, vw[0], woff, ring, ac, lane, [](auto) {});
-#elif defined(TC_PAIRS_MATRIX)
-                mpair_load_x<0>(qa0, smem);
-                wv_tile<false, true>(smem, CARRY * ROWX, vw[0], woff, ring, ac, lane, [&](auto kc) { mpair_stage<decltype(kc)::value>(qa0, qa1, smem, mp_w[0], lane); });
-                mpair_finish(qa1, mp_w[0], lane);
-#else
                 wv_tile(smem, CARRY * ROWX, vw[0], woff, ring, ac, lane, [](auto) {});
-#endif
                 prime_tc(ring, cw[1], woff, lane);
                 if (store) wv_pool_store(ac, yp_w[0], t0, hw, lane);
-#ifdef TC_EMU_ONEBUF   // timing emulation of a single row buffer (round 5, MODEL.md): nothing overlaps the helpers' V3 chunks 0, 1
-                TC_BARRIER();
-#endif
             }
             GNN_TICK(3)
 #pragma unroll
@@ -814,20 +628,9 @@ __global__ __launch_bounds__(512, 2) void fused_front_tc_kernel(Args a) {
             conv_tc(smem, cw[1], woff, ring, acc, lane, jitter_state);                         // b'_0 .. b'_7, conv3
             GNN_TICK(4)
             prime_wv(ring, vw[1], woff, lane);
-#ifdef TC_PAIRS_MATRIX   // head B's first two passes (x3(s) in bufY from B0 to the next conv2 epilogue), used in w_v B
-            MPair qb0, qb1;
-            {
-                const PairJob jb = {bufY, a.weff[1], a.pos_sorted[1], mp_w[1], t0, store ? a.bucket_ptr[1][step] : 0, store ? a.bucket_ptr[1][step + 1] : 0};
-                mpair_issue(qb0, jb, BUF_BYTES, 0, hw, lane);
-                mpair_issue(qb1, jb, BUF_BYTES, 1, hw, lane);
-            }
-#endif
             epilogue_x3(bufY, acc, a.inv_s[1], bias_s + C, hw, lane);
             GNN_TICK(5)
             TC_BARRIER_W();                                                      // ---- B0: x3 is in bufY
-#ifdef TC_SLEEP_B0
-            __builtin_amdgcn_s_sleep(TC_SLEEP_B0);
-#endif
             GNN_TICK(6)
             {
                 f32x16 ac[NMB];
@@ -835,19 +638,9 @@ __global__ __launch_bounds__(512, 2) void fused_front_tc_kernel(Args a) {
                 for (int mb = 0; mb < NMB; ++mb)
 #pragma unroll
                     for (int r = 0; r < 16; ++r) ac[mb][r] = 0.f;
-#ifdef TC_PAIRS_MATRIX
-                mpair_load_x<0>(qb0, smem);
-                wv_tile<false, true>(smem, BUF_BYTES + CARRY * ROWX, vw[1], woff, ring, ac, lane, [&](auto kc) { mpair_stage<decltype(kc)::value>(qb0, qb1, smem, mp_w[1], lane); });
-                mpair_finish(qb1, mp_w[1], lane);
-#else
                 wv_tile(smem, BUF_BYTES + CARRY * ROWX, vw[1], woff, ring, ac, lane, [](auto) {});
-#endif
                 prime_tc(ring, cw[0], woff, lane);
                 if (store) wv_pool_store(ac, yp_w[1], t0, hw, lane);
-#ifdef TC_EMU_ONEBUF   // ... and x1(s+1) is stored between two barriers behind w_v B
-                TC_BARRIER();
-                TC_BARRIER();
-#endif
             }
         }
     } else {
@@ -922,40 +715,16 @@ __global__ __launch_bounds__(512, 2) void fused_front_tc_kernel(Args a) {
             // slack, and wait in 16 registers each for b'_0, behind which bufX may be written; round 2 runs beside conv3.
             GRow ga;
             GOut o0, o1;
-#ifndef TC_PAIRS_MATRIX
             pass_issue(p1, ja, 0, hw, lane);
-#endif
             grow_issue(ga, prow, a.conv1_k, grow0, gpq);
             HBAR_W(8, 9);                                                        // b_6
             pass_compute(p0, jbp, 2, hw, lane);                                  // head B's last pass of step s-1 (requested behind B0(s-1)):
             pass_rest(p0, jbp, 3, hw, lane);                                     // bufY holds x3(s-1) until the conv2 epilogue behind b_7
-#ifndef TC_PAIRS_MATRIX
             pass_issue(p0, ja, 1, hw, lane);
-#endif
-#ifdef TC_EMU_ONEBUF   // every reader of x1 is done before the conv2 epilogue (which would overwrite it): all of head A's passes before b_7
+            HBAR(8, 9);                                                          // b_7
             pass_compute(p1, ja, 0, hw, lane);
             pass_issue(p1, ja, 2, hw, lane);
             pass_compute(p0, ja, 1, hw, lane);
-            if (ht < CARRY * ROW_U4) carry = *reinterpret_cast<const uint4*>(bufX + (FTT + cr) * ROWX + cc * 16);
-            pass_compute(p1, ja, 2, hw, lane);
-            pass_rest(p1, ja, 3, hw, lane);
-            HBAR(8, 9);                                                          // b_7
-            grow_compute(o0, ga);
-            grow_issue(ga, prow, a.conv1_k, grow0 + 32, gpq);
-            HBAR(8, 10);                                                         // ---- B1
-            TC_BARRIER();                                                        // behind the matrix waves' w_v A
-            TC_HPRIO_LOW();
-            load_x2(ra, h2, 0);
-            load_x2(rb, h2, 1);
-#else
-            HBAR(8, 9);                                                          // b_7
-#ifdef TC_PAIRS_MATRIX   // passes 0, 1 run on the matrix waves (beside w_v A); the helpers keep the remainder of a step's entries (pass 2 ..)
-            pass_issue(p1, ja, 2, hw, lane);
-#else
-            pass_compute(p1, ja, 0, hw, lane);
-            pass_issue(p1, ja, 2, hw, lane);
-            pass_compute(p0, ja, 1, hw, lane);
-#endif
             if (ht < CARRY * ROW_U4) carry = *reinterpret_cast<const uint4*>(bufX + (FTT + cr) * ROWX + cc * 16);
             grow_compute(o0, ga);
             grow_issue(ga, prow, a.conv1_k, grow0 + 32, gpq);
@@ -966,7 +735,6 @@ __global__ __launch_bounds__(512, 2) void fused_front_tc_kernel(Args a) {
             load_x2(rb, h2, 1);
             pass_compute(p1, ja, 2, hw, lane);
             pass_rest(p1, ja, 3, hw, lane);
-#endif
             transform_store<false>(ra, h2, 0);
             load_x2(ra, h2, 2);
             transform_store<false>(rb, h2, 1);
@@ -1014,34 +782,20 @@ __global__ __launch_bounds__(512, 2) void fused_front_tc_kernel(Args a) {
             // head B's pair products of this step (x3 in bufY from B0 to the next conv2 epilogue): the first two passes requested
             // beside the conv3 epilogue; behind B0, beside the matrix waves' w_v B: pass 0, the third pass's request, pass 1, V2 chunks
             // 0, 1 of the next step, pass 2
-#ifndef TC_PAIRS_MATRIX
             pass_issue(p0, jb, 0, hw, lane);
             pass_issue(p1, jb, 1, hw, lane);
-#endif
             GNN_TICK(13)
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             HBAR(13, 11);                                                        // ---- B0: x3 is in bufY, x1(s+1) in bufX
-#ifdef TC_SLEEP_B0
-            __builtin_amdgcn_s_sleep(TC_SLEEP_B0);
-#endif
             TC_HPRIO_LOW();
             load_x1(ra, h1, 0);
             load_x1(rb, h1, 1);
-#ifdef TC_PAIRS_MATRIX
-            pass_issue(p0, jb, 2, hw, lane);
-#else
             pass_compute(p0, jb, 0, hw, lane);
             pass_issue(p0, jb, 2, hw, lane);
             pass_compute(p1, jb, 1, hw, lane);
-#endif
             transform_store<true>(ra, h1, 0);
             load_x1(ra, h1, 2);
             transform_store<true>(rb, h1, 1);
-#ifdef TC_EMU_ONEBUF
-            TC_BARRIER_W();
-            __builtin_amdgcn_s_sleep(6);                                         // ~400 cycles: 16 x ds_write_b128 per helper lane
-            TC_BARRIER();
-#endif
             GNN_TICK(15)
         }
         if (s_hi > s_lo) {                                  // head B's last pass of this run's last step
