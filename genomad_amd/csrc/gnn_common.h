@@ -100,6 +100,7 @@ struct DeviceWeights {
     int32_t* bucket_ptr96[2] = {nullptr, nullptr};
     float* tc_yp_const = nullptr;
     float* tc_mp_const = nullptr;
+    float* tc_wva_tbl = nullptr;    // head A's y @ w_v per 9-mer: gnn_fused_tc.hip, WvaTable (1.38 GB)
     float* x3_yp_const[2] = {nullptr, nullptr};   // the same of gnn_fused_x3.hip: [0] bf16 limbs, [1] f16 limbs
     float* x3_mp_const[2] = {nullptr, nullptr};
 };

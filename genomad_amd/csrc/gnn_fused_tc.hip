@@ -80,6 +80,7 @@ struct Args {
     const float* weff[2];
     const int32_t* pos_sorted[2];
     const int32_t* bucket_ptr[2];     // (STEPST + 1,) entry ranges per 96-row step
+    const unsigned char* wva_tbl;     // head A's y @ w_v per 9-mer (WvaTable below)
     float* mp;
     float* yp;
     const float* yp_c;                // outputs of an all-N window (padding skip), nullptr = compute everything
@@ -237,6 +238,84 @@ __device__ __forceinline__ void wv_pool_store(const f32x16 (&acc)[NMB], wrsrc_t 
 #pragma unroll
         for (int i = 0; i < 4 * NMB; ++i)
             if (i < nq) __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(m[i]), yp_w, voff, (q0 + i) * (C * 4), 0);
+    }
+}
+
+// ---------------------------------------------------------------- head A's y @ w_v as a table lookup (round 6)
+// x1[t] = LeakyReLU(conv1) (model.py:11, igloo.py:45-48) is a function of the tokens t-5 .. t, i.e. of the NINE bases t-5 .. t+3, so
+// head A's y @ w_v row (igloo.py:208) is too: the matrix waves no longer compute it (288 of a step's 2 112 MFMAs per CU, 8 % of the
+// launch's energy, profiles/r05/MODEL.md) but gather it - one 512-byte row per position - from tables that gnn_load_weights builds on
+// the device (x1 exactly as the gather below makes it, the 128 x 128 product accumulated in f64 and rounded once: closer to the
+// reference's f32 than the three f16 products were) and take the 8-row maximum (igloo.py:209-210) in registers:
+//   D4  4^9 rows     all nine bases in ACGT, t >= 5: index = the 9-mer, first base most significant (128 MiB: the rows every window reads)
+//   S5  5^4 .. 5^8   the first five positions of a window (tokens before the window start are absent, not N): bases 0 .. t+3 in base 5
+//   D5  5^9 rows     t >= 5 with a non-ACGT base among the nine (digit 4)
+// One allocation [D4 | S5 | D5] of 2 703 394 rows = 1.38 GB, one buffer resource; a window's 5 992 pooled positions read 3.07 MB of it.
+struct WvaTable {
+    static constexpr uint32_t D4_ROWS = 262144u, S5_ROWS = 625u + 3125u + 15625u + 78125u + 390625u, D5_ROWS = 1953125u;
+    static constexpr uint32_t S5_OFF = D4_ROWS, D5_OFF = D4_ROWS + S5_ROWS, ROWS = D4_ROWS + S5_ROWS + D5_ROWS;
+    static constexpr uint32_t ROW_BYTES = C * 4;
+    __host__ __device__ static constexpr uint32_t s5_off(int t) { return S5_OFF + (t == 0 ? 0u : t == 1 ? 625u : t == 2 ? 3750u : t == 3 ? 19375u : 97500u); }
+};
+constexpr int WVA_ROWS_PER_WAVE = FTT / 4;    // 24 rows = 3 pooled rows per matrix wave and step
+struct WvaBytes {
+    uint32_t x0, x1, x2;       // the 12 aligned bytes that hold bases t-5 .. t+3 of the lane's row
+};
+// lane l < 24 of matrix wave hw owns row t0 + 24 hw + l; rows past the last token (the last step's tail) are never pooled: clamped
+__device__ __forceinline__ int wva_row(int t0, int hw, int lane) { return min(t0 + WVA_ROWS_PER_WAVE * hw + min(lane, WVA_ROWS_PER_WAVE - 1), T - 1); }
+__device__ __forceinline__ void wva_fetch(WvaBytes& b, const uint8_t* __restrict__ bases, int t) {
+    const uint32_t* src = reinterpret_cast<const uint32_t*>(bases + (max(t - 5, 0) & ~3));      // <= W - 12: windows start 4-byte aligned
+    b.x0 = src[0];
+    b.x1 = src[1];
+    b.x2 = src[2];
+}
+// table row of position t.  Branch-free: digit of a byte = ((b >> 1) & 3) ^ ((b >> 2) & 1) for A, C, G, T (65, 67, 71, 84 -> 0, 1, 2, 3:
+// the order of sequence.py:170-193), 4 for every other byte
+__device__ __forceinline__ uint32_t wva_digit(uint32_t byte) {
+    const uint32_t x = byte - 65u, c = (byte >> 1) & 3u;
+    const bool acgt = x < 20u && ((0x80045u >> (x & 31u)) & 1u);
+    return acgt ? (c ^ (c >> 1)) : 4u;
+}
+__device__ __forceinline__ uint32_t wva_index(const WvaBytes& b, int t) {
+    const int q = max(t - 5, 0), sh = q & 3, np = min(t, 5) + 4;            // np bases are present: all 9 from position 5 on
+    const uint32_t w0 = __builtin_amdgcn_alignbyte(b.x1, b.x0, (uint32_t)sh), w1 = __builtin_amdgcn_alignbyte(b.x2, b.x1, (uint32_t)sh),
+                   w2 = b.x2 >> (8 * sh);
+    uint32_t i4 = 0, i5 = 0, worst = 0;
+#pragma unroll
+    for (int k = 0; k < 9; ++k) {
+        const uint32_t d = wva_digit(((k < 4 ? w0 : k < 8 ? w1 : w2) >> (8 * (k & 3))) & 255u);
+        i4 = i4 * 4u + (d & 3u);
+        const uint32_t n5 = i5 * 5u + d;
+        i5 = k < np ? n5 : i5;
+        worst = max(worst, d);
+    }
+    // t < 5: the bytes behind the np present ones are ordinary bases of the window; they only decide `worst`, which is not used then
+    return t < 5 ? WvaTable::s5_off(t) + i5 : (worst < 4u ? i4 : WvaTable::D5_OFF + i5);
+}
+struct WvaRows {
+    u32x2 v[WVA_ROWS_PER_WAVE];     // 24 table rows, two channels per lane
+};
+// all 24 row requests of a wave: 64 lanes x 8 B = one 512-byte row per instruction, the row's byte offset in an SGPR
+__device__ __forceinline__ void wva_issue(WvaRows& r, wrsrc_t tbl, uint32_t my_row, int lane) {
+    const uint32_t l8 = (uint32_t)lane * 8u;
+#pragma unroll
+    for (int i = 0; i < WVA_ROWS_PER_WAVE; ++i) {
+        const uint32_t row = __builtin_amdgcn_readlane(my_row, i);
+        r.v[i] = __builtin_amdgcn_raw_buffer_load_b64(tbl, l8, row * WvaTable::ROW_BYTES, 0);
+    }
+}
+// MaxPool1D(8) over the gathered rows -> 3 pooled rows of yp (igloo.py:209-210)
+__device__ __forceinline__ void wva_pool_store(const WvaRows& r, wrsrc_t yp_w, int t0, int hw, int lane) {
+    const int q0 = t0 / GNN_POOL + 3 * hw;
+#pragma unroll
+    for (int p = 0; p < 3; ++p) {
+        float m0 = __uint_as_float(r.v[8 * p][0]), m1 = __uint_as_float(r.v[8 * p][1]);
+#pragma unroll
+        for (int j = 1; j < 8; ++j) {
+            m0 = max_nan(m0, __uint_as_float(r.v[8 * p + j][0]));
+            m1 = max_nan(m1, __uint_as_float(r.v[8 * p + j][1]));
+        }
+        if (q0 + p < POOLED) __builtin_amdgcn_raw_buffer_store_b64(u32x2{__float_as_uint(m0), __float_as_uint(m1)}, yp_w, (uint32_t)lane * 8u, (q0 + p) * (C * 4), 0);
     }
 }
 
@@ -586,11 +665,14 @@ __global__ __launch_bounds__(512, 2) void fused_front_tc_kernel(Args a) {
     if (!helper) {
         __builtin_amdgcn_s_setprio(2);
         const wrsrc_t cw[2] = {make_wrsrc(a.tcw[0], 64 * WUNIT_B), make_wrsrc(a.tcw[1], 64 * WUNIT_B)};
-        const wrsrc_t vw[2] = {make_wrsrc(a.wv_w[0], 8 * WUNIT_B), make_wrsrc(a.wv_w[1], 8 * WUNIT_B)};
+        const wrsrc_t vw = make_wrsrc(a.wv_w[1], 8 * WUNIT_B);            // head A's w_v is inside the table
+        const wrsrc_t tblr = make_wrsrc(a.wva_tbl, (int)(WvaTable::ROWS * WvaTable::ROW_BYTES));
         const wrsrc_t yp_w[2] = {make_wrsrc(reinterpret_cast<const unsigned char*>(a.yp + (wi * 2 + 0) * (size_t)POOLED * C), POOLED * C * 4),
                                  make_wrsrc(reinterpret_cast<const unsigned char*>(a.yp + (wi * 2 + 1) * (size_t)POOLED * C), POOLED * C * 4)};
         WU ring[RINGT];
         prime_tc(ring, cw[0], woff, lane);
+        WvaBytes wb;                                                             // the bases behind this lane's table row, fetched a step ahead
+        wva_fetch(wb, bases, wva_row(s_begin * FTT, hw, lane));
         __syncthreads();                                                         // x1 of the first step is in bufX
         if constexpr (PROF) tick_ = __builtin_readcyclecounter();
 #pragma unroll 1
@@ -605,21 +687,19 @@ __global__ __launch_bounds__(512, 2) void fused_front_tc_kernel(Args a) {
             GNN_TICK(7)
             conv_tc(smem, cw[0], woff, ring, acc, lane, jitter_state);                         // b_0 .. b_7, conv2
             GNN_TICK(0)
-            prime_wv(ring, vw[0], woff, lane);
+            // head A's y @ w_v rows of this step: requested here (the weight ring's registers are free), pooled behind B1 - the round
+            // trip to the Infinity Cache / HBM hides behind the epilogue.  (Unconditional: with the requests behind `if (store)` the register
+            // allocator spills 8 of the 24 rows - and waits for each - although 40 registers are free; a warm-up step of a time-split
+            // run reads its rows for nothing.)
+            WvaRows wr;
+            wva_issue(wr, tblr, wva_index(wb, wva_row(t0, hw, lane)), lane);
+            wva_fetch(wb, bases, wva_row(t0 + FTT, hw, lane));
             epilogue_f32(bufY, acc, a.inv_s[0], bias_s, hw, lane);
             GNN_TICK(1)
             TC_BARRIER_W();                                                      // ---- B1: x2 is in bufY
             GNN_TICK(2)
-            {
-                f32x16 ac[NMB];
-#pragma unroll
-                for (int mb = 0; mb < NMB; ++mb)
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) ac[mb][r] = 0.f;
-                wv_tile(smem, CARRY * ROWX, vw[0], woff, ring, ac, lane, [](auto) {});
-                prime_tc(ring, cw[1], woff, lane);
-                if (store) wv_pool_store(ac, yp_w[0], t0, hw, lane);
-            }
+            if (store) wva_pool_store(wr, yp_w[0], t0, hw, lane);
+            prime_tc(ring, cw[1], woff, lane);
             GNN_TICK(3)
 #pragma unroll
             for (int xi = 0; xi < NXI; ++xi)
@@ -627,7 +707,7 @@ __global__ __launch_bounds__(512, 2) void fused_front_tc_kernel(Args a) {
                 for (int r = 0; r < 16; ++r) acc[xi][r] = 0.f;
             conv_tc(smem, cw[1], woff, ring, acc, lane, jitter_state);                         // b'_0 .. b'_7, conv3
             GNN_TICK(4)
-            prime_wv(ring, vw[1], woff, lane);
+            prime_wv(ring, vw, woff, lane);
             epilogue_x3(bufY, acc, a.inv_s[1], bias_s + C, hw, lane);
             GNN_TICK(5)
             TC_BARRIER_W();                                                      // ---- B0: x3 is in bufY
@@ -638,7 +718,7 @@ __global__ __launch_bounds__(512, 2) void fused_front_tc_kernel(Args a) {
                 for (int mb = 0; mb < NMB; ++mb)
 #pragma unroll
                     for (int r = 0; r < 16; ++r) ac[mb][r] = 0.f;
-                wv_tile(smem, BUF_BYTES + CARRY * ROWX, vw[1], woff, ring, ac, lane, [](auto) {});
+                wv_tile(smem, BUF_BYTES + CARRY * ROWX, vw, woff, ring, ac, lane, [](auto) {});
                 prime_tc(ring, cw[0], woff, lane);
                 if (store) wv_pool_store(ac, yp_w[1], t0, hw, lane);
             }
@@ -824,6 +904,59 @@ __global__ __launch_bounds__(512, 2) void fused_front_tc_kernel(Args a) {
     }
 }
 
+// Builds WvaTable: one workgroup = 128 channels x WVA_BUILD_ROWS consecutive table rows.  x1 of a row exactly as grow_compute makes it
+// (the same three pair-table rows in the same order, LeakyReLU as max(v, 0.1 v)), then y[c] = sum_k x1[k] w_v[k][c] accumulated in f64
+// and rounded to f32 once.
+constexpr int WVA_BUILD_ROWS = 64;
+__global__ __launch_bounds__(128) void wva_table_kernel(const float* __restrict__ pairs6, const float* __restrict__ w_v, float* __restrict__ tbl) {
+    __shared__ float xs[C];
+    const int c = threadIdx.x;
+    float wcol[C];
+#pragma unroll
+    for (int k = 0; k < C; ++k) wcol[k] = w_v[k * C + c];
+    const int perm = ((c >> 2) & 3) * 32 + (c >> 4) * 4 + (c & 3);          // channel 16 pq + 4 i + e of a pair-table row (pack_fused_c6_weights)
+    const uint32_t r_end = min((uint32_t)(blockIdx.x + 1) * WVA_BUILD_ROWS, WvaTable::ROWS);
+    for (uint32_t row = blockIdx.x * WVA_BUILD_ROWS; row < r_end; ++row) {
+        // the row's nine base slots (positions t-5 .. t+3): 0..3 = ACGT, 4 = any other byte, -1 = before the window start
+        int dig[9];
+        if (row < WvaTable::D4_ROWS) {
+#pragma unroll
+            for (int i = 0; i < 9; ++i) dig[i] = (int)((row >> (2 * (8 - i))) & 3u);
+        } else {
+            int nabs = 0;
+            uint32_t idx = row - WvaTable::D5_OFF;
+            if (row < WvaTable::D5_OFF) {
+                int t = 4;
+                while (row < WvaTable::s5_off(t)) --t;
+                nabs = 5 - t;
+                idx = row - WvaTable::s5_off(t);
+            }
+#pragma unroll
+            for (int i = 8; i >= 0; --i) {
+                dig[i] = i >= nabs ? (int)(idx % 5u) : -1;
+                if (i >= nabs) idx /= 5u;
+            }
+        }
+        int tk[6];
+#pragma unroll
+        for (int i = 0; i < 6; ++i) {
+            const int d0 = dig[i], d1 = dig[i + 1], d2 = dig[i + 2], d3 = dig[i + 3];
+            tk[i] = d0 < 0 ? -1 : ((d0 | d1 | d2 | d3) & 4) ? 0 : 1 + d0 * 64 + d1 * 16 + d2 * 4 + d3;
+        }
+        float v[3];
+#pragma unroll
+        for (int j = 0; j < 3; ++j) v[j] = pairs6[((size_t)j * PAIR_ROWS + pair_row(tk[2 * j], tk[2 * j + 1])) * C + perm];
+        const float t = v[0] + v[1] + v[2];
+        xs[c] = vmax_raw(t, t * LRELU);
+        __syncthreads();
+        double acc = 0.0;
+#pragma unroll
+        for (int k = 0; k < C; ++k) acc = __builtin_fma((double)xs[k], (double)wcol[k], acc);
+        tbl[(size_t)row * C + c] = (float)acc;
+        __syncthreads();
+    }
+}
+
 static void fill_args(const gnn_ctx* ctx, Args& a, const uint8_t* bases) {
     const DeviceWeights& d = ctx->w;
     a.bases = bases;
@@ -837,6 +970,7 @@ static void fill_args(const gnn_ctx* ctx, Args& a, const uint8_t* bases) {
         a.pos_sorted[i] = d.pos_sorted[i];
         a.bucket_ptr[i] = d.bucket_ptr96[i];
     }
+    a.wva_tbl = reinterpret_cast<const unsigned char*>(d.tc_wva_tbl);
     a.cycles = nullptr;
     a.split = 1;
 }
@@ -926,6 +1060,22 @@ int pack_fused_tc_weights(gnn_ctx* ctx, const gnn_weights* w) {
         ctx->owned.push_back(p);
         GNN_HIP(hipMemcpy(p, ptr.data(), ptr.size() * 4, hipMemcpyHostToDevice));
         d.bucket_ptr96[h] = static_cast<int32_t*>(p);
+    }
+    // head A's y @ w_v table (WvaTable): 1.38 GB, built on the device from the pair tables and w_v A
+    {
+        void* p = nullptr;
+        const size_t bytes = (size_t)WvaTable::ROWS * WvaTable::ROW_BYTES;
+        hipError_t e = hipMalloc(&p, bytes);
+        if (e != hipSuccess) {
+            (void)hipGetLastError();
+            set_error("hipMalloc of the " + std::to_string(bytes >> 20) + " MiB table of head A's y @ w_v rows failed: " + hipGetErrorString(e));
+            return GNN_ERR_NOMEM;
+        }
+        ctx->owned.push_back(p);
+        d.tc_wva_tbl = static_cast<float*>(p);
+        hipLaunchKernelGGL(wva_table_kernel, dim3((WvaTable::ROWS + WVA_BUILD_ROWS - 1) / WVA_BUILD_ROWS), dim3(128), 0, ctx->stream, d.conv1_pairs6,
+                           d.w_v[0], d.tc_wva_tbl);
+        GNN_HIP(hipGetLastError());
     }
     // the all-N window's outputs, computed once by the kernel itself (padding skip)
     void* bn = nullptr;
