@@ -15,13 +15,17 @@ WINDOW, TOKENS, DEPTH, CH = 6000, 5997, 257, 128
 PATCHES, PATCH_SIZE, POOLED, FEAT, HIDDEN, CLASSES = 2100, 4, 749, 256, 512, 3
 
 PREC_F32, PREC_BF16X3, PREC_BF16, PREC_F16C8, PREC_F16X3, PREC_F16C6, PREC_F16X3TC = 0, 1, 2, 3, 4, 5, 6
-PRECISIONS = {"f32": PREC_F32, "bf16x3": PREC_BF16X3, "bf16": PREC_BF16, "f16c8": PREC_F16C8, "f16x3": PREC_F16X3,
-              "f16c6": PREC_F16C6, "f16x3tc": PREC_F16X3TC}
+# PREC_BF16 (single bf16 pass) and PREC_F16C8 (f16 + fp8 corrections) were removed in round 6: both fail the 1e-4 tolerance; the
+# library keeps the enum values and answers GNN_ERR_STATE, the Python side no longer knows their names
+PRECISIONS = {"f32": PREC_F32, "bf16x3": PREC_BF16X3, "f16x3": PREC_F16X3, "f16c6": PREC_F16C6, "f16x3tc": PREC_F16X3TC}
+# Arithmetics that are KNOWN to leave the 1e-4 score tolerance at scale (f16c6: 1.2e-4 on a few of 10^6 windows, profiles/history/
+# r02c6_tails.txt): selectable for measurements only - main() refuses them unless GENOMAD_AMD_ALLOW_OUT_OF_TOLERANCE=1 is set
+OUT_OF_TOLERANCE = {"f16c6": 1.2e-4}
 # Arithmetic of the fused front end when the caller names none.  "f16x3tc" (round 4): split-f16 limbs, three MFMA products per operand
 # pair, conv2 / conv3 by Toom-Cook F(3,6) minimal filtering over time (0.444x their MFMAs, f32 transforms), split-f16 logits GEMM and
 # exact-f32 dense head.  Class scores within 2e-5 (weight seed 42) / 4e-5 (seed 43) of the exact-f32 path on every one of 1 M windows -
 # the figures of "f16x3", the direct three-pass form it replaced as the default (profiles/r04_tails.txt) - and 1.16x its speed.
-# "f16c6" / "f16c8" (f16 + 4-bit correction MFMAs) stay opt-in: 1.2e-4 on a handful of 10^6 windows.  "bf16x3": f32 range; "f32": exact.
+# "f16c6" (f16 + 4-bit correction MFMAs) stays opt-in behind OUT_OF_TOLERANCE: 1.2e-4 on a handful of 10^6 windows.  "bf16x3": f32 range; "f32": exact.
 DEFAULT_PRECISION = "f16x3tc"
 OH_U8, OH_BF16, OH_F32 = 0, 1, 2
 K_FUSED, K_BACKEND, K_ENCODER, K_F32_FRONT = 0, 1, 2, 3
@@ -64,6 +68,7 @@ SIGNATURES = {
     "gnn_sync": (_int, [_vp]),
     "gnn_device_info": (_int, [_vp, C.c_char_p, _sz, C.POINTER(_int), C.POINTER(_i64)]),
     "gnn_device_mem_info": (_int, [_vp, C.POINTER(_i64), C.POINTER(_i64)]),
+    "gnn_device_pci_bus_id": (_int, [_vp, C.c_char_p, _sz]),
     "gnn_load_weights": (_int, [_vp, C.POINTER(Weights)]),
     "gnn_dev_alloc": (_int, [_vp, _sz, C.POINTER(_vp)]),
     "gnn_dev_free": (_int, [_vp, _vp]),

@@ -15,7 +15,7 @@ static thread_local std::string g_last_error;
 void set_error(const std::string& msg) { g_last_error = msg; }
 
 // Debug / measurement switches read from the environment (GNN_ASYNC_EVENT_WAIT, GNN_NO_BACKEND_OVERLAP, GNN_BACKEND_OVERLAP, GNN_DEBUG_POISON,
-// GNN_X3_ROUND1, GNN_NO_PAD_SKIP, GNN_NO_TIME_SPLIT, GNN_LOGITS_F32): each is read ONCE per process, and a switch that is set says so on stderr -
+// GNN_NO_PAD_SKIP, GNN_NO_TIME_SPLIT, GNN_LOGITS_F32): each is read ONCE per process, and a switch that is set says so on stderr -
 // a stray variable in a user's environment must not silently change ordering or arithmetic.
 bool debug_switch(const char* name) {
     static std::mutex mu;
@@ -306,8 +306,13 @@ int classify_chunks(gnn_ctx* ctx, const uint8_t* bases_dev, int64_t n, int preci
         set_error("gnn_load_weights has not been called");
         return GNN_ERR_STATE;
     }
-    if (precision != GNN_PREC_F32 && precision != GNN_PREC_BF16X3 && precision != GNN_PREC_BF16 &&
-        precision != GNN_PREC_F16C8 && precision != GNN_PREC_F16X3 && precision != GNN_PREC_F16C6 && precision != GNN_PREC_F16X3TC) {
+    if (precision == GNN_PREC_BF16 || precision == GNN_PREC_F16C8) {
+        set_error(std::string(precision == GNN_PREC_BF16 ? "GNN_PREC_BF16" : "GNN_PREC_F16C8") +
+                  " was removed in round 6 (it fails the 1e-4 score tolerance; the enum value is kept so that old callers get this error)");
+        return GNN_ERR_STATE;
+    }
+    if (precision != GNN_PREC_F32 && precision != GNN_PREC_BF16X3 && precision != GNN_PREC_F16X3 && precision != GNN_PREC_F16C6 &&
+        precision != GNN_PREC_F16X3TC) {
         set_error("unknown precision " + std::to_string(precision));
         return GNN_ERR_ARG;
     }
@@ -353,8 +358,17 @@ int classify_chunks(gnn_ctx* ctx, const uint8_t* bases_dev, int64_t n, int preci
         if ((rc = flush_backend(ctx))) return rc;
     }
     bool overlap = allow_overlap && !f32 && ((chunk_overlap && n > chunk) || defer_last || pending);
+    // a second workspace of `chunk` windows did not fit before: do not try again (up to six failing hipMallocs and a synchronisation
+    // of both streams per call) until a smaller launch shape is asked for - the asynchronous path runs in order on one workspace
+    if (overlap && ctx->alt_failed_chunk > 0 && chunk >= ctx->alt_failed_chunk && ctx->ws_alt.chunk < chunk) {
+        if ((rc = flush_backend(ctx))) return rc;
+        overlap = false;
+    }
     if (overlap && (rc = ensure_ws(ctx, ctx->ws_alt, chunk, 0)) == GNN_ERR_NOMEM) {
         // no room for the second workspace (the asynchronous path costs 2 x the workspace): run in order on one
+        std::fprintf(stderr, "libgenomad_nn_hip: no device memory for the second workspace of %lld windows: asynchronous calls run in order "
+                     "(back end not overlapped) from here on\n", (long long)chunk);
+        ctx->alt_failed_chunk = chunk;
         if ((rc = flush_backend(ctx))) return rc;
         overlap = false;
     } else if (rc) {
@@ -377,6 +391,24 @@ int classify_chunks(gnn_ctx* ctx, const uint8_t* bases_dev, int64_t n, int preci
     for (int64_t a = 0; a < n; a += chunk) {
         const int64_t m = std::min(chunk, n - a);
         const uint8_t* b = bases_dev + a * W;
+        // A window buffer that is not 4-byte aligned (possible only for device pointers a caller offsets by hand; W is a multiple of
+        // 4, so every chunk of it is misaligned alike): the streaming kernels fetch bases as aligned dwords, so the chunk goes through
+        // one aligned staging copy (6 KB per window, on the stream the front end runs on) and then through the SAME kernel - the
+        // scores do not depend on where the caller's buffer starts (nn_classification.py:316-317: any batch, any offset).
+        if (!f32 && (reinterpret_cast<uintptr_t>(b) & 3u)) {
+            if (ctx->align_windows < m) {
+                GNN_HIP(hipStreamSynchronize(guard.main));
+                if (ctx->align_buf) (void)hipFree(ctx->align_buf);
+                ctx->align_buf = nullptr;
+                ctx->align_windows = 0;
+                void* q = nullptr;
+                if ((rc = dev_buffer(ctx, (size_t)chunk * W, &q))) return rc;
+                ctx->align_buf = static_cast<uint8_t*>(q);
+                ctx->align_windows = chunk;
+            }
+            GNN_HIP(hipMemcpyAsync(ctx->align_buf, b, (size_t)m * W, hipMemcpyDeviceToDevice, guard.main));
+            b = ctx->align_buf;
+        }
         const int buf = ctx->buf_cur;
         if (overlap && ctx->back_pending[buf]) {      // the back end that last used this workspace
             GNN_HIP(hipStreamWaitEvent(guard.main, ctx->ev_back[buf], 0));
@@ -404,20 +436,9 @@ int classify_chunks(gnn_ctx* ctx, const uint8_t* bases_dev, int64_t n, int preci
             if ((rc = launch_front_f32(ctx, b, m))) return rc;
         } else {
             ProfScope ps(ctx, GNN_K_FUSED);
-            // the three-pass modes run the streaming kernel of gnn_fused_x3.hip; the round-1 kernel (gnn_fused.hip) keeps the
-            // single-pass bf16 mode, window buffers that are not 4-byte aligned, and GNN_X3_ROUND1=1 (A/B measurements)
-            static const bool x3_round1 = debug_switch("GNN_X3_ROUND1");
-            const bool x3 = (precision == GNN_PREC_F16X3 || precision == GNN_PREC_BF16X3) && !x3_round1 &&
-                            !(reinterpret_cast<uintptr_t>(b) & 3u);
-            // a window buffer that is not 4-byte aligned (possible only for device pointers a caller offsets by hand): the
-            // Toom-Cook kernel fetches bases as aligned dwords; the round-1 kernel (byte loads) computes the direct f16x3 form
-            const bool tc = precision == GNN_PREC_F16X3TC && !(reinterpret_cast<uintptr_t>(b) & 3u);
-            rc = tc                              ? launch_front_tc(ctx, b, m)
-                 : precision == GNN_PREC_F16X3TC ? launch_front_fused(ctx, b, m, GNN_PREC_F16X3)
-                 : precision == GNN_PREC_F16C6   ? launch_front_c6(ctx, b, m)
-                 : precision == GNN_PREC_F16C8 ? launch_front_c8(ctx, b, m)
-                 : x3                          ? launch_front_x3(ctx, b, m, precision)
-                                               : launch_front_fused(ctx, b, m, precision);
+            rc = precision == GNN_PREC_F16X3TC ? launch_front_tc(ctx, b, m)
+                 : precision == GNN_PREC_F16C6 ? launch_front_c6(ctx, b, m)
+                                               : launch_front_x3(ctx, b, m, precision);       // GNN_PREC_F16X3 / GNN_PREC_BF16X3
             if (rc) return rc;
         }
         if (overlap) {
@@ -500,7 +521,7 @@ int gnn_fused_rows_per_step(int precision) {
         case GNN_PREC_F32: return 0;
         case GNN_PREC_F16C6: return c6_rows_per_step();
         case GNN_PREC_F16X3TC: return 96;
-        case GNN_PREC_BF16X3: case GNN_PREC_BF16: case GNN_PREC_F16C8: case GNN_PREC_F16X3: return FT;
+        case GNN_PREC_BF16X3: case GNN_PREC_F16X3: return FT;
         default: return GNN_ERR_ARG;
     }
 }
@@ -590,6 +611,7 @@ int gnn_destroy(gnn_ctx* ctx) {
     if (ctx->comm || ctx->comm_scratch) (void)gnn_comm_destroy(ctx);
     free_contig_ws(ctx);
     free_stage(ctx);
+    if (ctx->align_buf) (void)hipFree(ctx->align_buf);
     free_ws(ctx->ws);
     free_ws(ctx->ws_alt);
     if (ctx->stream2) {
@@ -630,6 +652,17 @@ int gnn_device_info(gnn_ctx* ctx, char* name, size_t name_len, int* cus, int64_t
     }
     if (cus) *cus = prop.multiProcessorCount;
     if (hbm_bytes) *hbm_bytes = (int64_t)prop.totalGlobalMem;
+    return GNN_OK;
+}
+
+int gnn_device_pci_bus_id(gnn_ctx* ctx, char* out, size_t out_len) {
+    int rc = check_ctx(ctx, false);
+    if (rc) return rc;
+    if (!out || out_len < 16) {
+        set_error("gnn_device_pci_bus_id: out must hold at least 16 bytes");
+        return GNN_ERR_ARG;
+    }
+    GNN_HIP(hipDeviceGetPCIBusId(out, (int)out_len, ctx->device));
     return GNN_OK;
 }
 
@@ -751,7 +784,6 @@ int gnn_load_weights(gnn_ctx* ctx, const gnn_weights* w) {
     if ((rc = upload(ctx, w->out_kernel, (size_t)HID * GNN_CLASSES, &d.d3_k))) return rc;
     if ((rc = upload(ctx, w->out_bias, (size_t)GNN_CLASSES, &d.d3_b))) return rc;
     if ((rc = pack_fused_weights(ctx, w))) return rc;
-    if ((rc = pack_fused_c8_weights(ctx, w))) return rc;
     if ((rc = pack_fused_c6_weights(ctx, w))) return rc;
     if ((rc = pack_fused_x3_consts(ctx))) return rc;
     if ((rc = pack_fused_tc_weights(ctx, w))) return rc;
@@ -912,6 +944,12 @@ int gnn_debug_forward(gnn_ctx* ctx, const uint8_t* bases_host, int64_t n, int pr
             GNN_HIP(hipStreamSynchronize(ctx->stream));
             std::memcpy(scores_host + a0 * GNN_CLASSES, ctx->stage_scores_host, (size_t)m * GNN_CLASSES * sizeof(float));
         }
+    }
+    if (!rc && taps && precision != GNN_PREC_F32 && n > ctx->chunk_fused) {
+        // the launch size was lowered inside this call (free-memory clamp or halve-and-retry): the workspace holds the last launch only
+        set_error("gnn_debug_forward with taps: the launch size was reduced to " + std::to_string(ctx->chunk_fused) +
+                  " windows for lack of device memory; the taps of " + std::to_string(n) + " windows do not fit one launch");
+        return GNN_ERR_STATE;
     }
     if (!rc && taps) {
         const Workspace& ws = ctx->ws;

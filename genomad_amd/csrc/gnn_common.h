@@ -22,7 +22,7 @@ constexpr int HID = GNN_HIDDEN;
 constexpr float LRELU = 0.1f;             // igloo.py:48
 constexpr float BN_EPS = 1e-3f;           // Keras BatchNormalization default
 
-// ---- fused front end geometry (gnn_fused.hip) ----
+// ---- fused front end geometry (gnn_fused_x3.hip, gnn_fused_c6.hip) ----
 constexpr int FT = 128;                   // rows (token positions) per step of a workgroup
 constexpr int FSTEPS = (T + FT - 1) / FT; // 47 steps per window
 // rows of a conv1 pair table: 1024 five-mers | 256 (N, 4-mer) | 256 (4-mer, N) | (N, N) | (absent,
@@ -71,19 +71,13 @@ struct DeviceWeights {
     float* d3_b = nullptr;
     uint16_t* d1_frag = nullptr;   // BN-folded Dense512 kernels in MFMA fragment order, f16 hi / lo (dense_mfma_kernel):
     uint16_t* d2_frag = nullptr;   // [kstep][nblk 16][plane 2][lane 64][8]
-    // fused path packs (gnn_fused.hip): MFMA fragment order, bf16 hi / lo planes
+    // fused path packs (gnn_pack.hip): MFMA fragment order, bf16 hi / lo planes
     uint16_t* conv_frag[2] = {nullptr, nullptr};  // conv2, conv3: [kstep 48][nblk 4][plane 2][lane 64][8]
     uint16_t* wv_frag[2] = {nullptr, nullptr};    // head A, B:   [kstep 8][nblk 4][plane 2][lane 64][8]
     uint16_t* wqk_frag[2] = {nullptr, nullptr};   // head A, B:   [kstep 132][nblk 24][plane 2][lane 64][8], zero padded
     uint16_t* wqk_frag_h[2] = {nullptr, nullptr}; // the same with f16 hi / lo limbs (logits GEMM of GNN_PREC_F16X3)
     uint16_t* conv_frag_h[2] = {nullptr, nullptr};   // the same fragment layouts with f16 hi / lo limbs (GNN_PREC_F16X3)
     uint16_t* wv_frag_h[2] = {nullptr, nullptr};
-    // f16 + fp8-correction packs (gnn_fused_c8.hip): [k32 step][nblk 4][f16 even | f16 odd | fp8 lo | fp8 hi][lane 64] x 16 B
-    // and E8M0 block scales [tap][nblk 4][lane 64] u32
-    uint32_t* conv_c8[2] = {nullptr, nullptr};
-    uint32_t* conv_c8s[2] = {nullptr, nullptr};
-    uint32_t* wv_c8[2] = {nullptr, nullptr};
-    uint32_t* wv_c8s[2] = {nullptr, nullptr};
     // f16 + MX-fp6-correction packs (gnn_fused_c6.hip): [k32 step][nblk 4][f16 even 1 KiB | f16 odd 1 KiB | fp6 dwords 0-3 1 KiB |
     // fp6 dwords 4-5 512 B], scale words as above, pair tables in the gather's lane order (bias folded), entry ranges per step
     uint32_t* conv_c6[2] = {nullptr, nullptr};
@@ -145,6 +139,7 @@ struct gnn_ctx {
                                      // The DEFAULT is a ceiling, not a demand: classify_chunks clamps it to a quarter of the device memory that is
                                      // free when the workspace first grows, and any size (explicit or not) is halved and retried when the
                                      // allocation fails (shared / partitioned GPUs)
+    int64_t alt_failed_chunk = 0;    // a second workspace of this many windows did not fit (classify_chunks does not retry at or above it)
     bool chunk_explicit = false;     // gnn_set_chunk was called: no clamp against free memory, only the halve-and-retry on failure
     int64_t chunk_f32 = 64;
     bool profile = false;
@@ -167,6 +162,9 @@ struct gnn_ctx {
     void* pin[2] = {nullptr, nullptr};
     hipEvent_t pin_ev[2] = {nullptr, nullptr};
     bool pin_busy[2] = {false, false};
+    // classify_chunks: staging of a window buffer that is not 4-byte aligned (the streaming kernels fetch bases as aligned dwords)
+    uint8_t* align_buf = nullptr;
+    int64_t align_windows = 0;
     // RCCL communicator of this ctx (gnn_comm.hip); ncclComm_t kept opaque here
     void* comm = nullptr;
     int comm_ranks = 1, comm_rank = 0;
@@ -185,7 +183,6 @@ int launch_span_count(gnn_ctx* ctx, const uint8_t* seq, const int64_t* starts, c
 int launch_materialize(gnn_ctx* ctx, const uint8_t* seq, const int64_t* starts, const int32_t* lens, int64_t n,
                        uint8_t* bases);
 int launch_front_f32(gnn_ctx* ctx, const uint8_t* bases, int64_t n);         // -> ws.mp, ws.yp (+ ws.x)
-int launch_front_fused(gnn_ctx* ctx, const uint8_t* bases, int64_t n, int precision);  // -> ws.mp, ws.yp
 int launch_backend(gnn_ctx* ctx, int64_t n, int precision, float* scores_dev);   // ws.mp, ws.yp -> scores
 // one pass of the hot path over n windows whose padded bases are on the device (gnn_api.hip)
 // defer_last: leave the last chunk's back end pending on the second stream (gnn_classify_dev_async).  flush_backend()
@@ -197,18 +194,16 @@ int finish_pending(gnn_ctx* ctx);
 void free_contig_ws(gnn_ctx* ctx);     // gnn_contigs.hip
 void free_stage(gnn_ctx* ctx);         // gnn_api.hip: staging of the host-buffer entry points
 
-int launch_front_c8(gnn_ctx* ctx, const uint8_t* bases, int64_t n);             // GNN_PREC_F16C8 -> ws.mp, ws.yp
 int launch_front_c6(gnn_ctx* ctx, const uint8_t* bases, int64_t n);             // GNN_PREC_F16C6 -> ws.mp, ws.yp
 int launch_front_x3(gnn_ctx* ctx, const uint8_t* bases, int64_t n, int precision);   // GNN_PREC_F16X3 / BF16X3 (gnn_fused_x3.hip) -> ws.mp, ws.yp
 int launch_front_tc(gnn_ctx* ctx, const uint8_t* bases, int64_t n);             // GNN_PREC_F16X3TC (gnn_fused_tc.hip) -> ws.mp, ws.yp
 int pack_fused_tc_weights(gnn_ctx* ctx, const gnn_weights* w);                   // after pack_fused_c6_weights (shares its pair tables)
 int pack_fused_x3_consts(gnn_ctx* ctx);                                          // all-N window outputs of that kernel (after the other packs)
 
-// host-side packing for the fused paths (gnn_fused.hip, gnn_fused_c8.hip)
+// host-side packing for the fused paths (gnn_pack.hip)
 int pack_fused_weights(gnn_ctx* ctx, const gnn_weights* w);
-// K x N row-major f32 -> [kstep][nblk][plane hi, lo][lane 64][8 x 16 bit] (bf16 or f16 limbs), zero padded (gnn_fused.hip)
+// K x N row-major f32 -> [kstep][nblk][plane hi, lo][lane 64][8 x 16 bit] (bf16 or f16 limbs), zero padded (gnn_pack.hip)
 std::vector<uint16_t> pack_frags(const float* wmat, int K, int N, bool f16 = false);
-int pack_fused_c8_weights(gnn_ctx* ctx, const gnn_weights* w);
 int pack_fused_c6_weights(gnn_ctx* ctx, const gnn_weights* w);
 int c6_rows_per_step();
 int c6_pack_matrix(const float* wmat, int K, int N, std::vector<uint32_t>& out);   // host only (tests)

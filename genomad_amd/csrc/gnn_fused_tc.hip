@@ -14,23 +14,32 @@
 // channels) on the helper waves, which get ~6 issue slots per MFMA of the matrix wave they share a SIMD with.  Result: 21.7 vs
 // 26.7 ms per 4096 windows against the direct form (gnn_fused_x3.hip) on one box; DESIGN.md section 4.0 has the accounting.
 //
-// Structure: the streaming structure of gnn_fused_x3.hip (one workgroup = one window, both activation buffers in LDS with 5 carry
-// rows, 4 matrix waves + 4 helper waves) with steps of 96 rows and a ring of 3 x 16 KB in LDS through which the helper waves hand
-// the transformed activations of ONE k16 unit (8 points x hi | lo x 64 lanes x 16 B, MFMA B-fragment order) to the matrix waves:
+// Round 6: head A's y @ w_v (igloo.py:208 on x1) is no longer computed.  x1[t] is a function of the nine bases t-5 .. t+3, so the
+// row is gathered from a table of all 9-mers (WvaTable below: built on the device by gnn_load_weights, f64 accumulation) and the
+// 8-row max is taken in registers: 288 of a step's 2 112 MFMAs per CU and their weight stream are gone, and since nothing multiplies
+// x1 on the matrix pipe any more it is stored as f32 rows (no limb split in the gather, no reconstruction in conv2's input transform,
+// half the FMAs in head A's pair products).
 //
-//   matrix : [b0 it0 | b1 it1 | ... | b7 it7] conv2 -> inverse transform -> x2 (f32 rows) -> bufY | B1 | w_v A(s) [bufX] |
-//            [b0' .. b7'] conv3 -> inverse transform -> x3 (hi | lo rows) -> bufY | B0 | w_v B(s) [bufY]   -> step s+1
+// Structure: the streaming structure of gnn_fused_x3.hip (one workgroup = one window, both activation buffers in LDS with 5 carry
+// rows, 4 matrix waves + 4 helper waves) with steps of 96 rows and a ring of 3 x 16 KB in LDS through which the transformed
+// activations of ONE k16 unit (8 points x hi | lo x 64 lanes x 16 B, MFMA B-fragment order) reach the matrix waves:
+//
+//   matrix : [b0 it0 | b1 it1 | ... | b7 it7] conv2 -> inverse transform -> x2 (f32 rows) -> bufY | B1 | head A's 24 table rows per
+//            wave requested, V3 chunk 1 [bufY], next step's row indices, 8-row max of the table rows -> yp A |
+//            [b0' .. b7'] conv3 -> inverse transform -> x3 (hi | lo rows) -> bufY | B0 | w_v B(s) [bufY], V2(s+1) chunk 1 [bufX] -> step s+1
 //   helpers: beside conv2 units 0..5: V2 chunks 2..7 [bufX]; beside units 6, 7 and the conv2 epilogue: head A's pair products [bufX],
-//            gather round 0 of x1(s+1) (into registers) | B1 | V3 chunks 0, 1 [bufY], gather round 1 (registers) |
+//            gather round 0 of x1(s+1) (into registers) | B1 | V3 chunk 0 [bufY], head A's last pass, gather round 1 (registers) |
 //            beside conv3 units 0..5: V3 chunks 2..7, the held gather rounds -> bufX; units 6, 7 and the conv3 epilogue: gather round 2,
-//            carry rows, pair rows | B0 | head B's pair products [bufY], V2(s+1) chunks 0, 1
+//            carry rows, pair rows | B0 | head B's pair products [bufY], V2(s+1) chunk 0
 //   (tests/test_kernel_schedule.py is an executable model of this schedule: every LDS producer / consumer pair is ordered by a barrier)
 //
 // 18 workgroup barriers per step (bare s_barrier: a __syncthreads() would drain the matrix waves' weight loads in flight).  The
 // helpers run two chunks ahead of the matrix waves: before barrier b_c chunks <= c + 1 are complete, during unit c chunk c + 2
-// is written into slot (c + 2) % 3, which the matrix waves read last in unit c - 1.
+// is written into slot (c + 2) % 3, which the matrix waves read last in unit c - 1.  Chunks 0 and 1 of a conv are made in the
+// interval in front of its loop, chunk 0 by the helpers and chunk 1 by the matrix waves (same lane mapping: wave w of either role
+// owns the same 16 (tile, k half) combinations), so that neither role waits for the other there.
 //
-// LDS: bufX 101 rows x 528 B (x1: hi | lo planes), bufY 101 x 528 (x2 as f32 rows, then x3 as hi | lo planes), ring 3 x 16 KB,
+// LDS: bufX 101 rows x 528 B (x1 as f32 rows), bufY 101 x 528 (x2 as f32 rows, then x3 as hi | lo planes), ring 3 x 16 KB,
 // pair rows, biases: 157.3 KB.
 //
 // Compile-time switches: -DTC_JITTER only (libgenomad_nn_hip_jitter.so, a test build: random sleeps behind every barrier, results
@@ -221,7 +230,7 @@ __device__ __forceinline__ void prime_wv(WU (&ring)[RINGT], wrsrc_t wr, int woff
 }
 
 // MaxPool1D(8) of the y @ w_v tile -> yp rows (igloo.py:209-210); gnn_fused_x3.hip, wv_pool_store
-__device__ __forceinline__ void wv_pool_store(const f32x16 (&acc)[NMB], wrsrc_t yp_w, int t0, int wave, int lane) {
+__device__ __forceinline__ void wv_pool_store(const f32x16 (&acc)[NMB], wrsrc_t yp_w, int head_off, int t0, int wave, int lane) {
     float m[4 * NMB];
 #pragma unroll
     for (int i = 0; i < 4 * NMB; ++i) {
@@ -237,7 +246,7 @@ __device__ __forceinline__ void wv_pool_store(const f32x16 (&acc)[NMB], wrsrc_t 
         const uint32_t voff = (uint32_t)(wave * 32 + lane) * 4u;
 #pragma unroll
         for (int i = 0; i < 4 * NMB; ++i)
-            if (i < nq) __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(m[i]), yp_w, voff, (q0 + i) * (C * 4), 0);
+            if (i < nq) __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(m[i]), yp_w, voff, head_off + (q0 + i) * (C * 4), 0);
     }
 }
 
@@ -296,10 +305,11 @@ struct WvaRows {
     u32x2 v[WVA_ROWS_PER_WAVE];     // 24 table rows, two channels per lane
 };
 // all 24 row requests of a wave: 64 lanes x 8 B = one 512-byte row per instruction, the row's byte offset in an SGPR
+template <int I0 = 0, int I1 = WVA_ROWS_PER_WAVE>
 __device__ __forceinline__ void wva_issue(WvaRows& r, wrsrc_t tbl, uint32_t my_row, int lane) {
     const uint32_t l8 = (uint32_t)lane * 8u;
 #pragma unroll
-    for (int i = 0; i < WVA_ROWS_PER_WAVE; ++i) {
+    for (int i = I0; i < I1; ++i) {
         const uint32_t row = __builtin_amdgcn_readlane(my_row, i);
         r.v[i] = __builtin_amdgcn_raw_buffer_load_b64(tbl, l8, row * WvaTable::ROW_BYTES, 0);
     }
@@ -447,24 +457,17 @@ struct HLane {
     const unsigned char* rows;    // first input row of the lane's tile (buffer row 3 * tile), at the lane's channel pair
     unsigned char* frag;          // the lane's dword of the ring slot's fragments
 };
-__device__ __forceinline__ HLane hlane(unsigned char* smem, int buf_off, int hw, int lane, int bytes_per_ch) {
+__device__ __forceinline__ HLane hlane(unsigned char* smem, int buf_off, int hw, int lane) {
     const int pr = lane & 3, th = hw * 16 + (lane >> 2), tile = th & 31, half = th >> 5;
     HLane h;
-    h.rows = smem + buf_off + (3 * tile) * ROWX + (half * 8 + pr * 2) * bytes_per_ch;
+    h.rows = smem + buf_off + (3 * tile) * ROWX + (half * 8 + pr * 2) * 4;
     h.frag = smem + VRING_OFF + (hw * 64 + lane) * 4;
     return h;
 }
-struct Raw16 {   // 8 rows x 2 channels as stored: f16 hi | lo words (x1) or f32 pairs (x2)
+struct Raw16 {   // 8 rows x 2 channels as stored: f32 pairs (x1 and x2 rows alike since round 6)
     uint32_t a[8], b[8];
 };
-__device__ __forceinline__ void load_x1(Raw16& r, const HLane& h, int unit) {
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-        r.a[j] = *reinterpret_cast<const uint32_t*>(h.rows + j * ROWX + unit * 32);
-        r.b[j] = *reinterpret_cast<const uint32_t*>(h.rows + j * ROWX + unit * 32 + LOX);
-    }
-}
-__device__ __forceinline__ void load_x2(Raw16& r, const HLane& h, int unit) {
+__device__ __forceinline__ void load_rows(Raw16& r, const HLane& h, int unit) {
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
         const uint2 v = *reinterpret_cast<const uint2*>(h.rows + j * ROWX + unit * 64);
@@ -486,18 +489,12 @@ __device__ __forceinline__ void bt8(const float (&d)[8], float (&v)[8]) {
     v[6] = t5 - t6;
     v[7] = fmaf(d[3] - d[5], 5.25f, d[7] - d[1]);
 }
-template <bool X1>
 __device__ __forceinline__ void transform_store(const Raw16& r, const HLane& h, int slot) {
     float d0[8], d1[8], v0[8], v1[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
-        if constexpr (X1) {            // x = hi + lo in ONE v_fma_mix_f32 per value (hi * 1.0 + lo, both read as f16 halves)
-            asm("v_fma_mix_f32 %0, %1, 1.0, %2 op_sel:[0,0,0] op_sel_hi:[1,0,1]" : "=v"(d0[j]) : "v"(r.a[j]), "v"(r.b[j]));
-            asm("v_fma_mix_f32 %0, %1, 1.0, %2 op_sel:[1,0,1] op_sel_hi:[1,0,1]" : "=v"(d1[j]) : "v"(r.a[j]), "v"(r.b[j]));
-        } else {
-            d0[j] = __uint_as_float(r.a[j]);
-            d1[j] = __uint_as_float(r.b[j]);
-        }
+        d0[j] = __uint_as_float(r.a[j]);
+        d1[j] = __uint_as_float(r.b[j]);
     }
     bt8(d0, v0);
     bt8(d1, v1);
@@ -527,30 +524,20 @@ __device__ __forceinline__ void grow_issue(GRow& g, const uint16_t* __restrict__
         for (int i = 0; i < 4; ++i) g.v[j][i] = *reinterpret_cast<const f32x4*>(src + i * 32);
     }
 }
-struct GOut {         // a finished item: 16 channels as f16 hi | lo limbs, waiting for bufX to become writable
-    uint4 h0, h1, l0, l1;
+struct GOut {         // a finished item: 16 channels of one x1 row (f32), waiting for bufX to become writable
+    f32x4 v[4];       // channels 16 pq + 4 i ..
 };
 __device__ __forceinline__ void grow_compute(GOut& o, const GRow& g) {
-    uint32_t hi[8], lo[8];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const f32x4 t = g.v[0][i] + g.v[1][i] + g.v[2][i];           // the bias is folded into table 0
-        const float x0 = vmax_raw(t[0], t[0] * LRELU), x1 = vmax_raw(t[1], t[1] * LRELU);
-        const float x2 = vmax_raw(t[2], t[2] * LRELU), x3 = vmax_raw(t[3], t[3] * LRELU);
-        split2<true>(f32x2{x0, x1}, hi[2 * i], lo[2 * i]);
-        split2<true>(f32x2{x2, x3}, hi[2 * i + 1], lo[2 * i + 1]);
+        o.v[i] = f32x4{vmax_raw(t[0], t[0] * LRELU), vmax_raw(t[1], t[1] * LRELU), vmax_raw(t[2], t[2] * LRELU), vmax_raw(t[3], t[3] * LRELU)};
     }
-    o.h0 = make_uint4(hi[0], hi[1], hi[2], hi[3]);
-    o.h1 = make_uint4(hi[4], hi[5], hi[6], hi[7]);
-    o.l0 = make_uint4(lo[0], lo[1], lo[2], lo[3]);
-    o.l1 = make_uint4(lo[4], lo[5], lo[6], lo[7]);
 }
 __device__ __forceinline__ void grow_store(const GOut& o, unsigned char* __restrict__ xbuf, int row, int pq) {
-    unsigned char* d = xbuf + (CARRY + row) * ROWX + pq * 32;
-    *reinterpret_cast<uint4*>(d) = o.h0;
-    *reinterpret_cast<uint4*>(d + 16) = o.h1;
-    *reinterpret_cast<uint4*>(d + LOX) = o.l0;
-    *reinterpret_cast<uint4*>(d + LOX + 16) = o.l1;
+    unsigned char* d = xbuf + (CARRY + row) * ROWX + pq * 64;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) *reinterpret_cast<f32x4*>(d + i * 16) = o.v[i];
 }
 __device__ __forceinline__ void grow_finish(const GRow& g, unsigned char* __restrict__ xbuf, int row, int pq) {
     GOut o;
@@ -558,7 +545,9 @@ __device__ __forceinline__ void grow_finish(const GRow& g, unsigned char* __rest
     grow_store(o, xbuf, row, pq);
 }
 
-// dot product of an entry's 32 folded weights with block p of row u (x = hi + lo), summed over the entry's 4 lanes (gnn_fused_x3.hip)
+// dot product of an entry's 32 folded weights with block p of row u, summed over the entry's 4 lanes.  Two row formats: x3 (head B) is
+// stored as f16 hi | lo planes (the y @ w_v tile's MFMA operands; x = hi + lo), x1 (head A) as f32 since round 6 (nothing multiplies it on
+// the matrix pipe any more: conv2 reads it through the input transform, head A's y @ w_v comes from the table)
 struct PairCompute {
     static __device__ __forceinline__ void run(const PairW& w, const PairJob& jb, int e, int u, int p) {
         const unsigned char* xr = jb.xbuf + (CARRY + u - jb.t0) * ROWX + p * 64;
@@ -572,6 +561,26 @@ struct PairCompute {
         float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
 #pragma unroll
         for (int i = 0; i < 4; ++i) pair_fma16(hx[i], lx[i], w.w[2 * i], w.w[2 * i + 1], s0, s1, s2, s3);
+        float s = (s0 + s2) + (s1 + s3);
+        s += dpp_xor1(s);
+        s += dpp_xor2(s);
+        if (p == 0) jb.mp[e] = s;
+    }
+};
+struct PairComputeF32 {
+    static __device__ __forceinline__ void run(const PairW& w, const PairJob& jb, int e, int u, int p) {
+        const unsigned char* xr = jb.xbuf + (CARRY + u - jb.t0) * ROWX + p * 128;
+        f32x4 x[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) x[i] = *reinterpret_cast<const f32x4*>(xr + i * 16);
+        float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            s0 = fmaf(x[i][0], w.w[i].x, s0);
+            s1 = fmaf(x[i][1], w.w[i].y, s1);
+            s2 = fmaf(x[i][2], w.w[i].z, s2);
+            s3 = fmaf(x[i][3], w.w[i].w, s3);
+        }
         float s = (s0 + s2) + (s1 + s3);
         s += dpp_xor1(s);
         s += dpp_xor2(s);
@@ -594,16 +603,18 @@ __device__ __forceinline__ void pass_issue(PairPass& pp, const PairJob& jb, int 
         pair_load_w(pp.w, jb, e, lane & 3);
     }
 }
+template <class Compute = PairCompute>
 __device__ __forceinline__ void pass_compute(const PairPass& pp, const PairJob& jb, int k, int wave, int lane) {
     const int e = jb.e + wave * 16 + (lane >> 2) + 64 * k;
-    if (e < jb.e_end) PairCompute::run(pp.w, jb, e, pp.u, lane & 3);
+    if (e < jb.e_end) Compute::run(pp.w, jb, e, pp.u, lane & 3);
     GNN_REGION_END();        // keeps the scheduler from hoisting the next pass's 8 row reads (32 registers) above this pass
 }
 // a crowded step (more than 3 passes; rare): the remaining passes one by one, loads not hidden
+template <class Compute = PairCompute>
 __device__ __forceinline__ void pass_rest(PairPass& pp, const PairJob& jb, int k0, int wave, int lane) {
     for (int e = jb.e + wave * 16 + (lane >> 2) + 64 * k0; e < jb.e_end; e += 64) {
         pair_load_w(pp.w, jb, e, lane & 3);
-        PairCompute::run(pp.w, jb, e, jb.pos[e], lane & 3);
+        Compute::run(pp.w, jb, e, jb.pos[e], lane & 3);
     }
 }
 
@@ -664,15 +675,24 @@ __global__ __launch_bounds__(512, 2) void fused_front_tc_kernel(Args a) {
 
     if (!helper) {
         __builtin_amdgcn_s_setprio(2);
-        const wrsrc_t cw[2] = {make_wrsrc(a.tcw[0], 64 * WUNIT_B), make_wrsrc(a.tcw[1], 64 * WUNIT_B)};
-        const wrsrc_t vw = make_wrsrc(a.wv_w[1], 8 * WUNIT_B);            // head A's w_v is inside the table
+        // The wave's n-block (woff) is folded into the resources' base addresses, so the byte offset of every weight request is a
+        // compile-time constant: an `s_mov literal` the compiler rematerialises where it needs it.  As `woff + constant` (an s_add of
+        // a register) the 64 offsets of a conv loop were kept in SGPRs across the whole step loop, and when round 6 added the table's
+        // resource the overflow came back as v_readlane + wait states INSIDE the conv loops (18 per loop).
+        const wrsrc_t cw[2] = {make_wrsrc(a.tcw[0] + woff, 64 * WUNIT_B - woff), make_wrsrc(a.tcw[1] + woff, 64 * WUNIT_B - woff)};
+        const wrsrc_t vw = make_wrsrc(a.wv_w[1] + woff, 8 * WUNIT_B - woff);            // head A's w_v is inside the table
         const wrsrc_t tblr = make_wrsrc(a.wva_tbl, (int)(WvaTable::ROWS * WvaTable::ROW_BYTES));
-        const wrsrc_t yp_w[2] = {make_wrsrc(reinterpret_cast<const unsigned char*>(a.yp + (wi * 2 + 0) * (size_t)POOLED * C), POOLED * C * 4),
-                                 make_wrsrc(reinterpret_cast<const unsigned char*>(a.yp + (wi * 2 + 1) * (size_t)POOLED * C), POOLED * C * 4)};
+        // one resource for the window's pooled rows of both heads (head h at byte h * POOLED * C * 4): four SGPRs less than one per head -
+        // the matrix role lives at the edge of the SGPR file, and spilled SGPRs come back as v_readlane + wait states inside the conv loops
+        const wrsrc_t yp_w = make_wrsrc(reinterpret_cast<const unsigned char*>(a.yp + wi * 2 * (size_t)POOLED * C), 2 * POOLED * C * 4);
         WU ring[RINGT];
-        prime_tc(ring, cw[0], woff, lane);
-        WvaBytes wb;                                                             // the bases behind this lane's table row, fetched a step ahead
+        prime_tc(ring, cw[0], 0, lane);
+        // head A's table rows: the lane's row index of a step is computed a step ahead (behind B1, while the table rows of the current
+        // step travel), from bases fetched a step before that: no memory round trip in front of the requests
+        WvaBytes wb;
         wva_fetch(wb, bases, wva_row(s_begin * FTT, hw, lane));
+        uint32_t wva_next = wva_index(wb, wva_row(s_begin * FTT, hw, lane));
+        wva_fetch(wb, bases, wva_row((s_begin + 1) * FTT, hw, lane));
         __syncthreads();                                                         // x1 of the first step is in bufX
         if constexpr (PROF) tick_ = __builtin_readcyclecounter();
 #pragma unroll 1
@@ -685,29 +705,39 @@ __global__ __launch_bounds__(512, 2) void fused_front_tc_kernel(Args a) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[xi][r] = 0.f;
             GNN_TICK(7)
-            conv_tc(smem, cw[0], woff, ring, acc, lane, jitter_state);                         // b_0 .. b_7, conv2
+            conv_tc(smem, cw[0], 0, ring, acc, lane, jitter_state);                         // b_0 .. b_7, conv2
             GNN_TICK(0)
-            // head A's y @ w_v rows of this step: requested here (the weight ring's registers are free), pooled behind B1 - the round
-            // trip to the Infinity Cache / HBM hides behind the epilogue.  (Unconditional: with the requests behind `if (store)` the register
-            // allocator spills 8 of the 24 rows - and waits for each - although 40 registers are free; a warm-up step of a time-split
-            // run reads its rows for nothing.)
-            WvaRows wr;
-            wva_issue(wr, tblr, wva_index(wb, wva_row(t0, hw, lane)), lane);
-            wva_fetch(wb, bases, wva_row(t0 + FTT, hw, lane));
             epilogue_f32(bufY, acc, a.inv_s[0], bias_s, hw, lane);
             GNN_TICK(1)
             TC_BARRIER_W();                                                      // ---- B1: x2 is in bufY
             GNN_TICK(2)
-            if (store) wva_pool_store(wr, yp_w[0], t0, hw, lane);
-            prime_tc(ring, cw[1], woff, lane);
+            // The interval in which the matrix waves used to compute head A's y @ w_v.  Now: conv3's first weights, the step's 24 table
+            // rows per wave (all of them requested here: 384 missing lines per CU are more than the vector L1 keeps in flight, so a wave
+            // that requests them BEFORE the epilogue stalls at issue and the epilogue - which the helpers wait for - runs 1.7 k cycles
+            // longer, profiles/r06/), and while they travel (~4 k cycles) chunk 1 of V3 - the helpers make chunk 0 meanwhile - and the
+            // next step's row indices.  The requests are unconditional: behind `if (store)` the register allocator spills 8 of the 24
+            // rows and waits for each; a warm-up step of a time-split run reads its rows for nothing.
+            prime_tc(ring, cw[1], 0, lane);
+            WvaRows wr;
+            wva_issue(wr, tblr, wva_next, lane);
+            {
+                const HLane h2m = hlane(smem, BUF_BYTES, hw, lane);
+                Raw16 rm;
+                load_rows(rm, h2m, 1);
+                transform_store(rm, h2m, 1);
+            }
+            wva_next = wva_index(wb, wva_row(t0 + FTT, hw, lane));
+            wva_fetch(wb, bases, wva_row(t0 + 2 * FTT, hw, lane));
+            if (store) wva_pool_store(wr, yp_w, t0, hw, lane);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                  // chunk 1's fragments have landed before b'_0 releases the readers
             GNN_TICK(3)
 #pragma unroll
             for (int xi = 0; xi < NXI; ++xi)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[xi][r] = 0.f;
-            conv_tc(smem, cw[1], woff, ring, acc, lane, jitter_state);                         // b'_0 .. b'_7, conv3
+            conv_tc(smem, cw[1], 0, ring, acc, lane, jitter_state);                         // b'_0 .. b'_7, conv3
             GNN_TICK(4)
-            prime_wv(ring, vw, woff, lane);
+            prime_wv(ring, vw, 0, lane);
             epilogue_x3(bufY, acc, a.inv_s[1], bias_s + C, hw, lane);
             GNN_TICK(5)
             TC_BARRIER_W();                                                      // ---- B0: x3 is in bufY
@@ -718,9 +748,16 @@ __global__ __launch_bounds__(512, 2) void fused_front_tc_kernel(Args a) {
                 for (int mb = 0; mb < NMB; ++mb)
 #pragma unroll
                     for (int r = 0; r < 16; ++r) ac[mb][r] = 0.f;
-                wv_tile(smem, BUF_BYTES + CARRY * ROWX, vw, woff, ring, ac, lane, [](auto) {});
-                prime_tc(ring, cw[0], woff, lane);
-                if (store) wv_pool_store(ac, yp_w[1], t0, hw, lane);
+                wv_tile(smem, BUF_BYTES + CARRY * ROWX, vw, 0, ring, ac, lane, [](auto) {});
+                prime_tc(ring, cw[0], 0, lane);
+                if (store) wv_pool_store(ac, yp_w, POOLED * C * 4, t0, hw, lane);
+                {                                                                // V2 chunk 1 of the next step (x1(s+1) is in bufX since B0)
+                    const HLane h1m = hlane(smem, 0, hw, lane);
+                    Raw16 rm;
+                    load_rows(rm, h1m, 1);
+                    transform_store(rm, h1m, 1);
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                }
             }
         }
     } else {
@@ -737,7 +774,7 @@ __global__ __launch_bounds__(512, 2) void fused_front_tc_kernel(Args a) {
         __builtin_amdgcn_s_setprio(3);
         uint32_t nlo = 0, nhi = 0;                       // bytes of this thread's pair row of the step AFTER next
         if (ht < PROW_N) prow_fetch(bases, (s_begin + 2) * FTT - CARRY + ht, nlo, nhi);
-        const HLane h1 = hlane(smem, 0, hw, lane, 2), h2 = hlane(smem, BUF_BYTES, hw, lane, 4);
+        const HLane h1 = hlane(smem, 0, hw, lane), h2 = hlane(smem, BUF_BYTES, hw, lane);
         const int cr = ht / ROW_U4, cc = ht - cr * ROW_U4;   // carry rows: 5 rows x 33 chunks of 16 B
         __syncthreads();
         if constexpr (PROF) tick_ = __builtin_readcyclecounter();
@@ -745,11 +782,11 @@ __global__ __launch_bounds__(512, 2) void fused_front_tc_kernel(Args a) {
         PairPass p0, p1;
         p0.u = p1.u = 0;
         // V2 chunks 0 and 1 of the first step
-        load_x1(ra, h1, 0);
-        load_x1(rb, h1, 1);
-        transform_store<true>(ra, h1, 0);
-        load_x1(ra, h1, 2);
-        transform_store<true>(rb, h1, 1);
+        load_rows(ra, h1, 0);
+        load_rows(rb, h1, 1);
+        transform_store(ra, h1, 0);
+        load_rows(ra, h1, 2);
+        transform_store(rb, h1, 1);
 #pragma unroll 1
         for (int step = s_begin; step < s_hi; ++step) {
             const int t0 = step * FTT;
@@ -771,22 +808,22 @@ __global__ __launch_bounds__(512, 2) void fused_front_tc_kernel(Args a) {
             // the loop and run their epilogue without needing anything from the helpers.
             TC_HPRIO_HIGH();
             HBAR_W(8, 9);                                                        // b_0
-            load_x1(rb, h1, 3);
-            transform_store<true>(ra, h1, 2);
+            load_rows(rb, h1, 3);
+            transform_store(ra, h1, 2);
             HBAR_W(8, 9);                                                        // b_1
-            load_x1(ra, h1, 4);
-            transform_store<true>(rb, h1, 0);
+            load_rows(ra, h1, 4);
+            transform_store(rb, h1, 0);
             HBAR_W(8, 9);                                                        // b_2
-            load_x1(rb, h1, 5);
-            transform_store<true>(ra, h1, 1);
+            load_rows(rb, h1, 5);
+            transform_store(ra, h1, 1);
             HBAR_W(8, 9);                                                        // b_3
-            load_x1(ra, h1, 6);
-            transform_store<true>(rb, h1, 2);
+            load_rows(ra, h1, 6);
+            transform_store(rb, h1, 2);
             HBAR_W(8, 9);                                                        // b_4
-            load_x1(rb, h1, 7);
-            transform_store<true>(ra, h1, 0);
+            load_rows(rb, h1, 7);
+            transform_store(ra, h1, 0);
             HBAR_W(8, 9);                                                        // b_5
-            transform_store<true>(rb, h1, 1);
+            transform_store(rb, h1, 1);
             uint4 carry = make_uint4(0, 0, 0, 0);
             // head A's pair products of this step (x1 in bufX until the gather behind b'_0) beside units 6, 7 and the conv2 epilogue:
             // two register sets; the third pass is requested when the first is done and used last, where the helpers would wait for
@@ -802,22 +839,20 @@ __global__ __launch_bounds__(512, 2) void fused_front_tc_kernel(Args a) {
             pass_rest(p0, jbp, 3, hw, lane);                                     // bufY holds x3(s-1) until the conv2 epilogue behind b_7
             pass_issue(p0, ja, 1, hw, lane);
             HBAR(8, 9);                                                          // b_7
-            pass_compute(p1, ja, 0, hw, lane);
+            pass_compute<PairComputeF32>(p1, ja, 0, hw, lane);
             pass_issue(p1, ja, 2, hw, lane);
-            pass_compute(p0, ja, 1, hw, lane);
+            pass_compute<PairComputeF32>(p0, ja, 1, hw, lane);
             if (ht < CARRY * ROW_U4) carry = *reinterpret_cast<const uint4*>(bufX + (FTT + cr) * ROWX + cc * 16);
             grow_compute(o0, ga);
             grow_issue(ga, prow, a.conv1_k, grow0 + 32, gpq);
             HBAR(8, 10);                                                         // ---- B1: x2 is in bufY
             TC_HPRIO_LOW();
-            // head A's last pass, V3 chunks 0, 1 and gather round 1 beside the matrix waves' w_v A
-            load_x2(ra, h2, 0);
-            load_x2(rb, h2, 1);
-            pass_compute(p1, ja, 2, hw, lane);
-            pass_rest(p1, ja, 3, hw, lane);
-            transform_store<false>(ra, h2, 0);
-            load_x2(ra, h2, 2);
-            transform_store<false>(rb, h2, 1);
+            // head A's last pass, V3 chunk 0 (the matrix waves make chunk 1 while their table rows travel) and gather round 1
+            load_rows(ra, h2, 0);
+            pass_compute<PairComputeF32>(p1, ja, 2, hw, lane);
+            pass_rest<PairComputeF32>(p1, ja, 3, hw, lane);
+            transform_store(ra, h2, 0);
+            load_rows(ra, h2, 2);
             grow_compute(o1, ga);
             GNN_TICK(12)
             // ---- conv3 phase: chunks 2 .. 7; the conv1 gather of the next step (3 rows per lane, table loads two intervals ahead of
@@ -828,23 +863,23 @@ __global__ __launch_bounds__(512, 2) void fused_front_tc_kernel(Args a) {
                 if (ht < CARRY * ROW_U4) *reinterpret_cast<uint4*>(bufX + cr * ROWX + cc * 16) = carry;
                 grow_store(o0, bufX, grow0, gpq);
                 grow_store(o1, bufX, grow0 + 32, gpq);
-                load_x2(rb, h2, 3);
-                transform_store<false>(ra, h2, 2);
+                load_rows(rb, h2, 3);
+                transform_store(ra, h2, 2);
                 HBAR_W(13, 14);                                                  // b'_1
-                load_x2(ra, h2, 4);
-                transform_store<false>(rb, h2, 0);
+                load_rows(ra, h2, 4);
+                transform_store(rb, h2, 0);
                 HBAR_W(13, 14);                                                  // b'_2
-                load_x2(rb, h2, 5);
-                transform_store<false>(ra, h2, 1);
+                load_rows(rb, h2, 5);
+                transform_store(ra, h2, 1);
                 HBAR_W(13, 14);                                                  // b'_3
-                load_x2(ra, h2, 6);
-                transform_store<false>(rb, h2, 2);
+                load_rows(ra, h2, 6);
+                transform_store(rb, h2, 2);
                 HBAR_W(13, 14);                                                  // b'_4
-                load_x2(rb, h2, 7);
-                transform_store<false>(ra, h2, 0);
+                load_rows(rb, h2, 7);
+                transform_store(ra, h2, 0);
                 grow_issue(ga, prow, a.conv1_k, grow0 + 64, gpq);
                 HBAR_W(13, 14);                                                  // b'_5
-                transform_store<false>(rb, h2, 1);
+                transform_store(rb, h2, 1);
                 HBAR_W(13, 14);                                                  // b'_6: V3 is complete
                 grow_finish(ga, bufX, grow0 + 64, gpq);
                 // x2 carry rows: nobody reads rows 0..4 of bufY any more, the conv3 epilogue (behind b'_7) overwrites rows 96..100
@@ -860,22 +895,20 @@ __global__ __launch_bounds__(512, 2) void fused_front_tc_kernel(Args a) {
                 prow_fetch(bases, t + FTT, nlo, nhi);
             }
             // head B's pair products of this step (x3 in bufY from B0 to the next conv2 epilogue): the first two passes requested
-            // beside the conv3 epilogue; behind B0, beside the matrix waves' w_v B: pass 0, the third pass's request, pass 1, V2 chunks
-            // 0, 1 of the next step, pass 2
+            // beside the conv3 epilogue; behind B0, beside the matrix waves' w_v B: pass 0, the third pass's request, pass 1, V2 chunk
+            // 0 of the next step (chunk 1: the matrix waves, behind their w_v B tile), pass 2
             pass_issue(p0, jb, 0, hw, lane);
             pass_issue(p1, jb, 1, hw, lane);
             GNN_TICK(13)
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             HBAR(13, 11);                                                        // ---- B0: x3 is in bufY, x1(s+1) in bufX
             TC_HPRIO_LOW();
-            load_x1(ra, h1, 0);
-            load_x1(rb, h1, 1);
+            load_rows(ra, h1, 0);
             pass_compute(p0, jb, 0, hw, lane);
             pass_issue(p0, jb, 2, hw, lane);
             pass_compute(p1, jb, 1, hw, lane);
-            transform_store<true>(ra, h1, 0);
-            load_x1(ra, h1, 2);
-            transform_store<true>(rb, h1, 1);
+            transform_store(ra, h1, 0);
+            load_rows(ra, h1, 2);
             GNN_TICK(15)
         }
         if (s_hi > s_lo) {                                  // head B's last pass of this run's last step

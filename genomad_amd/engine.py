@@ -69,6 +69,11 @@ class NNEngine:
         except Exception:
             pass
 
+    def pci_bus_id(self) -> str:
+        buf = C.create_string_buffer(32)
+        check(self.lib.gnn_device_pci_bus_id(self.ctx, buf, 32))
+        return buf.value.decode()
+
     def device_info(self) -> dict:
         name = C.create_string_buffer(256)
         cus, mem = C.c_int(), C.c_int64()

@@ -52,10 +52,9 @@ typedef enum gnn_precision {
     GNN_PREC_F32 = 0,        /* f32 reference path: unfused f32 kernels, activations in HBM   */
     GNN_PREC_BF16X3 = 1,     /* fused path: split-bf16 (hi+lo), 3 MFMA passes, f32 accumulate (gnn_fused_x3.hip); f32 range:
                                 what main() recomputes a batch with when an f16-operand mode returns non-finite scores */
-    GNN_PREC_BF16 = 2,       /* fused path: single bf16 MFMA pass (fails the 1e-4 tolerance;
-                                for roofline experiments only)                                */
-    GNN_PREC_F16C8 = 3,      /* EXPERIMENTAL, not in the default build (see "experimental" below): gnn_classify* return
-                                GNN_ERR_STATE for it unless the library was built with GNN_EXPERIMENTAL=1                       */
+    GNN_PREC_BF16 = 2,       /* REMOVED in round 6 (single bf16 MFMA pass, 7e-3: a roofline experiment).  The value is kept so that
+                                an old caller gets GNN_ERR_STATE with a message instead of another arithmetic                    */
+    GNN_PREC_F16C8 = 3,      /* REMOVED in round 6 (f16 + MX-fp8 correction MFMAs, 1.3e-4 on 10^6 windows).  GNN_ERR_STATE          */
     GNN_PREC_F16C6 = 5,      /* FROZEN opt-in fast mode (gnn_fused_c6.hip, not tuned any more): one f16 MFMA pass + MX-scaled fp6
                                 (e2m3) correction MFMAs, both operands block scaled = 1.5 pass equivalents; 8.2e-5 on config 2,
                                 1.2e-4 on a few of 10^6 windows - NO head-room under the 1e-4 tolerance (bench.py exits non-zero
@@ -68,19 +67,19 @@ typedef enum gnn_precision {
                                 (profiles/r04_tails.txt).  Needs |activation| < ~2000 (the transformed activations, up to 32x the
                                 activations, are f16 operands): beyond that the scores are non-finite, never silently wrong, and
                                 main() recomputes the batch along the chain F16X3TC -> F16X3 (f16 range, 65504) -> BF16X3 (f32
-                                range), logging every hop with the arithmetic that failed.  A window buffer that is not 4-byte
-                                aligned is served by the direct F16X3 form (round-1 kernel gnn_fused.hip, byte loads)           */
+                                range), logging every hop with the arithmetic that failed.  Since round 6 head A's y @ w_v rows
+                                are not computed but gathered from a 1.38 GB table of all 9-mers that gnn_load_weights builds on
+                                the device (x1[t] is a function of the bases t-5 .. t+3; f64 accumulation, rounded once).  A window
+                                buffer that is not 4-byte aligned goes through one aligned staging copy and the same kernel: the
+                                scores do not depend on the buffer's address                                                   */
     GNN_PREC_F16X3 = 4       /* the direct three-pass form (gnn_fused_x3.hip), the default of round 3: split-f16 (hi+lo, 11+11 significant
                                 bits), 3 MFMA passes, logits GEMM split-f16 x 3 on the matrix pipe, dense head exact f32: f32-class
                                 accuracy (within 2e-5 of the exact-f32 path on every one of 10^6 windows); needs |activation| < 65504
                                 (f16 range)                                   */
 } gnn_precision;
 
-/* ---- experimental -------------------------------------------------------------------
- * GNN_PREC_F16C8 (gnn_fused_c8.hip): one f16 MFMA pass + MX-scaled fp8 (e4m3) correction MFMAs of both operands' f16
- * rounding residuals = 2.0 pass equivalents.  Inside the 1e-4 tolerance on BASELINE config 2 (7.2e-5), outside it on 10^6
- * windows (1.3e-4, profiles/history/r02c6_tails.txt): it cannot ship, is frozen, and is linked only by
- * `GNN_EXPERIMENTAL=1 genomad_amd/csrc/build.sh`; the default library answers GNN_ERR_STATE.  1 = this build has it. */
+/* Kept for ABI compatibility: rounds 4 and 5 could link an experimental f16c8 kernel (GNN_EXPERIMENTAL=1); round 6 deleted it
+ * together with the round-1 kernel.  Always 0. */
 int gnn_has_experimental(void);
 
 typedef enum gnn_onehot_dtype { GNN_OH_U8 = 0, GNN_OH_BF16 = 1, GNN_OH_F32 = 2 } gnn_onehot_dtype;
@@ -147,6 +146,8 @@ int gnn_create(int device, gnn_ctx** out);
 int gnn_destroy(gnn_ctx* ctx);
 int gnn_sync(gnn_ctx* ctx);                      /* hipStreamSynchronize on the ctx stream */
 int gnn_device_info(gnn_ctx* ctx, char* name, size_t name_len, int* cus, int64_t* hbm_bytes);
+int gnn_device_pci_bus_id(gnn_ctx* ctx, char* out, size_t out_len);   /* "0000:05:00.0" of the ctx's device (hipDeviceGetPCIBusId): what bench.py
+                                                                         prints per rank, so that two ranks bound to one GPU are visible */
 int gnn_device_mem_info(gnn_ctx* ctx, int64_t* free_bytes, int64_t* total_bytes);   /* hipMemGetInfo of the ctx's device (what the default launch size is clamped against) */
 
 /* replaces nn_model.load_weights(GenomadData.nn_model_file), nn_classification.py:310 */

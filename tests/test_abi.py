@@ -68,6 +68,11 @@ def test_weight_validation_rejects_bad_tensors(synth_weights):
         weights.validate(bad)
 
 
+def lib_rows(code):
+    from genomad_amd import _lib
+    return _lib.load().gnn_fused_rows_per_step(code)
+
+
 def test_precision_enum_matches_the_binding_and_rows_per_step():
     """include/genomad_nn.h's gnn_precision values are what genomad_amd/_lib.py sends, and the (GPU-free) geometry query
     answers for every mode: 128 rows per fused step (32 * GNN_C6_NMB for f16c6, 96 = 32 Toom-Cook tiles for f16x3tc), 0 for the
@@ -76,7 +81,10 @@ def test_precision_enum_matches_the_binding_and_rows_per_step():
     text = open(os.path.join(ROOT, "include", "genomad_nn.h")).read()
     text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
     enum = {name.lower(): int(val) for name, val in re.findall(r"GNN_PREC_([A-Z0-9]+)\s*=\s*(\d+)", text)}
+    # the two arithmetics round 6 removed keep their enum values (old callers get GNN_ERR_STATE) and have no name on the Python side
+    assert enum.pop("bf16") == _lib.PREC_BF16 == 2 and enum.pop("f16c8") == _lib.PREC_F16C8 == 3
     assert enum == _lib.PRECISIONS
+    assert lib_rows(_lib.PREC_BF16) < 0 and lib_rows(_lib.PREC_F16C8) < 0
     lib = _lib.load()
     for name, val in _lib.PRECISIONS.items():
         rows = lib.gnn_fused_rows_per_step(val)

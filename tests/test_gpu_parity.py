@@ -169,23 +169,9 @@ def test_errors_are_reported_not_swallowed(engine):
 # correction MFMAs (gnn_fused_c8.hip), f16x3 / bf16x3 = split-f16 / split-bf16, three passes (gnn_fused.hip).
 # Per-stage tolerances are absolute, against the fp64 oracle.
 # The parametrised matrix covers the arithmetics that can ship: the default (f16x3), its f32-range fallback (bf16x3) and the one
-# opt-in fast mode (f16c6).  f16c8 and the round-1 kernel are frozen: one smoke test each
-# (test_frozen_f16c8_kernel_smoke, test_single_pass_bf16_is_outside_tolerance_but_sane).
+# opt-in fast mode (f16c6).  f16c8 and the round-1 kernel (single-pass bf16) were removed in round 6: one test that the enum values answer
+# with an error (test_removed_arithmetics_answer_with_an_error).
 FUSED = ["f16c6", "f16x3", "f16x3tc", "bf16x3"]
-
-
-def _has_experimental() -> bool:
-    """the f16c8 kernel is linked only by GNN_EXPERIMENTAL=1 builds (include/genomad_nn.h, "experimental")"""
-    from genomad_amd import _lib
-    return bool(_lib.load().gnn_has_experimental())
-
-
-def _with_c8(precs):
-    """the list with "f16c8" only where this build has it"""
-    return [p for p in precs if p != "f16c8" or _has_experimental()]
-
-
-needs_experimental = pytest.mark.skipif(not _has_experimental(), reason="f16c8 is experimental: GNN_EXPERIMENTAL=1 genomad_amd/csrc/build.sh")
 # the contig front end is exercised with the default arithmetic first (what main() runs), then the fallback
 from genomad_amd._lib import DEFAULT_PRECISION  # noqa: E402
 CONTIG_PRECS = [DEFAULT_PRECISION, "bf16x3"]
@@ -196,7 +182,7 @@ def test_fused_intermediates(engine, oracle16, prec):
     """Fused kernels (activations in LDS, low-precision MFMA operands) against the fp64 oracle, per stage."""
     bases, scores64, t64 = oracle16
     scores, taps = engine.debug_forward(bases, prec)
-    loose = {"f16c6": 2.5, "f16c8": 2.5, "f16x3": 0.25, "f16x3tc": 0.25}.get(prec, 1.0)   # 4-bit correction terms / 11+11-bit limbs vs bf16's 8+8
+    loose = {"f16c6": 2.5, "f16x3": 0.25, "f16x3tc": 0.25}.get(prec, 1.0)   # 4-bit correction terms / 11+11-bit limbs vs bf16's 8+8
     checks = [("m_a", "mA", 1e-4), ("m_b", "mB", 1e-3), ("yp_a", "ypA", 1e-4), ("yp_b", "ypB", 1e-3),
               ("alpha_a", "alphaA", 1e-5), ("alpha_b", "alphaB", 2e-4), ("feat", "f", 5e-4)]
     for mine, ref, tol in checks:
@@ -245,46 +231,24 @@ def test_fused_edge_windows(engine, synth_weights, prec):
     assert engine.classify(bases[:0], prec).shape == (0, 3)
 
 
-def test_default_build_answers_f16c8_with_an_error(engine):
-    """the default library has no f16c8 kernel and says so instead of computing something else."""
-    from genomad_amd._lib import GnnError
-    if _has_experimental():
-        pytest.skip("experimental build")
-    with pytest.raises(GnnError, match="experimental"):
-        engine.classify(synthetic.synth_windows(0, 2), "f16c8")
-
-
-@needs_experimental
-def test_frozen_f16c8_kernel_smoke(engine, synth_weights):
-    """f16c8 (gnn_fused_c8.hip) is frozen: kept buildable and inside the tolerance on a small batch, no longer in the matrix."""
-    bases = synthetic.synth_windows(0, 64)
-    got = engine.classify(bases, "f16c8")
-    assert np.abs(got - igloo_oracle.classify_windows(bases, synth_weights, np.float32)).max() <= SCORE_TOL
-    assert np.array_equal(got[11:19], engine.classify(bases[11:19], "f16c8"))
-
-
-@needs_experimental
-def test_f16c8_large_activations_saturate_instead_of_nan(synth_weights):
-    """The e4m3 images of the f16c8 operands are clamped at +-448 (v_cvt_pk_fp8_f32 returns NaN above 464):
-    with conv1 weights scaled up until activations pass that bound the fused path must stay finite and
-    close to the exact f32 path (the correction terms merely lose accuracy there)."""
-    from genomad_amd.engine import NNEngine
-    w = dict(synth_weights)
-    # LeakyReLU is positively homogeneous: scaling conv1 (kernel and bias) by s scales x1 by s exactly; its three
-    # consumers are scaled back by 1/s, so the network computes the same function with |x1| up to ~900
-    for k, f in (("conv1_kernel", 400.0), ("conv1_bias", 400.0), ("conv2_kernel", 1 / 400.0),
-                 ("iglooA_w_mult", 1 / 400.0), ("iglooA_w_v", 1 / 400.0)):
-        w[k] = synth_weights[k] * np.float32(f)
-    bases = synthetic.synth_windows(0, 8)
-    with NNEngine(0, w) as e2:
-        _, taps = e2.debug_forward(bases, "f32", taps=("x1",))
-        assert np.abs(taps["x1"]).max() > 500.0        # beyond the 464 where the conversion turns to NaN
-        got, exact = e2.classify(bases, "f16c8"), e2.classify(bases, "f32")
-        got6 = e2.classify(bases, "f16c6")
-    assert np.isfinite(got).all() and exact.std(axis=0).min() > 0.01
-    assert np.abs(got - exact).max() <= 1e-3
-    # the block-scaled fp6 images of f16c6 follow the activations' magnitude: no clamp, full accuracy
-    assert np.isfinite(got6).all() and np.abs(got6 - exact).max() <= SCORE_TOL
+def test_removed_arithmetics_answer_with_an_error(engine):
+    """GNN_PREC_BF16 (round-1 kernel) and GNN_PREC_F16C8 (experimental kernel) are gone; their enum values
+    answer GNN_ERR_STATE with a message instead of computing something else, and the Python side no longer knows the names."""
+    import ctypes as C
+    from genomad_amd import _lib
+    assert "bf16" not in _lib.PRECISIONS and "f16c8" not in _lib.PRECISIONS
+    assert _lib.load().gnn_has_experimental() == 0
+    buf, out = engine.alloc(2 * 6000), engine.alloc(2 * 12)
+    try:
+        engine.synth_windows_dev(0, 2, buf.ptr)
+        for code in (_lib.PREC_BF16, _lib.PREC_F16C8):
+            rc = engine.lib.gnn_classify_dev(engine.ctx, C.c_void_p(buf.ptr), 2, code, C.c_void_p(out.ptr))
+            assert rc == -3 and b"removed in round 6" in engine.lib.gnn_last_error()          # GNN_ERR_STATE
+        with pytest.raises(KeyError):
+            engine.classify(synthetic.synth_windows(0, 2), "f16c8")
+    finally:
+        buf.free()
+        out.free()
 
 
 def _scaled_activations(synth_weights, f):
@@ -414,7 +378,7 @@ def test_f16_modes_overflow_is_detected_and_main_falls_back_to_bf16x3(synth_weig
     with NNEngine(0, w) as e2:
         exact, wide = e2.classify(bases, "f32"), e2.classify(bases, "bf16x3")
         assert np.isfinite(wide).all() and np.abs(wide - exact).max() <= 1e-3
-        for prec in _with_c8(("f16c8", "f16c6", "f16x3", "f16x3tc")):
+        for prec in ("f16c6", "f16x3", "f16x3tc"):
             assert not np.isfinite(e2.classify(bases, prec)).all(), prec
         wpath = tmp_path / "w.npz"
         W.save_npz(wpath, w)
@@ -427,14 +391,6 @@ def test_f16_modes_overflow_is_detected_and_main_falls_back_to_bf16x3(synth_weig
         want, _ = e2.classify_contigs(seq, off, False, "bf16x3")
     assert np.isfinite(z["predictions"]).all() and np.array_equal(z["predictions"], want)
     assert "recomputing" in (tmp_path / "out" / "s_nn_classification.log").read_text()
-
-
-def test_single_pass_bf16_is_outside_tolerance_but_sane(engine, oracle16):
-    """GNN_PREC_BF16 exists for roofline experiments; document that it misses the 1e-4 tolerance."""
-    bases, scores64, _ = oracle16
-    got = engine.classify(bases, "bf16")
-    err = np.abs(got - scores64).max()
-    assert 1e-4 < err < 5e-2, f"single-pass bf16 max |dscore| = {err:.3e}"
 
 
 # ------------------------------------------------------------------ drop-in entry point on the GPU
@@ -911,14 +867,12 @@ def test_second_weight_set_and_engine(synth_weights):
     want = igloo_oracle.classify_windows(bases, w2, np.float32)
     with NNEngine(0, w2) as e2:
         got = e2.classify(bases, "bf16x3")
-        got8 = e2.classify(bases, "f16c8") if _has_experimental() else None
         got6 = e2.classify(bases, "f16c6")
         got16 = e2.classify(bases, "f16x3")
         exact = e2.classify(bases, "f32")
     assert np.abs(exact - want).max() <= 2e-5
     assert np.abs(got16 - want).max() <= 2e-5
     assert np.abs(got - want).max() <= SCORE_TOL
-    assert got8 is None or np.abs(got8 - want).max() <= SCORE_TOL
     assert np.abs(got6 - want).max() <= SCORE_TOL
     assert not np.array_equal(got, np.zeros_like(got))
     w3 = _calibrated_weights(43)
@@ -926,11 +880,11 @@ def test_second_weight_set_and_engine(synth_weights):
     with NNEngine(0, w3) as e3:
         exact = e3.classify(big, "f32")
         assert exact.std(axis=0).min() > 0.05, exact.std(axis=0)          # every class score varies: the check is not vacuous
-        err = {prec: float(np.abs(e3.classify(big, prec) - exact).max()) for prec in _with_c8(("f16x3", "f16x3tc", "bf16x3", "f16c8", "f16c6"))}
+        err = {prec: float(np.abs(e3.classify(big, prec) - exact).max()) for prec in ("f16x3", "f16x3tc", "bf16x3", "f16c6")}
     print("seed-43 weights (calibrated), 4096 windows, max |dscore| vs the exact-f32 path:", err)
     assert DEFAULT_PRECISION == "f16x3tc" and err["f16x3tc"] <= SCORE_TOL / 4 and err["f16x3"] <= SCORE_TOL / 4
     assert err["bf16x3"] <= SCORE_TOL
-    assert err.get("f16c8", 0.0) <= 2 * SCORE_TOL and err["f16c6"] <= 2 * SCORE_TOL
+    assert err["f16c6"] <= 2 * SCORE_TOL
 
 
 @pytest.mark.parametrize("prec", ["f16c6", "f16x3", "f16x3tc", "bf16x3"])
@@ -967,34 +921,25 @@ def test_padding_skip_is_bit_identical(engine, prec):
     assert np.abs(skip - exact).max() <= SCORE_TOL
 
 
-def test_f16c6_rejects_a_misaligned_window_buffer(engine):
-    """The f16c6 kernel fetches the bases of its pair rows as aligned dwords: a device buffer that does not start on a
-    4-byte boundary is refused with an error (every gnn_dev_alloc / staging buffer is aligned), other modes take it."""
-    from genomad_amd._lib import GnnError
-    buf = engine.alloc(2 * 6000 + 8)
-    out = engine.alloc(2 * 12)
+def test_a_misaligned_window_buffer_gives_the_same_scores(engine):
+    """the streaming kernels fetch bases as aligned dwords.  A device buffer a caller offsets by 1, 2 or 3 bytes goes
+    through one aligned staging copy and the SAME kernel: bit-identical scores for every fused arithmetic (until round 5 the round-1
+    kernel served such buffers: another kernel, several times slower, other bits, no message; f16c6 refused them).  Reference shape:
+    nn_classification.py:316-317 - any batch at any offset gives the same scores."""
+    n = 300                                        # more than one round of workgroups, not a multiple of anything
+    buf = engine.alloc(n * 6000 + 8)
+    out = engine.alloc(n * 12)
     try:
-        engine.synth_windows_dev(0, 2, buf.ptr)
+        engine.synth_windows_dev(0, n, buf.ptr)
         engine.sync()
-        host = buf.download((2 * 6000 + 8,), np.uint8)
-        shifted = np.concatenate([np.zeros(1, np.uint8), host[:2 * 6000]])
-        buf.upload(np.concatenate([shifted, np.zeros(7, np.uint8)]))
-        with pytest.raises(GnnError, match="4-byte aligned"):
-            engine.classify_dev(buf.ptr + 1, 2, out.ptr, "f16c6")
-        if _has_experimental():
-            engine.classify_dev(buf.ptr + 1, 2, out.ptr, "f16c8")
-            engine.sync()
-            got = out.download((2, 3), np.float32)
-            want = engine.classify(host[:2 * 6000].reshape(2, 6000), "f16c8")
-            assert np.array_equal(got, want)
-        # the three-pass modes take it too: the round-1 kernel (byte loads) serves such a buffer instead of the streaming
-        # one; same arithmetic, sums in another order -> equal within f32 rounding, far inside the tolerance
-        for prec in ("f16x3", "f16x3tc", "bf16x3"):
-            engine.classify_dev(buf.ptr + 1, 2, out.ptr, prec)
-            engine.sync()
-            got = out.download((2, 3), np.float32)
-            want = engine.classify(host[:2 * 6000].reshape(2, 6000), prec)
-            assert np.abs(got - want).max() <= 2e-5, prec
+        host = buf.download((n * 6000,), np.uint8)
+        want = {prec: engine.classify(host.reshape(n, 6000), prec) for prec in FUSED}
+        for shift in (1, 2, 3):
+            buf.upload(np.concatenate([np.zeros(shift, np.uint8), host, np.zeros(8 - shift, np.uint8)]))
+            for prec in FUSED:
+                engine.classify_dev(buf.ptr + shift, n, out.ptr, prec)
+                engine.sync()
+                assert np.array_equal(out.download((n, 3), np.float32), want[prec]), (shift, prec)
     finally:
         buf.free()
         out.free()

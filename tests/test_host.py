@@ -949,6 +949,66 @@ def test_bench_n8_line_is_complete_over_the_fake_engine(tmp_path):
     assert "failed" not in o
 
 
+def test_bench_reports_a_dying_rank_with_one_json_line(tmp_path):
+    """the first 8-GPU run of bench.py happens unattended.  A rank that dies (here: rank 3 of 4 on entering the
+    gather; rank 1 of 2 in the timed region under the driver's launcher) must leave ONE JSON line on stdout with "error", the rank,
+    the stage, the RCCL ranks seen and the library's last error, a non-zero exit code, and no hanging peers."""
+    import socket
+    import subprocess
+    import time
+    root = Path(__file__).resolve().parents[1]
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT", "OMP_NUM_THREADS")}
+    env.update(GENOMAD_AMD_BENCH_FAKE_ENGINE="1", OPENBLAS_NUM_THREADS="2", GENOMAD_AMD_BENCH_TEST_FAIL="3:gather")
+    t = time.time()
+    r = subprocess.run([sys.executable, str(root / "bench.py"), "--gpus", "4", "--steps", "4", "--warmup", "1", "--windows-per-step", "1024",
+                        "--cpu-sample", "0"], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode != 0 and time.time() - t < 120
+    lines = [json.loads(x) for x in r.stdout.splitlines() if x.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    o = lines[0]
+    assert o["error"] == "RuntimeError" and o["rank"] == 3 and o["world"] == 4 and o["stage"] == "gather" and o["rccl_ranks"] == 4
+    assert o["value"] is None and "gnn_last_error" in o and "GENOMAD_AMD_BENCH_TEST_FAIL" in o["detail"]
+    assert "rank 0 FAILED in stage" in r.stderr                              # the peers were stopped, and said where they were
+    pytest.importorskip("torch")
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    env["GENOMAD_AMD_BENCH_TEST_FAIL"] = "1:timed"
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                        "--master-port", str(port), str(root / "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "1",
+                        "--windows-per-step", "512", "--cpu-sample", "0"], env=env, capture_output=True, text=True, timeout=900, cwd=str(root))
+    assert r.returncode != 0
+    lines = [json.loads(x) for x in r.stdout.splitlines() if x.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    assert lines[0]["rank"] == 1 and lines[0]["stage"] == "timed" and lines[0]["error"] == "RuntimeError"
+
+
+def test_out_of_tolerance_arithmetics_need_an_explicit_opt_in(monkeypatch):
+    """f16c6 is documented to leave the 1e-4 tolerance on 10^6 windows (1.2e-4) and a 64-window sentinel cannot see a
+    1-in-10^5 tail - main() refuses it unless GENOMAD_AMD_ALLOW_OUT_OF_TOLERANCE=1, and then says so once per run; the two arithmetics
+    round 6 removed (bf16, f16c8) are unknown names."""
+    monkeypatch.setenv("GENOMAD_AMD_PRECISION", "f16c6")
+    monkeypatch.delenv("GENOMAD_AMD_ALLOW_OUT_OF_TOLERANCE", raising=False)
+    with pytest.raises(ValueError, match="GENOMAD_AMD_ALLOW_OUT_OF_TOLERANCE"):
+        nnc.configured_precision()
+    monkeypatch.setenv("GENOMAD_AMD_ALLOW_OUT_OF_TOLERANCE", "1")
+    assert nnc.configured_precision() == "f16c6"
+    said = []
+
+    class Console:
+        def log(self, msg):
+            said.append(msg)
+    nnc._WARNED.discard(("oot", "f16c6"))
+    nnc._warn_out_of_tolerance(Console(), "f16c6")
+    nnc._warn_out_of_tolerance(Console(), "f16c6")
+    nnc._warn_out_of_tolerance(Console(), "f16x3tc")
+    assert len(said) == 1 and "OUTSIDE the 1e-4" in said[0] and "1.2e-04" in said[0]
+    for gone in ("bf16", "f16c8"):
+        monkeypatch.setenv("GENOMAD_AMD_PRECISION", gone)
+        with pytest.raises(ValueError, match="expected one of"):
+            nnc.configured_precision()
+
+
 # ------------------------------------------------------------------ sharded FASTA validation (VERDICT r03 item 7)
 class _FakeContigEngine:
     """classify_contigs of the device front end with a fixed function of the contig bytes in place of the network."""

@@ -143,9 +143,13 @@ def tc_schedule(steps: int = 4, ahead: int = 2):
                 ph += [("helper", "r", prow(s + 1), ("prow", s + 1), True),             # gather round 1: table loads
                        ("matrix", "w", "bufY.rows", ("x2", s), True)]                   # conv2 epilogue (the helpers touch bufX only)
             yield ph
-        yield [("matrix", "r", "bufX.rows", ("x1", s), True),                           # ---- B1 .. b'_0: w_v A(s)
+        # ---- B1 .. b'_0.  Round 6: head A's y @ w_v comes from the 9-mer table (no LDS access), the matrix waves make V3 chunk 1 while
+        # their table rows travel, the helpers chunk 0 and head A's last pair pass (x1(s) stays in bufX until the gather behind b'_0)
+        yield [("matrix", "r", "bufY.rows", ("x2", s), True), ("matrix", "r", "bufY.carry", ("x2c", s - 1), True),
+               ("matrix", "w", ring(1), ("c3", s, 1), True),
+               ("helper", "r", "bufX.rows", ("x1", s), True),
                ("helper", "r", "bufY.rows", ("x2", s), True), ("helper", "r", "bufY.carry", ("x2c", s - 1), True),
-               ("helper", "w", ring(0), ("c3", s, 0), True), ("helper", "w", ring(1), ("c3", s, 1), True)]
+               ("helper", "w", ring(0), ("c3", s, 0), True)]
         for c in range(8):                                                   # ---- conv3: b'_0 .. b'_7
             ph = conv_phase("c3", s, c, "bufY.rows", ("x2", s), "bufY.carry", ("x2c", s - 1))
             if c == 0:
@@ -160,10 +164,12 @@ def tc_schedule(steps: int = 4, ahead: int = 2):
                 ph += [("helper", "w", prow(s + 2), ("prow", s + 2), True),
                        ("matrix", "w", "bufY.rows", ("x3", s), True)]                   # conv3 epilogue overwrites x2 with x3
             yield ph
-        yield [("matrix", "r", "bufY.rows", ("x3", s), True),                           # ---- B0 .. b_0: w_v B(s)
+        yield [("matrix", "r", "bufY.rows", ("x3", s), True),                           # ---- B0 .. b_0: w_v B(s), then V2(s+1) chunk 1
+               ("matrix", "r", "bufX.rows", ("x1", s + 1), True), ("matrix", "r", "bufX.carry", ("x1c", s), True),
+               ("matrix", "w", ring(1), ("c2", s + 1, 1), True),
                ("helper", "r", "bufY.rows", ("x3", s), True),                           # head B's pair products
                ("helper", "r", "bufX.rows", ("x1", s + 1), True), ("helper", "r", "bufX.carry", ("x1c", s), True),
-               ("helper", "w", ring(0), ("c2", s + 1, 0), True), ("helper", "w", ring(1), ("c2", s + 1, 1), True)]
+               ("helper", "w", ring(0), ("c2", s + 1, 0), True)]
 
 
 def test_toomcook_kernel_schedule_orders_every_lds_producer_and_consumer_with_a_barrier():
