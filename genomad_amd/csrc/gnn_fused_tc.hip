@@ -74,9 +74,10 @@ constexpr int SMEMT = LAST_OFF + 16;
 constexpr int ROW_U4 = ROWX / 16;
 constexpr int WNBLK_B = 2048;                // weight bytes per (unit, [xi,] n-block): hi fragment | lo fragment
 constexpr int WUNIT_B = 4 * WNBLK_B;         // per k16 unit (w_v) / per (k16 unit, xi) (convs)
-constexpr int RINGV = 4;                     // w_v tiles: weight ring slots
+constexpr int RINGV = 8;                     // w_v tile: all 8 k16 units of its weights are loaded up front
 constexpr int RINGT = 8;                     // convs: weight ring slots of one (unit, xi); 7 in flight ahead of the MFMAs
 static_assert(SMEMT <= 160 * 1024, "LDS budget");
+static_assert(RINGV <= RINGT, "the w_v tile's weights live in the conv loops' ring registers");
 static_assert(T == 3 * 1999, "the tiles tile the window exactly");
 
 struct Args {
@@ -170,62 +171,52 @@ __device__ __forceinline__ void load_xu(XU& f, const unsigned char* __restrict__
         f.l[mb] = *reinterpret_cast<const uint4*>(xh + OFF + LOX + mb * 32 * ROWX);
     }
 }
-// DROPWL (pricing probe -DTC_WVA_DROP, round 5; changes results): the tile without its x_hi * w_lo product = w_v rounded to ONE f16 limb
-template <bool LX, int OFFN, bool DROPWL = false, bool FILL = false, class Stage>
-__device__ __forceinline__ void wv_unit(const WU& wc, WU& wl, bool lw, const XU& xc, XU& xl, const unsigned char* __restrict__ xh, wrsrc_t wr,
-                                        int wnext, uint32_t l16, f32x16 (&acc)[NMB], Stage&& stage) {
+// one k16 unit of the tile: 9 MFMAs (3 row blocks x 3 limb products), the next unit's six row reads interleaved 1:1 behind the first six
+template <bool LX, int OFFN>
+__device__ __forceinline__ void wv_unit(const WU& wc, const XU& xc, XU& xl, const unsigned char* __restrict__ xh, f32x16 (&acc)[NMB]) {
     if constexpr (LX) load_xu<OFFN>(xl, xh);
-    if (lw) load_wu(wl, wr, l16, wnext);
 #pragma unroll
     for (int mb = 0; mb < NMB; ++mb) {
         if (mb % 2 == 0) {
-            if constexpr (!DROPWL) acc[mb] = mma(xc.h[mb], wc.l, acc[mb]);
+            acc[mb] = mma(xc.h[mb], wc.l, acc[mb]);
             acc[mb] = mma(xc.h[mb], wc.h, acc[mb]);
             acc[mb] = mma(xc.l[mb], wc.h, acc[mb]);
         } else {
             acc[mb] = mma(xc.l[mb], wc.h, acc[mb]);
             acc[mb] = mma(xc.h[mb], wc.h, acc[mb]);
-            if constexpr (!DROPWL) acc[mb] = mma(xc.h[mb], wc.l, acc[mb]);
+            acc[mb] = mma(xc.h[mb], wc.l, acc[mb]);
         }
     }
-    stage();                 // TC_PAIRS_MATRIX: this unit's slice of the pair products (16 FMAs + the next slice's two row reads); else empty
 #pragma unroll
-    for (int i = 0; i < (DROPWL ? 2 : 3) * NMB; ++i) {
+    for (int i = 0; i < 3 * NMB; ++i) {
         __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-        if (FILL) __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);
-        if ((LX && i < 2 * NMB) || (FILL && i >= 2 * NMB && i < 2 * NMB + 2)) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-        if (i == 1 || i == 5) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+        if (LX && i < 2 * NMB) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
     }
     GNN_REGION_END();
 }
 // D = X W over the 96 rows that start at buffer row CARRY of `xoff`: a lane ends up with 16 rows of one channel per row block.
-// The ring's first RINGV - 1 units were requested by prime_wv.
-template <bool DROPWL = false, bool FILL = false, class StageFn>
-__device__ __forceinline__ void wv_tile(const unsigned char* __restrict__ smem, int xoff, wrsrc_t wr, int woff, WU (&ring)[RINGT],
-                                        f32x16 (&acc)[NMB], int lane, StageFn&& stagefn) {
+// All 8 weight units are in the ring (prime_wv, requested before the conv3 epilogue): the tile issues no memory request - it runs
+// while head A's table rows of the next step travel (requested right in front of it), and a wave's request behind 96 missing lines
+// waits at issue until the vector L1 has room.
+__device__ __forceinline__ void wv_tile(const unsigned char* __restrict__ smem, int xoff, const WU (&ring)[RINGT], f32x16 (&acc)[NMB], int lane) {
     uint32_t rowoff = (uint32_t)xoff + (uint32_t)(lane & 31) * ROWX + (uint32_t)(lane >> 5) * 16u;
     asm volatile("" : "+v"(rowoff));
     const unsigned char* xh = smem + rowoff;
-    const uint32_t l16 = (uint32_t)lane * 16u;
     XU xa, xb;
     load_xu<0>(xa, xh);
     GNN_REGION_END();
     static_for(std::make_integer_sequence<int, 8>{}, [&](auto kc) {
         constexpr int k = decltype(kc)::value, kn = k + 1;
         constexpr int OFFN = kn * 32;
-        constexpr bool LX = kn < 8, LW = k + RINGV - 1 < 8;
-        if constexpr (k % 2 == 0)
-            wv_unit<LX, OFFN, DROPWL, FILL>(ring[k % RINGV], ring[(k + RINGV - 1) % RINGV], LW, xa, xb, xh, wr, woff + (k + RINGV - 1) * WUNIT_B, l16, acc,
-                                            [&]() { stagefn(kc); });
-        else
-            wv_unit<LX, OFFN, DROPWL, FILL>(ring[k % RINGV], ring[(k + RINGV - 1) % RINGV], LW, xb, xa, xh, wr, woff + (k + RINGV - 1) * WUNIT_B, l16, acc,
-                                            [&]() { stagefn(kc); });
+        constexpr bool LX = kn < 8;
+        if constexpr (k % 2 == 0) wv_unit<LX, OFFN>(ring[k], xa, xb, xh, acc);
+        else wv_unit<LX, OFFN>(ring[k], xb, xa, xh, acc);
     });
 }
-__device__ __forceinline__ void prime_wv(WU (&ring)[RINGT], wrsrc_t wr, int woff, int lane) {
+__device__ __forceinline__ void prime_wv(WU (&ring)[RINGT], wrsrc_t wr, int lane) {
     const uint32_t l16 = (uint32_t)lane * 16u;
 #pragma unroll
-    for (int u = 0; u < RINGV - 1; ++u) load_wu(ring[u], wr, l16, woff + u * WUNIT_B);
+    for (int u = 0; u < RINGV; ++u) load_wu(ring[u], wr, l16, u * WUNIT_B);
     asm volatile("" ::: "memory");
 }
 
@@ -687,12 +678,19 @@ __global__ __launch_bounds__(512, 2) void fused_front_tc_kernel(Args a) {
         const wrsrc_t yp_w = make_wrsrc(reinterpret_cast<const unsigned char*>(a.yp + wi * 2 * (size_t)POOLED * C), 2 * POOLED * C * 4);
         WU ring[RINGT];
         prime_tc(ring, cw[0], 0, lane);
-        // head A's table rows: the lane's row index of a step is computed a step ahead (behind B1, while the table rows of the current
-        // step travel), from bases fetched a step before that: no memory round trip in front of the requests
+        // head A's table rows of step s+1 are requested behind B0 of step s and pooled at the end of that interval: their round trip
+        // (~4 k cycles with 384 missing lines per CU in flight) hides behind the w_v B tile.  The lane's row index is computed a step
+        // ahead of the request from bases fetched a step before that: no memory round trip in front of the requests
         WvaBytes wb;
         wva_fetch(wb, bases, wva_row(s_begin * FTT, hw, lane));
-        uint32_t wva_next = wva_index(wb, wva_row(s_begin * FTT, hw, lane));
-        wva_fetch(wb, bases, wva_row((s_begin + 1) * FTT, hw, lane));
+        {                                                                        // the first step's rows: nothing to hide their round trip behind
+            WvaRows w0;
+            wva_issue(w0, tblr, wva_index(wb, wva_row(s_begin * FTT, hw, lane)), lane);
+            wva_fetch(wb, bases, wva_row((s_begin + 1) * FTT, hw, lane));
+            if (s_begin >= s_lo && s_begin < s_hi) wva_pool_store(w0, yp_w, s_begin * FTT, hw, lane);      // not a warm-up step
+        }
+        uint32_t wva_next = wva_index(wb, wva_row((s_begin + 1) * FTT, hw, lane));
+        wva_fetch(wb, bases, wva_row((s_begin + 2) * FTT, hw, lane));
         __syncthreads();                                                         // x1 of the first step is in bufX
         if constexpr (PROF) tick_ = __builtin_readcyclecounter();
 #pragma unroll 1
@@ -711,24 +709,15 @@ __global__ __launch_bounds__(512, 2) void fused_front_tc_kernel(Args a) {
             GNN_TICK(1)
             TC_BARRIER_W();                                                      // ---- B1: x2 is in bufY
             GNN_TICK(2)
-            // The interval in which the matrix waves used to compute head A's y @ w_v.  Now: conv3's first weights, the step's 24 table
-            // rows per wave (all of them requested here: 384 missing lines per CU are more than the vector L1 keeps in flight, so a wave
-            // that requests them BEFORE the epilogue stalls at issue and the epilogue - which the helpers wait for - runs 1.7 k cycles
-            // longer, profiles/r06/), and while they travel (~4 k cycles) chunk 1 of V3 - the helpers make chunk 0 meanwhile - and the
-            // next step's row indices.  The requests are unconditional: behind `if (store)` the register allocator spills 8 of the 24
-            // rows and waits for each; a warm-up step of a time-split run reads its rows for nothing.
+            // The interval in which the matrix waves used to compute head A's y @ w_v: conv3's first weights and chunk 1 of V3 (the
+            // helpers make chunk 0 meanwhile)
             prime_tc(ring, cw[1], 0, lane);
-            WvaRows wr;
-            wva_issue(wr, tblr, wva_next, lane);
             {
                 const HLane h2m = hlane(smem, BUF_BYTES, hw, lane);
                 Raw16 rm;
                 load_rows(rm, h2m, 1);
                 transform_store(rm, h2m, 1);
             }
-            wva_next = wva_index(wb, wva_row(t0 + FTT, hw, lane));
-            wva_fetch(wb, bases, wva_row(t0 + 2 * FTT, hw, lane));
-            if (store) wva_pool_store(wr, yp_w, t0, hw, lane);
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                  // chunk 1's fragments have landed before b'_0 releases the readers
             GNN_TICK(3)
 #pragma unroll
@@ -737,18 +726,24 @@ __global__ __launch_bounds__(512, 2) void fused_front_tc_kernel(Args a) {
                 for (int r = 0; r < 16; ++r) acc[xi][r] = 0.f;
             conv_tc(smem, cw[1], 0, ring, acc, lane, jitter_state);                         // b'_0 .. b'_7, conv3
             GNN_TICK(4)
-            prime_wv(ring, vw, 0, lane);
+            prime_wv(ring, vw, lane);
             epilogue_x3(bufY, acc, a.inv_s[1], bias_s + C, hw, lane);
             GNN_TICK(5)
             TC_BARRIER_W();                                                      // ---- B0: x3 is in bufY
             GNN_TICK(6)
             {
+                // head A's 24 table rows per wave of the NEXT step, all requested here (unconditionally: behind a branch the register
+                // allocator spills 8 of the 24 rows and waits for each; the last step of a run reads rows nobody stores): 384 missing
+                // lines per CU are more than the vector L1 keeps in flight, so whoever requests memory behind them waits at issue -
+                // the w_v B tile has its weights already, and the rows are pooled at the end of the interval
+                WvaRows wr;
+                wva_issue(wr, tblr, wva_next, lane);
                 f32x16 ac[NMB];
 #pragma unroll
                 for (int mb = 0; mb < NMB; ++mb)
 #pragma unroll
                     for (int r = 0; r < 16; ++r) ac[mb][r] = 0.f;
-                wv_tile(smem, BUF_BYTES + CARRY * ROWX, vw, 0, ring, ac, lane, [](auto) {});
+                wv_tile(smem, BUF_BYTES + CARRY * ROWX, ring, ac, lane);
                 prime_tc(ring, cw[0], 0, lane);
                 if (store) wv_pool_store(ac, yp_w, POOLED * C * 4, t0, hw, lane);
                 {                                                                // V2 chunk 1 of the next step (x1(s+1) is in bufX since B0)
@@ -756,8 +751,11 @@ __global__ __launch_bounds__(512, 2) void fused_front_tc_kernel(Args a) {
                     Raw16 rm;
                     load_rows(rm, h1m, 1);
                     transform_store(rm, h1m, 1);
-                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 }
+                wva_next = wva_index(wb, wva_row(t0 + 2 * FTT, hw, lane));       // row indices of step s+2 from the bases fetched a step ago
+                wva_fetch(wb, bases, wva_row(t0 + 3 * FTT, hw, lane));
+                if (step + 1 >= s_lo && step + 1 < s_hi) wva_pool_store(wr, yp_w, t0 + FTT, hw, lane);
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");               // chunk 1's fragments have landed before b_0 releases the readers
             }
         }
     } else {

@@ -385,12 +385,17 @@ def test_f16_modes_overflow_is_detected_and_main_falls_back_to_bf16x3(synth_weig
         monkeypatch.setenv("GENOMAD_AMD_WEIGHTS", str(wpath))
         monkeypatch.setenv("GENOMAD_AMD_PRECISION", "f16c6")
         monkeypatch.setattr(nnc, "_ENGINE", e2)
+        with pytest.raises(ValueError, match="GENOMAD_AMD_ALLOW_OUT_OF_TOLERANCE"):          # round 6: the out-of-tolerance mode needs an explicit opt-in
+            nnc.main(fa, tmp_path / "out", False, 128, False, 1, False, False)
+        monkeypatch.setenv("GENOMAD_AMD_ALLOW_OUT_OF_TOLERANCE", "1")
+        nnc._WARNED.clear()                                       # the one-line warnings are said once per process
         nnc.main(fa, tmp_path / "out", False, 128, False, 1, False, False)
         z = np.load(tmp_path / "out" / "s_nn_classification" / "s_nn_classification.npz")
         names, seq, off = sequence.read_fasta_packed(fa)
         want, _ = e2.classify_contigs(seq, off, False, "bf16x3")
     assert np.isfinite(z["predictions"]).all() and np.array_equal(z["predictions"], want)
-    assert "recomputing" in (tmp_path / "out" / "s_nn_classification.log").read_text()
+    log = (tmp_path / "out" / "s_nn_classification.log").read_text()
+    assert "recomputing" in log and "OUTSIDE the 1e-4 score tolerance" in log
 
 
 # ------------------------------------------------------------------ drop-in entry point on the GPU
