@@ -292,6 +292,23 @@ __device__ __forceinline__ uint32_t wva_index(const WvaBytes& b, int t) {
     // t < 5: the bytes behind the np present ones are ordinary bases of the window; they only decide `worst`, which is not used then
     return t < 5 ? WvaTable::s5_off(t) + i5 : (worst < 4u ? i4 : WvaTable::D5_OFF + i5);
 }
+// Row indices of a step for a matrix wave (lane l < 24: row 24 hw + l).  The pair rows the helpers keep in LDS for the conv1 gather
+// already hold the 9-mer: prow[r] is the 5-mer of the bases t-5 .. t-1 and prow[r + 4] that of t-1 .. t+3 whenever both are < 1024 (all
+// nine bases in ACGT, none before the window start) - two LDS reads and three integer instructions.  Only a wave that sees another
+// pair row (a non-ACGT base, the first five positions of a window) reads the bases themselves and walks wva_index; that round trip
+// is exposed, on the few steps that have one.
+__device__ __forceinline__ uint32_t wva_step_index(const uint16_t* __restrict__ prow, const uint8_t* __restrict__ bases, int t0, int hw, int lane) {
+    const int r = WVA_ROWS_PER_WAVE * hw + min(lane, WVA_ROWS_PER_WAVE - 1);
+    const uint32_t p0 = prow[r], p4 = prow[r + 4];
+    uint32_t idx = (p0 << 8) | (p4 & 255u);
+    if (__builtin_amdgcn_ballot_w64(p0 >= 1024u || p4 >= 1024u)) {
+        const int t = wva_row(t0, hw, lane);
+        WvaBytes b;
+        wva_fetch(b, bases, t);
+        idx = wva_index(b, t);
+    }
+    return idx;
+}
 struct WvaRows {
     u32x2 v[WVA_ROWS_PER_WAVE];     // 24 table rows, two channels per lane
 };
@@ -679,18 +696,14 @@ __global__ __launch_bounds__(512, 2) void fused_front_tc_kernel(Args a) {
         WU ring[RINGT];
         prime_tc(ring, cw[0], 0, lane);
         // head A's table rows of step s+1 are requested behind B0 of step s and pooled at the end of that interval: their round trip
-        // (~4 k cycles with 384 missing lines per CU in flight) hides behind the w_v B tile.  The lane's row index is computed a step
-        // ahead of the request from bases fetched a step before that: no memory round trip in front of the requests
-        WvaBytes wb;
-        wva_fetch(wb, bases, wva_row(s_begin * FTT, hw, lane));
+        // (~4 k cycles with 384 missing lines per CU in flight) hides behind the w_v B tile.  The row indices are made behind B1 from
+        // the next step's pair rows (wva_step_index): no memory round trip in front of the requests
         {                                                                        // the first step's rows: nothing to hide their round trip behind
             WvaRows w0;
-            wva_issue(w0, tblr, wva_index(wb, wva_row(s_begin * FTT, hw, lane)), lane);
-            wva_fetch(wb, bases, wva_row((s_begin + 1) * FTT, hw, lane));
+            wva_issue(w0, tblr, wva_step_index(prow2(s_begin & 1), bases, s_begin * FTT, hw, lane), lane);
             if (s_begin >= s_lo && s_begin < s_hi) wva_pool_store(w0, yp_w, s_begin * FTT, hw, lane);      // not a warm-up step
         }
-        uint32_t wva_next = wva_index(wb, wva_row((s_begin + 1) * FTT, hw, lane));
-        wva_fetch(wb, bases, wva_row((s_begin + 2) * FTT, hw, lane));
+        uint32_t wva_next = 0;                                                   // row indices of step s+1: made behind B1 of step s
         __syncthreads();                                                         // x1 of the first step is in bufX
         if constexpr (PROF) tick_ = __builtin_readcyclecounter();
 #pragma unroll 1
@@ -709,8 +722,8 @@ __global__ __launch_bounds__(512, 2) void fused_front_tc_kernel(Args a) {
             GNN_TICK(1)
             TC_BARRIER_W();                                                      // ---- B1: x2 is in bufY
             GNN_TICK(2)
-            // The interval in which the matrix waves used to compute head A's y @ w_v: conv3's first weights and chunk 1 of V3 (the
-            // helpers make chunk 0 meanwhile)
+            // The interval in which the matrix waves used to compute head A's y @ w_v: conv3's first weights, chunk 1 of V3 (the
+            // helpers make chunk 0 meanwhile) and the row indices of the table rows that are requested behind B0
             prime_tc(ring, cw[1], 0, lane);
             {
                 const HLane h2m = hlane(smem, BUF_BYTES, hw, lane);
@@ -718,6 +731,7 @@ __global__ __launch_bounds__(512, 2) void fused_front_tc_kernel(Args a) {
                 load_rows(rm, h2m, 1);
                 transform_store(rm, h2m, 1);
             }
+            wva_next = wva_step_index(prow2((step + 1) & 1), bases, t0 + FTT, hw, lane);      // the next step's row indices (its pair rows are in LDS since B0 of the last step)
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                  // chunk 1's fragments have landed before b'_0 releases the readers
             GNN_TICK(3)
 #pragma unroll
@@ -752,8 +766,6 @@ __global__ __launch_bounds__(512, 2) void fused_front_tc_kernel(Args a) {
                     load_rows(rm, h1m, 1);
                     transform_store(rm, h1m, 1);
                 }
-                wva_next = wva_index(wb, wva_row(t0 + 2 * FTT, hw, lane));       // row indices of step s+2 from the bases fetched a step ago
-                wva_fetch(wb, bases, wva_row(t0 + 3 * FTT, hw, lane));
                 if (step + 1 >= s_lo && step + 1 < s_hi) wva_pool_store(wr, yp_w, t0 + FTT, hw, lane);
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");               // chunk 1's fragments have landed before b_0 releases the readers
             }

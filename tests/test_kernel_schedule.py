@@ -147,6 +147,7 @@ def tc_schedule(steps: int = 4, ahead: int = 2):
         # their table rows travel, the helpers chunk 0 and head A's last pair pass (x1(s) stays in bufX until the gather behind b'_0)
         yield [("matrix", "r", "bufY.rows", ("x2", s), True), ("matrix", "r", "bufY.carry", ("x2c", s - 1), True),
                ("matrix", "w", ring(1), ("c3", s, 1), True),
+               ("matrix", "r", prow(s + 1), ("prow", s + 1), True),                     # row indices of the next step's table rows
                ("helper", "r", "bufX.rows", ("x1", s), True),
                ("helper", "r", "bufY.rows", ("x2", s), True), ("helper", "r", "bufY.carry", ("x2c", s - 1), True),
                ("helper", "w", ring(0), ("c3", s, 0), True)]
@@ -191,28 +192,56 @@ def test_toomcook_model_notices_a_dropped_barrier_and_a_ring_overrun():
 
 # ------------------------------------------------------------------ the model against the source: barrier count and order parsed from the .hip
 def _tc_source():
-    """gnn_fused_tc.hip as the shipped library compiles it: the branches of the measurement switches (#ifdef TC_... / #if defined
-    TC_..., all undefined in the product build) are dropped, their #else branches kept."""
+    """gnn_fused_tc.hip as the shipped library compiles it: every conditional on a TC_* macro (#ifdef / #ifndef / #if defined(..) /
+    #elif defined(..) chains; all TC_* macros are undefined in the product build) is resolved, other conditionals are kept."""
     import os
     import re
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    out, stack = [], []          # stack of (keep this branch?, is a TC_ switch?)
+    out, stack = [], []          # stack of [keep this branch?, is a TC_ switch?, has a branch of the chain been taken?]
     for line in open(os.path.join(root, "genomad_amd", "csrc", "gnn_fused_tc.hip")):
-        m = re.match(r"\s*#\s*(ifdef|ifndef|else|endif|if)\b\s*(\w*)", line)
-        if m and m.group(1) in ("ifdef", "ifndef") and m.group(2).startswith("TC_"):
-            stack.append([m.group(1) == "ifndef", True])
+        m = re.match(r"\s*#\s*(ifdef|ifndef|elif|else|endif|if)\b\s*(.*)", line)
+        if not m:
+            if all(f[0] for f in stack):
+                out.append(line)
             continue
-        if m and m.group(1) in ("ifdef", "ifndef", "if"):
-            stack.append([True, False])
-        elif m and m.group(1) == "else" and stack and stack[-1][1]:
-            stack[-1][0] = not stack[-1][0]
-            continue
-        elif m and m.group(1) == "endif" and stack:
-            if stack.pop()[1]:
-                continue
-        if all(keep for keep, _ in stack):
+        d, rest = m.group(1), re.sub(r"//.*", "", m.group(2)).strip()
+        sw = re.fullmatch(r"defined\((TC_\w+)\)", rest) if d in ("if", "elif") else None
+        if d in ("ifdef", "ifndef") and rest.split()[0].startswith("TC_"):
+            stack.append([d == "ifndef", True, d == "ifndef"])
+        elif d == "if" and sw:
+            stack.append([False, True, False])
+        elif d in ("ifdef", "ifndef", "if"):
+            stack.append([True, False, True])
+            if all(f[0] for f in stack):
+                out.append(line)
+        elif d == "elif" and stack and stack[-1][1]:
+            assert sw, "an #elif of a TC_ chain that is not a TC_ switch: " + line
+            stack[-1][0] = False                      # defined(TC_...) is false in the product build
+        elif d == "else" and stack and stack[-1][1]:
+            stack[-1][0] = not stack[-1][2]
+            stack[-1][2] = True
+        elif d == "endif" and stack:
+            top = stack.pop()
+            if not top[1] and all(f[0] for f in stack):
+                out.append(line)
+        elif all(f[0] for f in stack):
             out.append(line)
+    assert not stack
     return "".join(out)
+
+
+def test_tc_source_filter_resolves_every_form_of_a_switch(tmp_path, monkeypatch):
+    """`#if defined(TC_X) / #elif defined(TC_Y) / #else` chains and plain #ifdef / #ifndef switches all resolve to the
+    product build (every TC_* macro undefined); a non-TC conditional stays as it is."""
+    import os
+    text = ("a\n#ifdef TC_A\nb\n#else\nc\n#endif\n#if defined(TC_B)\nd\n#elif defined(TC_C)\ne\n#else\nf\n#endif\n#ifndef TC_D\ng\n#else\nh\n#endif\n"
+            "#ifdef OTHER\ni\n#endif\n#if defined(TC_E)\nj\n#endif\nk\n")
+    d = tmp_path / "genomad_amd" / "csrc"
+    d.mkdir(parents=True)
+    (d / "gnn_fused_tc.hip").write_text(text)
+    real = os.path.dirname
+    monkeypatch.setattr(os.path, "dirname", lambda p_: str(tmp_path) if p_ == real(os.path.abspath(__file__)) else real(p_))
+    assert _tc_source().split() == ["a", "c", "f", "g", "#ifdef", "OTHER", "i", "#endif", "k"]
 
 
 def _loop_body(src, start):
