@@ -6,7 +6,7 @@ cd "$(dirname "$0")"
 HIPCC=${HIPCC:-/opt/rocm/bin/hipcc}
 FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wall -Wno-unused-result"
 STEMS="gnn_api gnn_encode gnn_front_f32 gnn_backend gnn_pack gnn_fused_c6 gnn_fused_x3 gnn_fused_tc gnn_probe gnn_consumers gnn_fasta gnn_comm gnn_contigs"
-HDRS="gnn_common.h gnn_fused_common.h gnn_fused_helpers.h ../../include/genomad_nn.h"
+HDRS="gnn_common.h gnn_fused_common.h gnn_fused_helpers.h gnn_tc_dev.h ../../include/genomad_nn.h"
 stale() { [ ! -f "$2" ] && return 0; for d in "$1" $HDRS; do [ "$d" -nt "$2" ] && return 0; done; return 1; }
 mkdir -p obj
 pids=()

@@ -192,13 +192,18 @@ def test_toomcook_model_notices_a_dropped_barrier_and_a_ring_overrun():
 
 # ------------------------------------------------------------------ the model against the source: barrier count and order parsed from the .hip
 def _tc_source():
-    """gnn_fused_tc.hip as the shipped library compiles it: every conditional on a TC_* macro (#ifdef / #ifndef / #if defined(..) /
+    """gnn_tc_dev.h + gnn_fused_tc.hip as the shipped library compiles them: every conditional on a TC_* macro (#ifdef / #ifndef / #if defined(..) /
     #elif defined(..) chains; all TC_* macros are undefined in the product build) is resolved, other conditionals are kept."""
     import os
     import re
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     out, stack = [], []          # stack of [keep this branch?, is a TC_ switch?, has a branch of the chain been taken?]
-    for line in open(os.path.join(root, "genomad_amd", "csrc", "gnn_fused_tc.hip")):
+    csrc = os.path.join(root, "genomad_amd", "csrc")
+    lines = []
+    for name in ("gnn_tc_dev.h", "gnn_fused_tc.hip"):     # the device helpers (conv_tc and its barriers) live in the header since round 6
+        if os.path.exists(os.path.join(csrc, name)):
+            lines += open(os.path.join(csrc, name)).readlines()
+    for line in lines:
         m = re.match(r"\s*#\s*(ifdef|ifndef|elif|else|endif|if)\b\s*(.*)", line)
         if not m:
             if all(f[0] for f in stack):
