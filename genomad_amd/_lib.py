@@ -14,10 +14,11 @@ LIB_PATH = Path(os.environ.get("GENOMAD_AMD_LIB", _HERE / "csrc" / "libgenomad_n
 WINDOW, TOKENS, DEPTH, CH = 6000, 5997, 257, 128
 PATCHES, PATCH_SIZE, POOLED, FEAT, HIDDEN, CLASSES = 2100, 4, 749, 256, 512, 3
 
-PREC_F32, PREC_BF16X3, PREC_BF16, PREC_F16C8, PREC_F16X3, PREC_F16C6, PREC_F16X3TC = 0, 1, 2, 3, 4, 5, 6
+PREC_F32, PREC_BF16X3, PREC_BF16, PREC_F16C8, PREC_F16X3, PREC_F16C6, PREC_F16X3TC, PREC_F16X3TK = 0, 1, 2, 3, 4, 5, 6, 7
 # PREC_BF16 (single bf16 pass) and PREC_F16C8 (f16 + fp8 corrections) were removed in round 6: both fail the 1e-4 tolerance; the
 # library keeps the enum values and answers GNN_ERR_STATE, the Python side no longer knows their names
-PRECISIONS = {"f32": PREC_F32, "bf16x3": PREC_BF16X3, "f16x3": PREC_F16X3, "f16c6": PREC_F16C6, "f16x3tc": PREC_F16X3TC}
+PRECISIONS = {"f32": PREC_F32, "bf16x3": PREC_BF16X3, "f16x3": PREC_F16X3, "f16c6": PREC_F16C6, "f16x3tc": PREC_F16X3TC,
+              "f16x3tk": PREC_F16X3TK}
 # Arithmetics that are KNOWN to leave the 1e-4 score tolerance at scale (f16c6: 1.2e-4 on a few of 10^6 windows, profiles/history/
 # r02c6_tails.txt): selectable for measurements only - main() refuses them unless GENOMAD_AMD_ALLOW_OUT_OF_TOLERANCE=1 is set
 OUT_OF_TOLERANCE = {"f16c6": 1.2e-4}
@@ -27,6 +28,7 @@ OUT_OF_TOLERANCE = {"f16c6": 1.2e-4}
 # the figures of "f16x3", the direct three-pass form it replaced as the default (profiles/r04_tails.txt) - and 1.16x its speed.
 # "f16c6" (f16 + 4-bit correction MFMAs) stays opt-in behind OUT_OF_TOLERANCE: 1.2e-4 on a handful of 10^6 windows.  "bf16x3": f32 range; "f32": exact.
 DEFAULT_PRECISION = "f16x3tc"
+ERR_ARG, ERR_HIP, ERR_STATE, ERR_WEIGHTS, ERR_NOMEM = -1, -2, -3, -4, -5      # gnn_status
 OH_U8, OH_BF16, OH_F32 = 0, 1, 2
 K_FUSED, K_BACKEND, K_ENCODER, K_F32_FRONT = 0, 1, 2, 3
 
@@ -70,6 +72,11 @@ SIGNATURES = {
     "gnn_device_mem_info": (_int, [_vp, C.POINTER(_i64), C.POINTER(_i64)]),
     "gnn_device_pci_bus_id": (_int, [_vp, C.c_char_p, _sz]),
     "gnn_load_weights": (_int, [_vp, C.POINTER(Weights)]),
+    "gnn_build_kmer_tables": (_int, [_vp, _i64]),
+    "gnn_has_kmer_tables": (_int, [_vp]),
+    "gnn_drop_kmer_tables": (_int, [_vp]),
+    "gnn_kmer_tables_bytes": (_i64, []),
+    "gnn_debug_kmer_table_row": (_int, [_vp, _int, _u64, _vp]),
     "gnn_dev_alloc": (_int, [_vp, _sz, C.POINTER(_vp)]),
     "gnn_dev_free": (_int, [_vp, _vp]),
     "gnn_memcpy_h2d": (_int, [_vp, _vp, _vp, _sz]),

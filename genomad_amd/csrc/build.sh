@@ -5,7 +5,7 @@ set -euo pipefail
 cd "$(dirname "$0")"
 HIPCC=${HIPCC:-/opt/rocm/bin/hipcc}
 FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wall -Wno-unused-result"
-STEMS="gnn_api gnn_encode gnn_front_f32 gnn_backend gnn_pack gnn_fused_c6 gnn_fused_x3 gnn_fused_tc gnn_probe gnn_consumers gnn_fasta gnn_comm gnn_contigs"
+STEMS="gnn_api gnn_encode gnn_front_f32 gnn_backend gnn_pack gnn_fused_c6 gnn_fused_x3 gnn_fused_tc gnn_fused_tk gnn_probe gnn_consumers gnn_fasta gnn_comm gnn_contigs"
 HDRS="gnn_common.h gnn_fused_common.h gnn_fused_helpers.h gnn_tc_dev.h ../../include/genomad_nn.h"
 stale() { [ ! -f "$2" ] && return 0; for d in "$1" $HDRS; do [ "$d" -nt "$2" ] && return 0; done; return 1; }
 mkdir -p obj
@@ -14,7 +14,7 @@ for f in $STEMS; do
   if stale $f.hip obj/$f.o; then
     # gnn_fused_tc: no SLP vectorisation - the helpers' transform runs beside the MFMA stream, where v_pk_*_f32 issue worse than
     # two scalar ops (MI355X_MICROARCH.md, "price of one filler beside MFMAs"; 23.5 vs 24.1 ms per 4096 windows)
-    PERFILE=""; [ $f = gnn_fused_tc ] && PERFILE="-fno-slp-vectorize"
+    PERFILE=""; { [ $f = gnn_fused_tc ] || [ $f = gnn_fused_tk ]; } && PERFILE="-fno-slp-vectorize"
     $HIPCC $FLAGS $PERFILE -c $f.hip -o obj/$f.o &
     pids+=($!)
   fi

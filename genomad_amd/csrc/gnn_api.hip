@@ -312,9 +312,13 @@ int classify_chunks(gnn_ctx* ctx, const uint8_t* bases_dev, int64_t n, int preci
         return GNN_ERR_STATE;
     }
     if (precision != GNN_PREC_F32 && precision != GNN_PREC_BF16X3 && precision != GNN_PREC_F16X3 && precision != GNN_PREC_F16C6 &&
-        precision != GNN_PREC_F16X3TC) {
+        precision != GNN_PREC_F16X3TC && precision != GNN_PREC_F16X3TK) {
         set_error("unknown precision " + std::to_string(precision));
         return GNN_ERR_ARG;
+    }
+    if (precision == GNN_PREC_F16X3TK && !(ctx->w.tk_x2_tbl && ctx->w.tk_mpa_tbl)) {
+        set_error("GNN_PREC_F16X3TK needs the k-mer tables: call gnn_build_kmer_tables first (it answers GNN_ERR_NOMEM on a device without ~190 GB free)");
+        return GNN_ERR_STATE;
     }
     const bool f32 = precision == GNN_PREC_F32;
     int64_t chunk = std::min<int64_t>(f32 ? ctx->chunk_f32 : ctx->chunk_fused, std::max<int64_t>(n, 1));
@@ -436,7 +440,8 @@ int classify_chunks(gnn_ctx* ctx, const uint8_t* bases_dev, int64_t n, int preci
             if ((rc = launch_front_f32(ctx, b, m))) return rc;
         } else {
             ProfScope ps(ctx, GNN_K_FUSED);
-            rc = precision == GNN_PREC_F16X3TC ? launch_front_tc(ctx, b, m)
+            rc = precision == GNN_PREC_F16X3TK ? launch_front_tk(ctx, b, m)
+                 : precision == GNN_PREC_F16X3TC ? launch_front_tc(ctx, b, m)
                  : precision == GNN_PREC_F16C6 ? launch_front_c6(ctx, b, m)
                                                : launch_front_x3(ctx, b, m, precision);       // GNN_PREC_F16X3 / GNN_PREC_BF16X3
             if (rc) return rc;
@@ -449,7 +454,7 @@ int classify_chunks(gnn_ctx* ctx, const uint8_t* bases_dev, int64_t n, int preci
         {
             ProfScope ps(ctx, GNN_K_BACKEND);
             // the Toom-Cook front end feeds the back end of the default arithmetic
-            rc = launch_backend(ctx, m, precision == GNN_PREC_F16X3TC ? GNN_PREC_F16X3 : precision, scores_dev + a * GNN_CLASSES);
+            rc = launch_backend(ctx, m, (precision == GNN_PREC_F16X3TC || precision == GNN_PREC_F16X3TK) ? GNN_PREC_F16X3 : precision, scores_dev + a * GNN_CLASSES);
         }
         if (overlap) {
             if (!rc) {
@@ -520,7 +525,7 @@ int gnn_fused_rows_per_step(int precision) {
     switch (precision) {
         case GNN_PREC_F32: return 0;
         case GNN_PREC_F16C6: return c6_rows_per_step();
-        case GNN_PREC_F16X3TC: return 96;
+        case GNN_PREC_F16X3TC: case GNN_PREC_F16X3TK: return 96;
         case GNN_PREC_BF16X3: case GNN_PREC_F16X3: return FT;
         default: return GNN_ERR_ARG;
     }
@@ -612,6 +617,7 @@ int gnn_destroy(gnn_ctx* ctx) {
     free_contig_ws(ctx);
     free_stage(ctx);
     if (ctx->align_buf) (void)hipFree(ctx->align_buf);
+    free_kmer_tables(ctx);
     free_ws(ctx->ws);
     free_ws(ctx->ws_alt);
     if (ctx->stream2) {
@@ -788,6 +794,54 @@ int gnn_load_weights(gnn_ctx* ctx, const gnn_weights* w) {
     if ((rc = pack_fused_x3_consts(ctx))) return rc;
     if ((rc = pack_fused_tc_weights(ctx, w))) return rc;
     ctx->has_weights = true;
+    return GNN_OK;
+}
+
+// k-mer tables of GNN_PREC_F16X3TK (gnn_fused_tk.hip).  reserve_bytes < 0: the default reserve = two workspaces of the ctx's launch
+// size (the asynchronous entry point alternates two) + 8 GiB for the caller's own buffers.
+int gnn_build_kmer_tables(gnn_ctx* ctx, int64_t reserve_bytes) {
+    int rc = check_ctx(ctx);
+    if (rc) return rc;
+    if (!ctx->has_weights) {
+        set_error("gnn_load_weights has not been called");
+        return GNN_ERR_STATE;
+    }
+    if ((rc = finish_pending(ctx))) return rc;
+    const size_t reserve = reserve_bytes >= 0 ? (size_t)reserve_bytes : 2 * (size_t)ctx->chunk_fused * WS_BYTES_PER_WINDOW + ((size_t)8 << 30);
+    return build_kmer_tables(ctx, reserve);
+}
+
+int gnn_has_kmer_tables(gnn_ctx* ctx) {
+    return ctx && ctx->w.tk_x2_tbl && ctx->w.tk_mpa_tbl && ctx->w.tk_pt_tbl && ctx->w.tk_yp_const ? 1 : 0;
+}
+
+int gnn_drop_kmer_tables(gnn_ctx* ctx) {
+    int rc = check_ctx(ctx);
+    if (rc) return rc;
+    if ((rc = finish_pending(ctx))) return rc;
+    GNN_HIP(hipStreamSynchronize(ctx->stream));
+    free_kmer_tables(ctx);
+    return GNN_OK;
+}
+
+int64_t gnn_kmer_tables_bytes(void) { return (int64_t)kmer_tables_bytes(); }
+
+// test aid: row `row` of the 14-mer table (128 floats) / entry (e = row >> 32, 9-mer = row & 0xffffffff) of head A's table (1 float)
+int gnn_debug_kmer_table_row(gnn_ctx* ctx, int which, uint64_t row, float* out_host) {
+    int rc = check_ctx(ctx);
+    if (rc) return rc;
+    if (!gnn_has_kmer_tables(ctx) || !out_host) {
+        set_error("gnn_debug_kmer_table_row: no tables / NULL output");
+        return GNN_ERR_STATE;
+    }
+    if (which == 0) {
+        if (row > ((uint64_t)1 << 28)) { set_error("14-mer row out of range"); return GNN_ERR_ARG; }
+        GNN_HIP(hipMemcpy(out_host, ctx->w.tk_x2_tbl + (size_t)row * C, C * sizeof(float), hipMemcpyDeviceToHost));
+    } else {
+        const uint64_t e = row >> 32, n = row & 0xffffffffu;
+        if (e >= (uint64_t)NPAIR || n > ((uint64_t)1 << 18)) { set_error("(entry, 9-mer) out of range"); return GNN_ERR_ARG; }
+        GNN_HIP(hipMemcpy(out_host, ctx->w.tk_mpa_tbl + (size_t)e * (((size_t)1 << 18) + 1) + n, sizeof(float), hipMemcpyDeviceToHost));
+    }
     return GNN_OK;
 }
 

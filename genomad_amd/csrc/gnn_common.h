@@ -95,6 +95,13 @@ struct DeviceWeights {
     float* tc_yp_const = nullptr;
     float* tc_mp_const = nullptr;
     float* tc_wva_tbl = nullptr;    // head A's y @ w_v per 9-mer: gnn_fused_tc.hip, WvaTable (1.38 GB)
+    // k-mer tables of GNN_PREC_F16X3TK (gnn_fused_tk.hip, gnn_build_kmer_tables): x2 per 14-mer (137.4 GB), head A's pair products per
+    // (entry, 9-mer) (8.8 GB), that kernel's outputs of an all-N window.  Not in ctx->owned: gnn_drop_kmer_tables frees them
+    float* tk_x2_tbl = nullptr;
+    float* tk_mpa_tbl = nullptr;
+    float* tk_pt_tbl = nullptr;     // conv2's six tap tables over WvaTable's index space (8.3 GB): the rows the 14-mer table cannot index
+    float* tk_yp_const = nullptr;
+    float* tk_mp_const = nullptr;
     float* x3_yp_const[2] = {nullptr, nullptr};   // the same of gnn_fused_x3.hip: [0] bf16 limbs, [1] f16 limbs
     float* x3_mp_const[2] = {nullptr, nullptr};
 };
@@ -197,6 +204,11 @@ void free_stage(gnn_ctx* ctx);         // gnn_api.hip: staging of the host-buffe
 int launch_front_c6(gnn_ctx* ctx, const uint8_t* bases, int64_t n);             // GNN_PREC_F16C6 -> ws.mp, ws.yp
 int launch_front_x3(gnn_ctx* ctx, const uint8_t* bases, int64_t n, int precision);   // GNN_PREC_F16X3 / BF16X3 (gnn_fused_x3.hip) -> ws.mp, ws.yp
 int launch_front_tc(gnn_ctx* ctx, const uint8_t* bases, int64_t n);             // GNN_PREC_F16X3TC (gnn_fused_tc.hip) -> ws.mp, ws.yp
+int launch_front_tk(gnn_ctx* ctx, const uint8_t* bases, int64_t n);             // GNN_PREC_F16X3TK (gnn_fused_tk.hip) -> ws.mp, ws.yp
+int build_kmer_tables(gnn_ctx* ctx, size_t reserve);                             // gnn_fused_tk.hip: GNN_ERR_NOMEM when free memory < tables + reserve
+void free_kmer_tables(gnn_ctx* ctx);
+size_t kmer_tables_bytes();
+int build_wva_rows_table(gnn_ctx* ctx, const float* w_kc, float* tbl);          // gnn_fused_tc.hip: x1(row) @ w for every row of WvaTable's index space
 int pack_fused_tc_weights(gnn_ctx* ctx, const gnn_weights* w);                   // after pack_fused_c6_weights (shares its pair tables)
 int pack_fused_x3_consts(gnn_ctx* ctx);                                          // all-N window outputs of that kernel (after the other packs)
 

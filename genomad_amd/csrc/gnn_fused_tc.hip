@@ -425,6 +425,19 @@ __global__ __launch_bounds__(128) void wva_table_kernel(const float* __restrict_
     }
 }
 
+}  // namespace tc
+
+// tbl[row][c] = sum_k x1(row)[k] w[k][c] for every row of WvaTable's index space (all 9-mers, window starts, 9-mers with a non-ACGT
+// byte): head A's y @ w_v table with w = w_v A, and the tap tables of gnn_fused_tk.hip with w = one tap of conv2
+int build_wva_rows_table(gnn_ctx* ctx, const float* w_kc, float* tbl) {
+    using namespace tc;
+    hipLaunchKernelGGL(wva_table_kernel, dim3((WvaTable::ROWS + WVA_BUILD_ROWS - 1) / WVA_BUILD_ROWS), dim3(128), 0, ctx->stream, ctx->w.conv1_pairs6, w_kc, tbl);
+    GNN_HIP(hipGetLastError());
+    return GNN_OK;
+}
+
+namespace tc {
+
 static void fill_args(const gnn_ctx* ctx, Args& a, const uint8_t* bases) {
     const DeviceWeights& d = ctx->w;
     a.bases = bases;
@@ -541,9 +554,8 @@ int pack_fused_tc_weights(gnn_ctx* ctx, const gnn_weights* w) {
         }
         ctx->owned.push_back(p);
         d.tc_wva_tbl = static_cast<float*>(p);
-        hipLaunchKernelGGL(wva_table_kernel, dim3((WvaTable::ROWS + WVA_BUILD_ROWS - 1) / WVA_BUILD_ROWS), dim3(128), 0, ctx->stream, d.conv1_pairs6,
-                           d.w_v[0], d.tc_wva_tbl);
-        GNN_HIP(hipGetLastError());
+        const int rc = build_wva_rows_table(ctx, d.w_v[0], d.tc_wva_tbl);
+        if (rc) return rc;
     }
     // the all-N window's outputs, computed once by the kernel itself (padding skip)
     void* bn = nullptr;

@@ -1,0 +1,748 @@
+// Fused front end, GNN_PREC_F16X3TK (round 6): the f16x3tc arithmetic with everything that is a function of a short k-mer read
+// from tables in HBM instead of being computed - the design point that 288 GB per GPU open.
+//
+//   x1[t] = LeakyReLU(conv1)(t)  depends on the bases t-5 .. t+3    (model.py:11, igloo.py:45-48)           a  9-mer
+//   x2[t] = LeakyReLU(conv2(x1))(t) depends on x1[t-5 .. t], i.e. on the bases t-10 .. t+3 (igloo.py:65-67)  a 14-mer
+//
+//   X2Table   4^14 + 1 rows x 128 f32 = 137.4 GB   x2[t] per 14-mer (row 4^14: every token of the 14 bases is the N token)
+//   MpaTable  8400 x (4^9 + 1) f32    =   8.8 GB   head A's pair product of entry e (igloo.py:192-204 folded) per 9-mer at pos[e]
+//   WvaTable  (gnn_tc_dev.h)          =   1.4 GB   head A's y @ w_v row per 9-mer
+//
+// conv2 - 43 % of a window's FLOPs, half of the default kernel's MFMAs, weight stream, input transforms and barriers - becomes ONE
+// 512-byte row gather per position (3.1 MB per window; scripts/probe_gather_big.hip: the memory system delivers such rows from a
+// 137 GB table at 11.6 G rows/s = 5.9 TB/s, 1.9 M windows/s worth), head A's pair products one 4-byte read per entry.  What is left
+// on the matrix pipe is conv3 (Toom-Cook F(3,6), three f16 products, as gnn_fused_tc.hip) and head B's y @ w_v; x1 is never
+// materialised.  All tables are built on the device (f64 accumulation, rounded to f32 once: closer to the reference's f32 than the
+// three f16 products they replace) by gnn_build_kmer_tables() when the device has the memory; otherwise the library keeps serving
+// GNN_PREC_F16X3TC.
+//
+// What a k-mer table cannot index is computed in place, in f32, by the whole workgroup (dirty_rows_pass / pair_a_slow): the first
+// ten positions of a window (tokens before the window start are absent, not N) and k-mers that mix ACGT with other bytes.  A k-mer
+// in which every 4-mer holds a non-ACGT byte (all its tokens are the N token: N runs, the padding of a contig's last window) has
+// its own row.  These are a dozen rows per window start and per N-run edge.
+//
+// Structure (one workgroup = one window, 4 matrix waves + 4 helper waves, steps of 96 rows, the ring of 3 x 16 KB of transformed
+// activations - all as gnn_fused_tc.hip): two row buffers P, Q of 101 rows x 528 B alternate; step s finds x2(s) (rows t0-5 ..
+// t0+95: the five carry rows are gathered again instead of being carried) in buf[s & 1], the conv3 epilogue overwrites it with x3(s)
+// (hi | lo planes), and x2(s+1) lands in the other buffer, whose x3(s-1) is dead by then:
+//
+//   matrix : [c0 it0 | ... | c7 it7] conv3 -> inverse transform -> x3 -> buf[s&1] | E | head A's 24 table rows per wave of step s+1
+//            requested, w_v B(s), pooled -> yp B | F | V3(s+1) chunk 1, 8-row max of the table rows -> yp A
+//   helpers: beside units 0..5: V3 chunks 2..7; c6: row indices of x2(s+1) from the window's 2-bit codes, 26 rows per wave requested
+//            (registers), head A's pair products read from MpaTable; c7: head B's weights requested | E | head B's passes 0, 1,
+//            x2(s+1) rows -> buf[(s+1)&1] | F | (rows no table holds: dirty_rows_pass, all waves) V3(s+1) chunk 0, head B's last pass
+//
+// 10 workgroup barriers per step instead of 18.  LDS: 2 x 53.3 KB + 48 KB ring + 3 KB of 2-bit codes = 159.6 KB.
+#include "gnn_tc_dev.h"
+
+#ifndef TK_SLOW_ATTR
+#define TK_SLOW_ATTR __noinline__
+#endif
+
+namespace gnn {
+namespace tk {
+
+using namespace tc;
+
+constexpr uint32_t X2_ROWS = (1u << 28) + 1u;       // 4^14 fourteen-mers + the all-N-token row
+constexpr uint32_t X2_NN = 1u << 28;
+constexpr uint32_t K9_ROWS = (1u << 18) + 1u;       // 4^9 nine-mers + the all-N-token 9-mer
+constexpr uint32_t K9_NN = 1u << 18;
+constexpr int QUADS = W / 4;                        // 1500 aligned groups of four bases
+constexpr int QUAD_N = QUADS + 4;                   // + zero tail: a 14-mer at the worst alignment reads one group past the end
+constexpr int QUAD_OFF = VRING_OFF + VRING * VSLOT;
+constexpr int BIASK_OFF = QUAD_OFF + ((QUAD_N * 2 + 15) / 16) * 16;
+constexpr int DIRTY_OFF = BIASK_OFF + C * 4;        // [0] count, [1..] buffer rows no table holds
+constexpr int DIRTY_MAX = BUF_ROWS;
+constexpr int LASTK_OFF = DIRTY_OFF + ((4 + DIRTY_MAX + 15) / 16) * 16;
+constexpr int SMEMK = LASTK_OFF + 16;
+constexpr int X2_PER_WAVE = (BUF_ROWS + 3) / 4;     // 26 rows of the next step per helper wave (the last wave: 23)
+static_assert(SMEMK <= 160 * 1024, "LDS budget");
+
+struct ArgsK {
+    const uint8_t* bases;
+    const unsigned char* tcw3;        // transformed conv3 weights (gnn_fused_tc.hip, pack_fused_tc_weights)
+    float inv_s3;
+    const float* conv_b3;
+    const unsigned char* wv_w;        // head B's w_v fragments
+    const float* weff_b;              // head B's folded IGLOO weights (weff6 layout)
+    const int32_t* pos_sorted[2];
+    const int32_t* bucket_ptr[2];     // (STEPST + 1,) entry ranges per 96-row step
+    const unsigned char* wva_tbl;     // WvaTable
+    const float* x2_tbl;              // X2Table
+    const float* mpa_tbl;             // MpaTable
+    const float* pairs6;              // conv1 pair tables (slow paths)
+    const float* pt_tbl;              // conv2's tap tables over WvaTable's index space (rows the 14-mer table cannot index)
+    const float* conv2_b;
+    const float* weff_a;              // (8400, 128) f32, entry order (slow path)
+    float* mp;
+    float* yp;
+    const float* yp_c;                // outputs of an all-N window (padding skip), nullptr = compute everything
+    const float* mp_c;
+    unsigned long long* cycles;
+    int split;
+};
+
+// ---------------------------------------------------------------- the window as 2-bit codes
+// One u16 per aligned group of four bases: bits 7..0 the four digits (A, C, G, T -> 0..3 in the order of sequence.py:170-193, first
+// base on top, 0 for any other byte), bits 11..8 one flag per base (same order) set for a non-ACGT byte.  Built once per window.
+__device__ __forceinline__ uint32_t quad_of(uint32_t w4) {
+    uint32_t code = 0, dirty = 0;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const uint32_t d = wva_digit((w4 >> (8 * i)) & 255u);
+        code = (code << 2) | (d & 3u);
+        dirty = (dirty << 1) | (d >> 2);
+    }
+    return (dirty << 8) | code;
+}
+// the LEN-mer that starts at base b (0 <= b <= W - LEN): 2 LEN bits, first base on top; `dirty` one bit per base (same order)
+template <int LEN>
+__device__ __forceinline__ void kmer_q(const uint16_t* __restrict__ quads, int b, uint32_t& code, uint32_t& dirty) {
+    constexpr int NQ = (LEN + 6) / 4;                  // groups a LEN-mer spans at the worst alignment
+    const int q0 = b >> 2, r = b & 3;
+    unsigned long long c = 0;
+    uint32_t d = 0;
+#pragma unroll
+    for (int i = 0; i < NQ; ++i) {
+        const uint32_t v = quads[q0 + i];
+        c = (c << 8) | (v & 255u);
+        d = (d << 4) | (v >> 8);
+    }
+    const int drop = 4 * NQ - r - LEN;
+    code = (uint32_t)(c >> (2 * drop)) & ((1u << (2 * LEN)) - 1u);
+    dirty = (d >> drop) & ((1u << LEN) - 1u);
+}
+// every token (4-mer) inside the LEN bases holds a flagged base: the activations are those of an all-N stretch
+template <int LEN>
+__device__ __forceinline__ bool all_n_tokens(uint32_t dirty) {
+    const uint32_t clean = ~dirty & ((1u << LEN) - 1u);
+    return ((clean & (clean >> 1) & (clean >> 2) & (clean >> 3)) & ((1u << (LEN - 3)) - 1u)) == 0u;
+}
+constexpr uint32_t ROW_DIRTY = 0x80000000u;            // flag on a row index: no table row, dirty_rows_pass computes it (the index then is X2_NN: a valid row)
+// X2Table row of position t (any int: the rows of a step run from t0 - 5 to t0 + 95)
+__device__ __forceinline__ uint32_t x2_index(const uint16_t* __restrict__ quads, int t) {
+    if (t < 10) return ROW_DIRTY | X2_NN;              // t < 0: a zero row (causal padding of conv3); 0 .. 9: tokens before the window start are absent
+    uint32_t code, dirty;
+    kmer_q<14>(quads, min(t, T - 1) - 10, code, dirty);     // rows past the last token are never used: any finite row
+    if (dirty == 0u) return code;
+    return all_n_tokens<14>(dirty) ? X2_NN : (ROW_DIRTY | X2_NN);
+}
+// WvaTable row of the matrix wave's lane (lane l < 24 of wave hw: row 24 hw + l of the step), from the 2-bit codes; a lane whose
+// 9-mer is not all ACGT (or t < 5) makes the wave walk the bytes (wva_index: the side tables S5 / D5)
+__device__ __forceinline__ uint32_t wva_step_index_q(const uint16_t* __restrict__ quads, const uint8_t* __restrict__ bases, int t0, int hw, int lane) {
+    const int t = wva_row(t0, hw, lane);
+    uint32_t code, dirty;
+    kmer_q<9>(quads, max(t - 5, 0), code, dirty);
+    uint32_t idx = code;
+    if (__builtin_amdgcn_ballot_w64(t < 5 || dirty != 0u)) {
+        WvaBytes b;
+        wva_fetch(b, bases, t);
+        idx = wva_index(b, t);
+    }
+    return idx;
+}
+
+// ---------------------------------------------------------------- what the k-mer tables cannot index
+// head A's pair product of entry e at position u (igloo.py:192-204 folded): one lane, 128 channels
+__device__ TK_SLOW_ATTR float pair_a_slow(const uint8_t* __restrict__ bases, const float* __restrict__ pairs6, const float* __restrict__ weff_a, int e, int u) {
+    uint32_t r[3];
+#pragma unroll
+    for (int j = 0; j < 3; ++j) r[j] = pair_row(token_state(bases, u - 5 + 2 * j), token_state(bases, u - 4 + 2 * j));
+    float s = 0.f;
+    for (int k = 0; k < C; ++k) {
+        const int perm = ((k >> 2) & 3) * 32 + (k >> 4) * 4 + (k & 3);
+        const float v = pairs6[((size_t)0 * PAIR_ROWS + r[0]) * C + perm] + pairs6[((size_t)1 * PAIR_ROWS + r[1]) * C + perm] +
+                        pairs6[((size_t)2 * PAIR_ROWS + r[2]) * C + perm];
+        s = fmaf(vmax_raw(v, v * LRELU), weff_a[(size_t)e * C + k], s);
+    }
+    return s;
+}
+// The rows of buffer `buf` (row r = position tb + r) that the list in LDS names: x2[t] = LeakyReLU(b2 + sum_j W2[j]^T x1[t-5+j])
+// (igloo.py:65-67) as the sum of <= 6 rows of the tap tables PT[j][row of x1[t-5+j] in WvaTable's index space] (f32; the taps whose
+// x1 row lies before the window start add nothing), a zero row for t < 0.  NT threads (the helper waves: 256, the prologue: all 512),
+// 128 per row, no barrier inside; the caller puts a barrier behind it and resets the list.
+__device__ __forceinline__ uint32_t dirty_count(const unsigned char* __restrict__ smem) {
+    return *reinterpret_cast<const volatile uint32_t*>(smem + DIRTY_OFF);
+}
+template <int NT>
+__device__ TK_SLOW_ATTR void dirty_rows_fill(unsigned char* __restrict__ smem, unsigned char* __restrict__ buf, int tb, const uint8_t* __restrict__ bases,
+                                             const float* __restrict__ pt, const float* __restrict__ conv2_b, int tid) {
+    const int n = (int)dirty_count(smem);
+    const unsigned char* drows = smem + DIRTY_OFF + 4;
+    const int c = tid & (C - 1);
+    for (int i = tid >> 7; i < n; i += NT / 128) {
+        const int r = drows[i], t = min(tb + r, T - 1);
+        float v = 0.f;
+        if (t >= 0) {
+            v = conv2_b[c];
+#pragma unroll
+            for (int j = 0; j < KS; ++j) {
+                const int p = t - CARRY + j;
+                if (p >= 0) {
+                    WvaBytes wb;
+                    wva_fetch(wb, bases, p);
+                    v += pt[((size_t)j * WvaTable::ROWS + wva_index(wb, p)) * C + c];
+                }
+            }
+            v = vmax_raw(v, v * LRELU);
+        }
+        *reinterpret_cast<float*>(buf + r * ROWX + c * 4) = v;
+    }
+}
+
+// ---------------------------------------------------------------- x2 rows of a step: indices, requests, stores
+struct X2Rows {
+    u32x2 v[X2_PER_WAVE];
+};
+// lane l < X2_PER_WAVE of wave part w (0..3): buffer row 26 w + l (position tb + row); rows behind the buffer's 101 are clamped
+// (requested twice, stored once).  A row no table holds goes onto the list in LDS (`list`) and keeps its flag: it is requested as the
+// all-N row (any valid row) and not stored - dirty_rows_fill writes it.
+__device__ __forceinline__ uint32_t x2_rows_index(unsigned char* __restrict__ smem, const uint16_t* __restrict__ quads, int tb, int w, int lane, bool list) {
+    const int r = min(X2_PER_WAVE * w + min(lane, X2_PER_WAVE - 1), BUF_ROWS - 1);
+    const uint32_t idx = x2_index(quads, tb + r);
+    if (list && (idx & ROW_DIRTY) && lane < X2_PER_WAVE && X2_PER_WAVE * w + lane < BUF_ROWS) {
+        uint32_t* dl = reinterpret_cast<uint32_t*>(smem + DIRTY_OFF);
+        const uint32_t slot = atomicAdd(dl, 1u);
+        smem[DIRTY_OFF + 4 + slot] = (unsigned char)r;
+    }
+    return idx;
+}
+template <int I0, int I1>
+__device__ __forceinline__ void x2_rows_issue(X2Rows& x, const float* __restrict__ tbl, uint32_t my_row, int lane) {
+#pragma unroll
+    for (int i = I0; i < I1; ++i) {
+#ifdef TK_ABL_SMALLTBL      // measurement: the same requests against TK_ABL_SMALLTBL rows of the table (wrong results)
+        const uint32_t row = __builtin_amdgcn_readlane(my_row, i) & (TK_ABL_SMALLTBL - 1u);
+#else
+        const uint32_t row = __builtin_amdgcn_readlane(my_row, i) & ~ROW_DIRTY;
+#endif
+        const unsigned char* p = reinterpret_cast<const unsigned char*>(tbl) + (size_t)row * (C * 4);      // wave-uniform 64-bit base
+#ifdef TK_ABL_NOX2LOAD
+        x.v[i] = u32x2{row, (uint32_t)(uintptr_t)p};
+#else
+        x.v[i] = *reinterpret_cast<const u32x2*>(p + lane * 8);                                           // 64 lanes x 8 B = one row
+#endif
+    }
+}
+__device__ __forceinline__ void x2_rows_store(const X2Rows& x, unsigned char* __restrict__ buf, uint32_t my_row, int w, int lane) {
+#pragma unroll
+    for (int i = 0; i < X2_PER_WAVE; ++i) {
+        const int r = X2_PER_WAVE * w + i;
+        const bool dirty = (__builtin_amdgcn_readlane(my_row, i) & ROW_DIRTY) != 0u;
+        if (r < BUF_ROWS && !dirty) *reinterpret_cast<u32x2*>(buf + r * ROWX + lane * 8) = x.v[i];
+    }
+}
+
+template <bool PROF>
+__global__ __launch_bounds__(512, 2) void fused_front_tk_kernel(ArgsK a) {
+    __shared__ __attribute__((aligned(16))) unsigned char smem[SMEMK];
+    const unsigned long long t_entry = PROF ? __builtin_readcyclecounter() : 0ull;
+    uint16_t* quads = reinterpret_cast<uint16_t*>(smem + QUAD_OFF);
+    float* bias_s = reinterpret_cast<float*>(smem + BIASK_OFF);
+    int* s_last = reinterpret_cast<int*>(smem + LASTK_OFF);
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const bool helper = wave >= 4;
+    const int hw = wave & 3;
+    const int ht = tid & 255;
+    const int64_t wi = blockIdx.x / a.split;
+    const int part = blockIdx.x % a.split;
+    const uint8_t* bases = a.bases + wi * W;
+    float* mp_w[2] = {a.mp + (wi * 2 + 0) * NPAIR, a.mp + (wi * 2 + 1) * NPAIR};
+    const int woff = hw * WNBLK_B;
+
+    for (int q = tid; q < QUAD_N; q += 512)
+        quads[q] = q < QUADS ? (uint16_t)quad_of(reinterpret_cast<const uint32_t*>(bases)[q]) : (uint16_t)0;
+    if (tid < C) bias_s[tid] = a.conv_b3[tid];
+    if (tid == 0) {
+        *s_last = -1;
+        *reinterpret_cast<uint32_t*>(smem + DIRTY_OFF) = 0u;
+    }
+    __syncthreads();
+    if (a.yp_c) {
+        int last = -1;
+        for (int q = tid; q < QUADS; q += 512) {
+            const uint32_t clean = ~((uint32_t)quads[q] >> 8) & 15u;         // bit 3 = first base of the group
+            if (clean) last = max(last, 4 * q + 3 - (int)__builtin_ctz(clean));
+        }
+        if (last >= 0) atomicMax(s_last, last);
+    }
+    __syncthreads();
+    const int nsteps = a.yp_c ? max(1, min(STEPST, (*s_last + 1 + 15 + FTT - 1) / FTT)) : STEPST;
+    const int per = (nsteps + a.split - 1) / a.split;
+    const int s_lo = min(part * per, nsteps), s_hi = min(s_lo + per, nsteps);       // no warm-up step: a step depends on nothing before it
+    unsigned jitter_state = 0x9E3779B9u * (unsigned)(wave + 1) + (unsigned)blockIdx.x * 7919u;     // TC_JITTER builds only
+    (void)jitter_state;
+    unsigned long long cyc[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long tick_ = 0;
+    if constexpr (PROF) tick_ = t_entry;
+
+    if (s_hi > s_lo) {
+        // x2 of the first step: every wave gathers 13 of its 101 rows, nothing hides the round trip (once per window / part)
+        {
+            const int tb = s_lo * FTT - CARRY;
+            unsigned char* buf = smem + (s_lo & 1) * BUF_BYTES;
+            const int r = min(13 * wave + min(lane, 12), BUF_ROWS - 1);
+            const uint32_t idx = x2_index(quads, tb + r);
+            if ((idx & ROW_DIRTY) && lane < 13 && 13 * wave + lane < BUF_ROWS) {
+                const uint32_t slot = atomicAdd(reinterpret_cast<uint32_t*>(smem + DIRTY_OFF), 1u);
+                smem[DIRTY_OFF + 4 + slot] = (unsigned char)r;
+            }
+#pragma unroll 1
+            for (int i = 0; i < 13; ++i) {
+                const int rr = 13 * wave + i;
+                const uint32_t row = __builtin_amdgcn_readlane(idx, i);
+                if (rr < BUF_ROWS && !(row & ROW_DIRTY)) {
+                    const unsigned char* p = reinterpret_cast<const unsigned char*>(a.x2_tbl) + (size_t)row * (C * 4);
+                    *reinterpret_cast<u32x2*>(buf + rr * ROWX + lane * 8) = *reinterpret_cast<const u32x2*>(p + lane * 8);
+                }
+            }
+            __syncthreads();
+            if (dirty_count(smem)) {
+                dirty_rows_fill<512>(smem, buf, tb, bases, a.pt_tbl, a.conv2_b, tid);
+                __syncthreads();
+                if (tid == 0) *reinterpret_cast<uint32_t*>(smem + DIRTY_OFF) = 0u;
+            }
+            __syncthreads();
+        }
+
+        if (!helper) {
+            __builtin_amdgcn_s_setprio(2);
+            const wrsrc_t cw = make_wrsrc(a.tcw3 + woff, 64 * WUNIT_B - woff);
+            const wrsrc_t vw = make_wrsrc(a.wv_w + woff, 8 * WUNIT_B - woff);
+            const wrsrc_t tblr = make_wrsrc(a.wva_tbl, (int)(WvaTable::ROWS * WvaTable::ROW_BYTES));
+            const wrsrc_t yp_w = make_wrsrc(reinterpret_cast<const unsigned char*>(a.yp + wi * 2 * (size_t)POOLED * C), 2 * POOLED * C * 4);
+            WU ring[RINGT];
+            prime_tc(ring, cw, 0, lane);
+            {                                                                    // head A's rows of the first step: nothing to hide their round trip behind
+                WvaRows w0;
+                wva_issue(w0, tblr, wva_step_index_q(quads, bases, s_lo * FTT, hw, lane), lane);
+                wva_pool_store(w0, yp_w, s_lo * FTT, hw, lane);
+            }
+            {                                                                    // V3 chunk 1 of the first step (the helpers make chunk 0)
+                const HLane h0 = hlane(smem, (s_lo & 1) * BUF_BYTES, hw, lane);
+                Raw16 rm;
+                load_rows(rm, h0, 1);
+                transform_store(rm, h0, 1);
+            }
+            uint32_t wva_next = wva_step_index_q(quads, bases, (s_lo + 1) * FTT, hw, lane);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            GNN_TICK(6)
+#pragma unroll 1
+            for (int step = s_lo; step < s_hi; ++step) {
+                const int t0 = step * FTT;
+                const int xoff = (step & 1) * BUF_BYTES, yoff = BUF_BYTES - xoff;
+                f32x16 acc[NXI];
+#pragma unroll
+                for (int xi = 0; xi < NXI; ++xi)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[xi][r] = 0.f;
+                GNN_TICK(5)
+                conv_tc(smem, cw, 0, ring, acc, lane, jitter_state);             // c_0 .. c_7, conv3
+                GNN_TICK(0)
+                prime_wv(ring, vw, lane);
+                epilogue_x3(smem + xoff, acc, a.inv_s3, bias_s, hw, lane);
+                GNN_TICK(1)
+                TC_BARRIER_W();                                                  // ---- E: x3 is in buf[s & 1]
+                GNN_TICK(2)
+                {
+                    WvaRows wr;
+                    wva_issue(wr, tblr, wva_next, lane);                         // head A's table rows of the next step (unconditionally, as gnn_fused_tc.hip)
+                    f32x16 ac[NMB];
+#pragma unroll
+                    for (int mb = 0; mb < NMB; ++mb)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) ac[mb][r] = 0.f;
+                    wv_tile(smem, xoff + CARRY * ROWX, ring, ac, lane);
+                    prime_tc(ring, cw, 0, lane);
+                    wv_pool_store(ac, yp_w, POOLED * C * 4, t0, hw, lane);
+                    GNN_TICK(3)
+                    if (step + 1 < s_hi) {
+                        const HLane hn = hlane(smem, yoff, hw, lane);            // V3 chunk 1 of the next step: x2(s+1) is in buf[(s+1) & 1] since c_7
+                        Raw16 rm;
+                        load_rows(rm, hn, 1);
+                        transform_store(rm, hn, 1);
+                        wva_pool_store(wr, yp_w, t0 + FTT, hw, lane);
+                    }
+                    wva_next = wva_step_index_q(quads, bases, t0 + 2 * FTT, hw, lane);
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");           // chunk 1's fragments have landed before c_0 releases the readers
+                    GNN_TICK(4)
+                }
+            }
+        } else {
+            __builtin_amdgcn_s_setprio(3);
+            if constexpr (PROF) tick_ = __builtin_readcyclecounter();
+            Raw16 ra, rb;
+            PairPass p0, p1;
+            p0.u = p1.u = 0;
+            // head A's entry of this thread in the first step (its position is requested a step ahead)
+            int ea = a.bucket_ptr[0][s_lo] + ht;
+            int ea_end = a.bucket_ptr[0][s_lo + 1];
+            int ua = ea < ea_end ? a.pos_sorted[0][ea] : 0;
+            {                                                                    // V3 chunk 0 of the first step
+                const HLane h0 = hlane(smem, (s_lo & 1) * BUF_BYTES, hw, lane);
+                load_rows(ra, h0, 0);
+                transform_store(ra, h0, 0);
+                load_rows(ra, h0, 2);
+            }
+#pragma unroll 1
+            for (int step = s_lo; step < s_hi; ++step) {
+                const int t0 = step * FTT;
+                const int xoff = (step & 1) * BUF_BYTES, yoff = BUF_BYTES - xoff;
+                const HLane hx = hlane(smem, xoff, hw, lane), hy = hlane(smem, yoff, hw, lane);
+                const bool more = step + 1 < s_hi;
+                const PairJob jb = {smem + xoff, a.weff_b, a.pos_sorted[1], mp_w[1], t0, a.bucket_ptr[1][step], a.bucket_ptr[1][step + 1]};
+                // head A's pair product of this thread's entry: one table read, requested first (a wave's loads return in order: behind the x2 rows
+                // it would hold their stores back for its own round trip, a 4-byte read at a random address of an 8.8 GB table), stored behind E
+                float va = 0.f;
+                bool va_slow = false;
+                if (ea < ea_end) {
+                    uint32_t code, dirty;
+                    kmer_q<9>(quads, max(ua - 5, 0), code, dirty);
+                    const bool nn = all_n_tokens<9>(dirty);
+                    va_slow = ua < 5 || (dirty != 0u && !nn);
+                    va = a.mpa_tbl[(size_t)ea * K9_ROWS + (dirty == 0u ? code : K9_NN)];
+                }
+                const int ea_cur = ea, ea_end_cur = ea_end, ua_cur = ua;
+                ea = more ? a.bucket_ptr[0][step + 1] + ht : 0;                  // the next step's entry and its position
+                ea_end = more ? a.bucket_ptr[0][step + 2] : 0;
+                ua = ea < ea_end ? a.pos_sorted[0][ea] : 0;
+                // x2 of the next step: 26 rows per wave, requested a few at a time beside the conv loop (their misses share the vector L1
+                // with the matrix waves' weight stream), stored behind c_6 when nobody reads buf[(s+1) & 1] any more
+                X2Rows xr;
+                const uint32_t my_row = x2_rows_index(smem, quads, t0 + FTT - CARRY, hw, lane, more);
+                GNN_TICK(14)
+                TC_HPRIO_HIGH();
+                HBAR_W(15, 8);                                                   // c_0
+                x2_rows_issue<0, 5>(xr, a.x2_tbl, my_row, lane);
+                load_rows(rb, hx, 3);
+                transform_store(ra, hx, 2);
+                HBAR_W(9, 8);                                                    // c_1
+                x2_rows_issue<5, 10>(xr, a.x2_tbl, my_row, lane);
+                load_rows(ra, hx, 4);
+                transform_store(rb, hx, 0);
+                HBAR_W(10, 8);                                                   // c_2
+                x2_rows_issue<10, 14>(xr, a.x2_tbl, my_row, lane);
+                load_rows(rb, hx, 5);
+                transform_store(ra, hx, 1);
+                HBAR_W(10, 8);                                                   // c_3
+                x2_rows_issue<14, 18>(xr, a.x2_tbl, my_row, lane);
+                load_rows(ra, hx, 6);
+                transform_store(rb, hx, 2);
+                HBAR_W(10, 8);                                                   // c_4
+                x2_rows_issue<18, 22>(xr, a.x2_tbl, my_row, lane);
+                load_rows(rb, hx, 7);
+                transform_store(ra, hx, 0);
+                HBAR_W(10, 8);                                                   // c_5
+                x2_rows_issue<22, X2_PER_WAVE>(xr, a.x2_tbl, my_row, lane);
+                transform_store(rb, hx, 1);
+                HBAR_W(11, 8);                                                   // c_6: V3 is complete, buf[(s+1) & 1] (x3(s-1)) is dead
+                x2_rows_store(xr, smem + yoff, my_row, hw, lane);
+                if (more && dirty_count(smem)) {                                 // rows the 14-mer table cannot index (the list is the next step's)
+                    dirty_rows_fill<256>(smem, smem + yoff, t0 + FTT - CARRY, bases, a.pt_tbl, a.conv2_b, ht);
+                }
+                HBAR_W(12, 8);                                                   // c_7: x2(s+1) is in buf[(s+1) & 1]
+                if (ht == 0) *reinterpret_cast<volatile uint32_t*>(smem + DIRTY_OFF) = 0u;
+                if (more) {                                                      // V3(s+1) chunk 0 (ring slot 0: chunk 6 was read in front of c_7)
+                    load_rows(ra, hy, 0);
+                    transform_store(ra, hy, 0);
+                    load_rows(ra, hy, 2);
+                }
+                pass_issue(p0, jb, 0, hw, lane);
+                pass_issue(p1, jb, 1, hw, lane);
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                HBAR(13, 8);                                                     // ---- E: x3 is in buf[s & 1]
+                TC_HPRIO_LOW();
+                pass_compute(p0, jb, 0, hw, lane);
+                pass_issue(p0, jb, 2, hw, lane);
+                pass_compute(p1, jb, 1, hw, lane);
+                if (ea_cur < ea_end_cur) {
+                    if (va_slow) va = pair_a_slow(bases, a.pairs6, a.weff_a, ea_cur, ua_cur);
+                    mp_w[0][ea_cur] = va;
+                    for (int e = ea_cur + 256; e < ea_end_cur; e += 256) {       // a crowded step (more than 256 entries; rare)
+                        const int u = a.pos_sorted[0][e];
+                        uint32_t code, dirty;
+                        kmer_q<9>(quads, max(u - 5, 0), code, dirty);
+                        const bool nn = all_n_tokens<9>(dirty);
+                        mp_w[0][e] = (u < 5 || (dirty != 0u && !nn)) ? pair_a_slow(bases, a.pairs6, a.weff_a, e, u)
+                                                                      : a.mpa_tbl[(size_t)e * K9_ROWS + (dirty == 0u ? code : K9_NN)];
+                    }
+                }
+                pass_compute(p0, jb, 2, hw, lane);
+                pass_rest(p0, jb, 3, hw, lane);
+            }
+        }
+    }
+    __syncthreads();
+    if (nsteps < STEPST && part == a.split - 1) {   // the all-N tail: copy instead of compute
+        const int q0 = nsteps * (FTT / GNN_POOL);
+        const int nrow4 = (POOLED - q0) * (C / 4);
+        for (int i = tid; i < 2 * nrow4; i += 512) {
+            const int h = i >= nrow4, j = i - h * nrow4;
+            const size_t off = (size_t)h * POOLED * C + (size_t)q0 * C + (size_t)j * 4;
+            *reinterpret_cast<float4*>(a.yp + wi * 2 * (size_t)POOLED * C + off) = *reinterpret_cast<const float4*>(a.yp_c + off);
+        }
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+            for (int e = a.bucket_ptr[h][nsteps] + tid; e < NPAIR; e += 512) mp_w[h][e] = a.mp_c[h * NPAIR + e];
+    }
+    if constexpr (PROF) {
+        if (tid == 0)
+            for (int i = 0; i < 8; ++i) atomicAdd(a.cycles + i, cyc[i]);
+        if (tid == 256)
+            for (int i = 8; i < 16; ++i) atomicAdd(a.cycles + i, cyc[i]);
+    }
+}
+
+// ---------------------------------------------------------------- table builders (gnn_build_kmer_tables)
+// x1 per 9-mer, natural channel order, exactly as the kernels' conv1 gather makes it; row 4^9 = the all-N-token 9-mer
+__global__ __launch_bounds__(128) void x1tab_kernel(const float* __restrict__ pairs6, float* __restrict__ x1tab) {
+    const uint32_t n = blockIdx.x;
+    const int c = threadIdx.x;
+    int tk[6];
+#pragma unroll
+    for (int i = 0; i < 6; ++i) tk[i] = n == K9_NN ? 0 : 1 + (int)((n >> (2 * (5 - i))) & 255u);
+    const int perm = ((c >> 2) & 3) * 32 + (c >> 4) * 4 + (c & 3);
+    float v = 0.f;
+#pragma unroll
+    for (int j = 0; j < 3; ++j) v += pairs6[((size_t)j * PAIR_ROWS + pair_row(tk[2 * j], tk[2 * j + 1])) * C + perm];
+    x1tab[(size_t)n * C + c] = vmax_raw(v, v * LRELU);
+}
+// P[j][n][c] = sum_k x1tab[n][k] W2[j][k][c] in f64: conv2's contribution of tap j when the 9-mer n sits at that tap
+constexpr int PJ_ROWS = 64;
+__global__ __launch_bounds__(128) void pj_kernel(const float* __restrict__ x1tab, const float* __restrict__ conv2_k, double* __restrict__ P) {
+    __shared__ float xs[C];
+    const int c = threadIdx.x, j = blockIdx.y;
+    float wcol[C];
+#pragma unroll
+    for (int k = 0; k < C; ++k) wcol[k] = conv2_k[((size_t)j * C + k) * C + c];
+    const uint32_t r_end = min((uint32_t)(blockIdx.x + 1) * PJ_ROWS, K9_ROWS);
+    for (uint32_t n = blockIdx.x * PJ_ROWS; n < r_end; ++n) {
+        xs[c] = x1tab[(size_t)n * C + c];
+        __syncthreads();
+        double acc = 0.0;
+#pragma unroll
+        for (int k = 0; k < C; ++k) acc = __builtin_fma((double)xs[k], (double)wcol[k], acc);
+        P[((size_t)j * K9_ROWS + n) * C + c] = acc;
+        __syncthreads();
+    }
+}
+// X2Table row n14: LeakyReLU(f32(b2 + sum_j P[j][9-mer at tap j])), the sum in f64, rounded once.  32 lanes x 4 channels per row.
+constexpr uint32_t X2TAB_ROWS = 128;      // rows per workgroup (a launch must stay below 2^32 threads: 4^14 rows x 32 lanes would not)
+__global__ __launch_bounds__(256) void x2tab_kernel(const double* __restrict__ P, const float* __restrict__ conv2_b, float* __restrict__ tbl) {
+    const int sub = threadIdx.x & 31;
+    double b[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) b[i] = (double)conv2_b[sub * 4 + i];
+    for (uint32_t k = 0; k < X2TAB_ROWS / 8; ++k) {
+        const uint32_t row = blockIdx.x * X2TAB_ROWS + k * 8u + (threadIdx.x >> 5);
+        if (row >= X2_ROWS) return;
+        double s[4] = {b[0], b[1], b[2], b[3]};
+#pragma unroll
+        for (int j = 0; j < KS; ++j) {
+            const uint32_t n9 = row == X2_NN ? K9_NN : (row >> (2 * (5 - j))) & 0x3FFFFu;
+            const double4 p = *reinterpret_cast<const double4*>(P + ((size_t)j * K9_ROWS + n9) * C + sub * 4);
+            s[0] += p.x; s[1] += p.y; s[2] += p.z; s[3] += p.w;
+        }
+        float4 o;
+        float v;
+        v = (float)s[0]; o.x = vmax_raw(v, v * LRELU);
+        v = (float)s[1]; o.y = vmax_raw(v, v * LRELU);
+        v = (float)s[2]; o.z = vmax_raw(v, v * LRELU);
+        v = (float)s[3]; o.w = vmax_raw(v, v * LRELU);
+        *reinterpret_cast<float4*>(tbl + (size_t)row * C + sub * 4) = o;
+    }
+}
+// MpaTable[e][n] = sum_k x1tab[n][k] weff_a[e][k] in f64, rounded once: a 64 (9-mers) x 64 (entries) tile per workgroup
+constexpr int MPA_T = 64, MPA_LD = C + 1;
+__global__ __launch_bounds__(256) void mpa_kernel(const float* __restrict__ x1tab, const float* __restrict__ weff_a, float* __restrict__ tbl) {
+    __shared__ float xa[MPA_T * MPA_LD], wb[MPA_T * MPA_LD];
+    const uint32_t n0 = blockIdx.x * MPA_T;
+    const int e0 = blockIdx.y * MPA_T;
+    for (int i = threadIdx.x; i < MPA_T * C; i += 256) {
+        const int r = i >> 7, k = i & (C - 1);
+        xa[r * MPA_LD + k] = n0 + r < K9_ROWS ? x1tab[(size_t)(n0 + r) * C + k] : 0.f;
+        wb[r * MPA_LD + k] = e0 + r < NPAIR ? weff_a[(size_t)(e0 + r) * C + k] : 0.f;
+    }
+    __syncthreads();
+    const int tn = threadIdx.x & 15, te = threadIdx.x >> 4;
+    double acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = 0.0;
+    for (int k = 0; k < C; ++k) {
+        double x[4], w[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            x[i] = (double)xa[(tn + 16 * i) * MPA_LD + k];
+            w[i] = (double)wb[(te * 4 + i) * MPA_LD + k];
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_fma(x[i], w[j], acc[i][j]);
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int e = e0 + te * 4 + j;
+        if (e >= NPAIR) continue;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const uint32_t n = n0 + tn + 16 * i;
+            if (n < K9_ROWS) tbl[(size_t)e * K9_ROWS + n] = (float)acc[i][j];
+        }
+    }
+}
+
+static void fill_args(const gnn_ctx* ctx, ArgsK& a, const uint8_t* bases) {
+    const DeviceWeights& d = ctx->w;
+    a.bases = bases;
+    a.tcw3 = reinterpret_cast<const unsigned char*>(d.tc_frag[1]);
+    a.inv_s3 = d.tc_inv_s[1];
+    a.conv_b3 = d.conv_b[1];
+    a.wv_w = reinterpret_cast<const unsigned char*>(d.wv_frag_h[1]);
+    a.weff_b = d.weff6[1];
+    for (int i = 0; i < 2; ++i) {
+        a.pos_sorted[i] = d.pos_sorted[i];
+        a.bucket_ptr[i] = d.bucket_ptr96[i];
+    }
+    a.wva_tbl = reinterpret_cast<const unsigned char*>(d.tc_wva_tbl);
+    a.x2_tbl = d.tk_x2_tbl;
+    a.mpa_tbl = d.tk_mpa_tbl;
+    a.pairs6 = d.conv1_pairs6;
+    a.pt_tbl = d.tk_pt_tbl;
+    a.conv2_b = d.conv_b[0];
+    a.weff_a = d.weff_sorted[0];
+    a.cycles = nullptr;
+    a.split = 1;
+}
+
+static void launch(const ArgsK& a, bool prof, unsigned nwin, hipStream_t stream) {
+    const unsigned n = nwin * (unsigned)a.split;
+    if (prof) hipLaunchKernelGGL((fused_front_tk_kernel<true>), dim3(n), dim3(512), 0, stream, a);
+    else hipLaunchKernelGGL((fused_front_tk_kernel<false>), dim3(n), dim3(512), 0, stream, a);
+}
+
+}  // namespace tk
+
+size_t kmer_tables_bytes() {
+    return (size_t)tk::X2_ROWS * C * 4 + (size_t)NPAIR * tk::K9_ROWS * 4 + (size_t)KS * tc::WvaTable::ROWS * C * 4;
+}
+
+void free_kmer_tables(gnn_ctx* ctx) {
+    DeviceWeights& d = ctx->w;
+    for (float** p : {&d.tk_x2_tbl, &d.tk_mpa_tbl, &d.tk_pt_tbl, &d.tk_yp_const, &d.tk_mp_const}) {
+        if (*p) (void)hipFree(*p);
+        *p = nullptr;
+    }
+}
+
+// X2Table and MpaTable on the device.  `reserve` bytes must stay free behind them (workspaces of the launches to come).
+int build_kmer_tables(gnn_ctx* ctx, size_t reserve) {
+    using namespace tk;
+    DeviceWeights& d = ctx->w;
+    if (d.tk_x2_tbl && d.tk_mpa_tbl && d.tk_pt_tbl && d.tk_yp_const) return GNN_OK;
+    free_kmer_tables(ctx);
+    const size_t x2_b = (size_t)X2_ROWS * C * 4, mpa_b = (size_t)NPAIR * K9_ROWS * 4;
+    const size_t x1_b = (size_t)K9_ROWS * C * 4, p_b = (size_t)KS * K9_ROWS * C * 8;
+    size_t free_b = 0, total_b = 0;
+    GNN_HIP(hipMemGetInfo(&free_b, &total_b));
+    const size_t pt_b = (size_t)KS * WvaTable::ROWS * C * 4;
+    const size_t need = x2_b + mpa_b + pt_b + x1_b + p_b + reserve;
+    if (free_b < need) {
+        set_error("k-mer tables: " + std::to_string(need >> 30) + " GiB needed (" + std::to_string((x2_b + mpa_b) >> 30) + " GiB of tables, the rest workspace reserve), " +
+                  std::to_string(free_b >> 30) + " GiB free on the device: GNN_PREC_F16X3TC keeps serving");
+        return GNN_ERR_NOMEM;
+    }
+    void *x1 = nullptr, *P = nullptr, *x2 = nullptr, *mpa = nullptr, *pt = nullptr;
+    auto fail = [&](hipError_t e, const char* what) {
+        (void)hipGetLastError();
+        for (void* p : {x1, P, x2, mpa, pt})
+            if (p) (void)hipFree(p);
+        set_error(std::string("k-mer tables: ") + what + " failed: " + hipGetErrorString(e));
+        return e == hipErrorOutOfMemory ? GNN_ERR_NOMEM : GNN_ERR_HIP;
+    };
+    hipError_t e;
+    if ((e = hipMalloc(&x2, x2_b)) != hipSuccess) return fail(e, "hipMalloc of the 14-mer table");
+    if ((e = hipMalloc(&mpa, mpa_b)) != hipSuccess) return fail(e, "hipMalloc of head A's pair-product table");
+    if ((e = hipMalloc(&x1, x1_b)) != hipSuccess) return fail(e, "hipMalloc of the 9-mer x1 table");
+    if ((e = hipMalloc(&pt, pt_b)) != hipSuccess) return fail(e, "hipMalloc of conv2's tap tables");
+    if ((e = hipMalloc(&P, p_b)) != hipSuccess) return fail(e, "hipMalloc of the f64 tap tables");
+    for (int j = 0; j < KS; ++j)
+        if (build_wva_rows_table(ctx, d.conv_k[0] + (size_t)j * C * C, static_cast<float*>(pt) + (size_t)j * WvaTable::ROWS * C)) return fail(hipGetLastError(), "launch of a tap-table build");
+    hipStream_t st = ctx->stream;
+    hipLaunchKernelGGL(x1tab_kernel, dim3(K9_ROWS), dim3(128), 0, st, d.conv1_pairs6, static_cast<float*>(x1));
+    if ((e = hipGetLastError()) != hipSuccess) return fail(e, "launch of x1tab_kernel");
+    hipLaunchKernelGGL(pj_kernel, dim3((K9_ROWS + PJ_ROWS - 1) / PJ_ROWS, KS), dim3(128), 0, st, static_cast<const float*>(x1), d.conv_k[0], static_cast<double*>(P));
+    if ((e = hipGetLastError()) != hipSuccess) return fail(e, "launch of pj_kernel");
+    hipLaunchKernelGGL(x2tab_kernel, dim3((X2_ROWS + X2TAB_ROWS - 1) / X2TAB_ROWS), dim3(256), 0, st, static_cast<const double*>(P), d.conv_b[0], static_cast<float*>(x2));
+    if ((e = hipGetLastError()) != hipSuccess) return fail(e, "launch of x2tab_kernel");
+    hipLaunchKernelGGL(mpa_kernel, dim3((K9_ROWS + MPA_T - 1) / MPA_T, (NPAIR + MPA_T - 1) / MPA_T), dim3(256), 0, st, static_cast<const float*>(x1),
+                       d.weff_sorted[0], static_cast<float*>(mpa));
+    if ((e = hipGetLastError()) != hipSuccess) return fail(e, "launch of mpa_kernel");
+    if ((e = hipStreamSynchronize(st)) != hipSuccess) return fail(e, "building the tables");
+    (void)hipFree(x1);
+    (void)hipFree(P);
+    x1 = P = nullptr;
+    d.tk_x2_tbl = static_cast<float*>(x2);
+    d.tk_mpa_tbl = static_cast<float*>(mpa);
+    d.tk_pt_tbl = static_cast<float*>(pt);
+    // the all-N window's outputs, computed once by the kernel itself (padding skip)
+    void *bn = nullptr, *yc = nullptr, *mc = nullptr;
+    if ((e = hipMalloc(&bn, W)) != hipSuccess || (e = hipMalloc(&yc, (size_t)2 * POOLED * C * sizeof(float))) != hipSuccess ||
+        (e = hipMalloc(&mc, (size_t)2 * NPAIR * sizeof(float))) != hipSuccess) {
+        for (void* p : {bn, yc, mc})
+            if (p) (void)hipFree(p);
+        free_kmer_tables(ctx);
+        x2 = mpa = pt = nullptr;
+        return fail(e, "hipMalloc of the all-N window's outputs");
+    }
+    (void)hipMemsetAsync(bn, 'N', W, st);
+    ArgsK a;
+    fill_args(ctx, a, static_cast<const uint8_t*>(bn));
+    a.mp = static_cast<float*>(mc);
+    a.yp = static_cast<float*>(yc);
+    a.yp_c = nullptr;
+    a.mp_c = nullptr;
+    launch(a, false, 1, st);
+    e = hipGetLastError();
+    if (e == hipSuccess) e = hipStreamSynchronize(st);
+    (void)hipFree(bn);
+    d.tk_yp_const = static_cast<float*>(yc);
+    d.tk_mp_const = static_cast<float*>(mc);
+    if (e != hipSuccess) {
+        free_kmer_tables(ctx);
+        x2 = mpa = pt = nullptr;
+        return fail(e, "the all-N window's launch");
+    }
+    return GNN_OK;
+}
+
+int launch_front_tk(gnn_ctx* ctx, const uint8_t* bases, int64_t n) {
+    using namespace tk;
+    if (!ctx->w.tk_x2_tbl || !ctx->w.tk_mpa_tbl) {
+        set_error("f16x3tk: the k-mer tables have not been built (gnn_build_kmer_tables)");
+        return GNN_ERR_STATE;
+    }
+    if (reinterpret_cast<uintptr_t>(bases) & 3u) {
+        set_error("f16x3tk: the window buffer must be 4-byte aligned");
+        return GNN_ERR_ARG;
+    }
+    ArgsK a;
+    fill_args(ctx, a, bases);
+    a.mp = ctx->ws.mp;
+    a.yp = ctx->ws.yp;
+    a.yp_c = ctx->c6_pad_skip ? ctx->w.tk_yp_const : nullptr;
+    a.mp_c = ctx->c6_pad_skip ? ctx->w.tk_mp_const : nullptr;
+    a.cycles = ctx->phase_cycles;
+    if (ctx->time_split && n > 0 && ctx->cu_count > 0) a.split = (int)std::max<int64_t>(1, std::min<int64_t>(4, ctx->cu_count / n));
+    ctx->last_split = a.split;
+    launch(a, ctx->phase_cycles != nullptr, (unsigned)n, ctx->stream);
+    GNN_HIP(hipGetLastError());
+    return GNN_OK;
+}
+
+}  // namespace gnn

@@ -92,6 +92,21 @@ class NNEngine:
         check(self.lib.gnn_load_weights(self.ctx, C.byref(s)))
         self._weights_keepalive = keep
 
+    def build_kmer_tables(self, reserve_bytes: int = -1) -> bool:
+        """The k-mer tables of "f16x3tk" (146 GB: x2 per 14-mer, head A's pair products per (entry, 9-mer)); False - with nothing
+        allocated - on a device that cannot hold them behind `reserve_bytes` (< 0: the library's default reserve)."""
+        rc = self.lib.gnn_build_kmer_tables(self.ctx, int(reserve_bytes))
+        if rc == _lib.ERR_NOMEM:
+            return False
+        check(rc)
+        return True
+
+    def has_kmer_tables(self) -> bool:
+        return bool(self.lib.gnn_has_kmer_tables(self.ctx))
+
+    def drop_kmer_tables(self):
+        check(self.lib.gnn_drop_kmer_tables(self.ctx))
+
     def sync(self):
         check(self.lib.gnn_sync(self.ctx))
 

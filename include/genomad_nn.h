@@ -72,6 +72,13 @@ typedef enum gnn_precision {
                                 the device (x1[t] is a function of the bases t-5 .. t+3; f64 accumulation, rounded once).  A window
                                 buffer that is not 4-byte aligned goes through one aligned staging copy and the same kernel: the
                                 scores do not depend on the buffer's address                                                   */
+    GNN_PREC_F16X3TK = 7,    /* round 6 (gnn_fused_tk.hip): F16X3TC with everything that is a function of a short k-mer READ FROM TABLES IN HBM
+                                instead of computed - x2[t] = LeakyReLU(conv2(x1))[t] depends on the bases t-10 .. t+3, so conv2 (43 % of a
+                                window's FLOPs) is one 512-byte row gather per position from a table of all 4^14 fourteen-mers (137.4 GB),
+                                head A's pair products one 4-byte read per entry from an (entry, 9-mer) table (8.8 GB); conv3 and head B's
+                                y @ w_v stay on the matrix pipe with the F16X3TC arithmetic.  The tables are built on the device by
+                                gnn_build_kmer_tables (f64 accumulation, rounded once: closer to exact f32 than the three f16 products);
+                                without them this value answers GNN_ERR_STATE and the caller stays on F16X3TC.  Same range rule as F16X3TC */
     GNN_PREC_F16X3 = 4       /* the direct three-pass form (gnn_fused_x3.hip), the default of round 3: split-f16 (hi+lo, 11+11 significant
                                 bits), 3 MFMA passes, logits GEMM split-f16 x 3 on the matrix pipe, dense head exact f32: f32-class
                                 accuracy (within 2e-5 of the exact-f32 path on every one of 10^6 windows); needs |activation| < 65504
@@ -152,6 +159,19 @@ int gnn_device_mem_info(gnn_ctx* ctx, int64_t* free_bytes, int64_t* total_bytes)
 
 /* replaces nn_model.load_weights(GenomadData.nn_model_file), nn_classification.py:310 */
 int gnn_load_weights(gnn_ctx* ctx, const gnn_weights* w);
+
+/* The k-mer tables of GNN_PREC_F16X3TK: gnn_kmer_tables_bytes() bytes (146.2 GB) of device memory + 1.7 GB of temporaries while they
+ * are built (about a second).  reserve_bytes = device memory that must stay free behind them (the workspaces of the launches to come and
+ * the caller's own buffers; < 0 = the library's default: two workspaces of the ctx's launch size + 8 GiB).  GNN_ERR_NOMEM - nothing
+ * allocated, message says how much is missing - on a device that cannot hold them: the caller keeps GNN_PREC_F16X3TC.  Idempotent.
+ * gnn_drop_kmer_tables frees them (gnn_destroy does too). */
+int gnn_build_kmer_tables(gnn_ctx* ctx, int64_t reserve_bytes);
+int gnn_has_kmer_tables(gnn_ctx* ctx);
+int gnn_drop_kmer_tables(gnn_ctx* ctx);
+int64_t gnn_kmer_tables_bytes(void);
+/* test aid: which = 0: row `row` (a 14-mer, first base in the top two of 28 bits; 4^14 = the all-N-token row) of the x2 table -> 128
+ * floats; which = 1: head A's table, entry row >> 32 at the 9-mer row & 0xffffffff (4^9 = all-N-token) -> 1 float */
+int gnn_debug_kmer_table_row(gnn_ctx* ctx, int which, uint64_t row, float* out_host);
 
 /* ---- raw device memory (so a ctypes host needs no torch for buffers) ------------------ */
 int gnn_dev_alloc(gnn_ctx* ctx, size_t bytes, void** dev_ptr);
