@@ -66,15 +66,21 @@ HBM_PEAK_GBS = 8000.0
 # matrix-pipe cost of one product in units of one bf16/f16 pass
 # f16x3tc: conv2 + conv3 (85.35 % of the algorithmic FLOPs) issue 8 / 18 of the direct form's MFMAs, y @ w_v and the rest all of them
 # since round 6 head A's y @ w_v (7.11 %) is a table lookup: no MFMAs at all
-MFMA_PASSES = {"f16c6": 1.5, "f16x3": 3.0, "f16x3tc": round(3.0 * (0.8535 * 8 / 18 + 0.1465 - 0.0711), 3), "bf16x3": 3.0}
+# f16x3tk (round 6): conv2 (42.675 %) and head A's pair products are table reads as well: conv3 by Toom-Cook and head B's y @ w_v are what is left
+MFMA_PASSES = {"f16c6": 1.5, "f16x3": 3.0, "f16x3tc": round(3.0 * (0.8535 * 8 / 18 + 0.1465 - 0.0711), 3), "bf16x3": 3.0,
+               "f16x3tk": round(3.0 * (0.42675 * 8 / 18 + 0.1465 - 0.0711), 3)}
 # the dominant kernel as rocprofv3's kernel trace names it (profiles/*/kernel_stats.csv)
-FRONT_KERNEL = {"f16x3tc": "gnn::tc::fused_front_tc_kernel<false>", "f16x3": "gnn::x3::fused_front_x3_kernel<true, false>", "bf16x3": "gnn::x3::fused_front_x3_kernel<false, false>",
+FRONT_KERNEL = {"f16x3tk": "gnn::tk::fused_front_tk_kernel<false>", "f16x3tc": "gnn::tc::fused_front_tc_kernel<false>", "f16x3": "gnn::x3::fused_front_x3_kernel<true, false>", "bf16x3": "gnn::x3::fused_front_x3_kernel<false, false>",
                 "f16c6": "gnn::c6::fused_front_c6_kernel", "f32": "f32 front end (5 kernels)"}
 DTYPE_TEXT = {"f16c6": "f16 MFMA + MX-fp6 (e2m3, both operands block scaled) correction MFMAs, f32 accumulate (1.5 f16-pass equivalents)",
               "f16x3": "f16x3 (split-f16 MFMA, 3 passes, f32 accumulate; logits GEMM split-f16 x 3 as well, dense head exact f32)",
               "f16x3tc": "f16x3tc (split-f16 MFMA, 3 products per operand pair, f32 accumulate; conv2 / conv3 by Toom-Cook F(3,6) minimal filtering over "
                          "time with f32 transforms: 0.444x their MFMAs; head A's y @ w_v rows gathered from a 9-mer table (exact f32), head B's "
                          "direct; logits GEMM split-f16 x 3, dense head exact f32)",
+              "f16x3tk": "f16x3tk (conv2 read from a 137 GB table of all 14-mers in HBM - x2[t] is a function of the bases t-10 .. t+3 -, head A's pair "
+                         "products from an (entry, 9-mer) table, head A's y @ w_v rows from a 9-mer table, all exact f32; conv3 by Toom-Cook F(3,6) "
+                         "with split-f16 MFMA, 3 products per operand pair, f32 accumulate; head B's y @ w_v direct; logits GEMM split-f16 x 3, "
+                         "dense head exact f32)",
               "bf16x3": "bf16x3 (split-bf16 MFMA, 3 passes, f32 accumulate)", "f32": "f32"}
 
 
@@ -199,7 +205,13 @@ def front_roofline(precision, windows_per_launch, avg_ms, launches, front_ms, ba
     per_window, source = hbm_traffic(precision)
     traffic = int(per_window * windows_per_launch) if per_window is not None else None
     alg = int(6012 * windows_per_launch)
-    return {
+    tk = precision == "f16x3tk"
+    # f16x3tk: the table rows a window reads ARE its algorithm's bytes: 63 steps x 101 rows x 512 B of the 14-mer table (the five carry rows
+    # of a step are read again), 5 992 rows x 512 B of head A's y @ w_v table, 8 400 4-byte entries of head A's pair-product table
+    tk_bytes = {"x2_rows_14mer_table": 63 * 101 * 512, "wva_rows_9mer_table": 5992 * 512, "pair_products_a": 8400 * 4, "bases": 6000, "scores": 12}
+    if tk:
+        alg = int(sum(tk_bytes.values()) * windows_per_launch)
+    r = {
         "bound": "mfma", "achieved": round(tflops, 2), "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
         "frac": round(tflops / MFMA_PEAK_TFLOPS, 4), "traffic": traffic, "traffic_source": source,
         "algorithmic_bytes_per_launch": alg,
@@ -214,6 +226,21 @@ def front_roofline(precision, windows_per_launch, avg_ms, launches, front_ms, ba
                 "1e-4 tolerance needs more than one 16-bit pass per product (profiles/history/r02_precision_study.json): "
                 "mfma_passes bf16-pass equivalents are issued, which caps frac at 1/mfma_passes",
         "backend_ms_total": round(back_ms, 2), "front_ms_total": round(front_ms, 2)}
+    if tk:
+        share = 0.42675 + 0.0711                       # conv2 + head A's y @ w_v of the algorithmic FLOPs are table reads
+        r["table_reads"] = {
+            "share_of_algorithmic_flops": round(share, 4), "flop_executed_per_window": int(FLOP_PER_WINDOW * (1.0 - share)),
+            "bytes_per_window": tk_bytes, "gather_gb_per_s": round(sum(tk_bytes.values()) * windows_per_launch / (avg_ms * 1e-3) / 1e9, 1) if avg_ms > 0 else None,
+            "gather_frac_of_hbm_peak": round(sum(tk_bytes.values()) * windows_per_launch / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if avg_ms > 0 else None,
+            "probe": "scripts/probe_gather_big.hip: 512-byte rows at random 14-mers of a 137 GB table arrive at 5.9 TB/s (11.6 G rows/s) on this chip: "
+                     "the gather is not the bound, the conv3 weight stream (L2 -> CU) and the board's power are"}
+        r["note"] = ("achieved counts ALGORITHMIC flops (2.763 GFLOP/window) against the dense 16-bit MFMA peak; f16x3tk EXECUTES half of them (conv3 by "
+                     "Toom-Cook, head B's y @ w_v: mfma_passes bf16-pass equivalents per algorithmic FLOP) and READS the other half - conv2 and head A - "
+                     "from k-mer tables in HBM (table_reads): x2[t] is a function of 14 bases, 4^14 rows of 512 B fit one MI355X's 288 GB")
+        r["traffic_note"] = ("algorithmic bytes = the table rows a window gathers (table_reads.bytes_per_window: 6.4 MB) + bases + scores; traffic = "
+                             "fabric-side counters (Infinity-Cache hits included) of the PMC passes named in traffic_source; the excess over the "
+                             "algorithmic bytes is the f32 spill of the pooled y @ w_v rows (767 KB/window) and pair products (67 KB/window) to the back end")
+    return r
 
 
 class PowerSampler:
@@ -591,9 +618,11 @@ def main():
     ap.add_argument("--scaling", default="strong", choices=["strong", "weak"])
     ap.add_argument("--chunk", type=int, default=16384, help="windows per launch of the fused kernel (183.9 k windows/s against 180.3 k with "
                     "launches of 4096 on one box - the launch's tail is amortised over 64 instead of 16 rounds of workgroups per CU)")
-    ap.add_argument("--precision", default=DEFAULT_PRECISION, choices=["f16c6", "f16x3", "f16x3tc", "bf16x3", "f32"],
-                    help=f"arithmetic of the fused front end (default {DEFAULT_PRECISION}: the fastest mode with margin inside the 1e-4 "
-                         "tolerance; f16c6 is faster and exceeds it on a few of 10^6 windows)")
+    ap.add_argument("--precision", default="auto", choices=["auto", "f16c6", "f16x3", "f16x3tc", "f16x3tk", "bf16x3", "f32"],
+                    help=f"arithmetic of the fused front end (default auto: f16x3tk when every rank's device can hold the k-mer tables - 146 GB "
+                         f"built in 1.5 .. 6 s, outside the timed region - else {DEFAULT_PRECISION}; both have margin inside the 1e-4 tolerance; "
+                         "f16c6 is faster than f16x3tc and exceeds it on a few of 10^6 windows)")
+    ap.add_argument("--no-kmer-tables", action="store_true", help="--precision auto: do not build the k-mer tables (measure f16x3tc)")
     ap.add_argument("--async-steps", action="store_true",
                     help="step with gnn_classify_dev_async (the last back end of a step runs beside the next step's front end) "
                          "instead of the synchronous gnn_classify_dev that main() uses.  Measured equal for the default arithmetic "
@@ -682,6 +711,25 @@ def main():
         eng.sync()
         comm.barrier()
         eng.sync()
+
+    # ---- the arithmetic of this run (outside every timed region): f16x3tk needs its tables on EVERY rank
+    kmer = None
+    if args.precision in ("auto", "f16x3tk") and args.kernel == "classify":
+        set_stage("kmer_tables")
+        t_k = time.perf_counter()
+        built = False
+        if not (args.precision == "auto" and args.no_kmer_tables) and hasattr(eng, "build_kmer_tables"):
+            built = bool(eng.build_kmer_tables())
+        all_built = comm.allreduce_max(0.0 if built else 1.0) == 0.0
+        if args.precision == "f16x3tk" and not all_built:
+            raise RuntimeError("--precision f16x3tk: a rank's device cannot hold the k-mer tables (146 GB + workspaces)")
+        if built and not all_built:
+            eng.drop_kmer_tables()
+        kmer = {"built": all_built, "seconds": round(time.perf_counter() - t_k, 2),
+                "gb": round(eng.lib.gnn_kmer_tables_bytes() / 1e9, 1) if all_built else 0.0,
+                "note": "x2 per 14-mer (137.4 GB), head A's pair products per (entry, 9-mer) (8.8 GB), conv2's tap tables for the rows no "
+                        "14-mer indexes (8.3 GB); built by gnn_build_kmer_tables before anything is timed; most of the seconds are hipMalloc"}
+        args.precision = "f16x3tk" if all_built else DEFAULT_PRECISION
 
     def max_over_ranks(x: float) -> float:
         return comm.allreduce_max(x)
@@ -969,7 +1017,7 @@ def main():
                 out["roofline"]["mfma_probe_same_mix_algorithmic_tflops"] = round(same.value, 1)
                 out["roofline"]["frac_of_power_floor"] = round(tflops / same.value, 4)
                 out["roofline"]["frac_ceiling_at_power_floor"] = round(same.value / MFMA_PEAK_TFLOPS, 4)
-            if args.precision in ("f16x3", "f16x3tc", "bf16x3"):
+            if args.precision in ("f16x3", "f16x3tc", "f16x3tk", "bf16x3"):
                 # the power floor of THIS arithmetic: register-operand MFMAs of the kernel's own instruction (f16 draws more than
                 # bf16 per MFMA on this chip), nothing else running; the kernel issues `passes` of them per algorithmic product
                 same = ctypes.c_double()
@@ -988,7 +1036,9 @@ def main():
                 out["encoder"] = {"skipped": f"{type(exc).__name__}: {exc}"}
         # the drop-in entry point and config 5 under the driver's clock: N = 1 only, untimed, after everything
         # that enters `value`; a failure is reported inside its block and in `failed`
-        if world == 1 and real and not args.no_extras and args.precision == DEFAULT_PRECISION:
+        if kmer is not None:
+            out["kmer_tables"] = kmer
+        if world == 1 and real and not args.no_extras and args.precision in (DEFAULT_PRECISION, "f16x3tk"):
             for name, fn in (("main_e2e", lambda: main_e2e_block(eng, weights)), ("metagenome", lambda: metagenome_block(eng, args.precision))):
                 set_stage(name)
                 t_x = time.perf_counter()

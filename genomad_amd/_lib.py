@@ -27,6 +27,9 @@ OUT_OF_TOLERANCE = {"f16c6": 1.2e-4}
 # exact-f32 dense head.  Class scores within 2e-5 (weight seed 42) / 4e-5 (seed 43) of the exact-f32 path on every one of 1 M windows -
 # the figures of "f16x3", the direct three-pass form it replaced as the default (profiles/r04_tails.txt) - and 1.16x its speed.
 # "f16c6" (f16 + 4-bit correction MFMAs) stays opt-in behind OUT_OF_TOLERANCE: 1.2e-4 on a handful of 10^6 windows.  "bf16x3": f32 range; "f32": exact.
+# "f16x3tk" (round 6): f16x3tc with conv2 read from a 137 GB table of all 14-mers and head A's pair products from an 8.8 GB (entry, 9-mer)
+# table - 1.4x the speed, scores equal to 1e-6 - on an engine whose device could hold them (NNEngine.build_kmer_tables); main() and
+# bench.py promote the default to it when the tables are there or worth building (nn_classification.select_arithmetic).
 DEFAULT_PRECISION = "f16x3tc"
 ERR_ARG, ERR_HIP, ERR_STATE, ERR_WEIGHTS, ERR_NOMEM = -1, -2, -3, -4, -5      # gnn_status
 OH_U8, OH_BF16, OH_F32 = 0, 1, 2

@@ -26,8 +26,12 @@ echo "built $(pwd)/libgenomad_nn_hip.so"
 # Test variant (tests/test_gpu_parity.py::test_toomcook_kernel_is_bit_identical_under_delay_injection): the same library with random
 # sleeps behind every barrier of the default kernel.  Never loaded by the product; built with the main library so that it travels
 # to the GPU box.
-if stale gnn_fused_tc.hip obj/gnn_fused_tc_jitter.o; then
-  $HIPCC $FLAGS -fno-slp-vectorize -DTC_JITTER -c gnn_fused_tc.hip -o obj/gnn_fused_tc_jitter.o
-fi
-$HIPCC --offload-arch=gfx950 -shared -fPIC -o libgenomad_nn_hip_jitter.so ${OBJS/obj\/gnn_fused_tc.o/obj\/gnn_fused_tc_jitter.o} -ldl
+for k in gnn_fused_tc gnn_fused_tk; do
+  if stale $k.hip obj/${k}_jitter.o; then
+    $HIPCC $FLAGS -fno-slp-vectorize -DTC_JITTER -c $k.hip -o obj/${k}_jitter.o
+  fi
+done
+JOBJS=${OBJS/obj\/gnn_fused_tc.o/obj\/gnn_fused_tc_jitter.o}
+JOBJS=${JOBJS/obj\/gnn_fused_tk.o/obj\/gnn_fused_tk_jitter.o}
+$HIPCC --offload-arch=gfx950 -shared -fPIC -o libgenomad_nn_hip_jitter.so $JOBJS -ldl
 echo "built $(pwd)/libgenomad_nn_hip_jitter.so"

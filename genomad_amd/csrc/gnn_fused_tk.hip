@@ -33,6 +33,9 @@
 //            x2(s+1) rows -> buf[(s+1)&1] | F | (rows no table holds: dirty_rows_pass, all waves) V3(s+1) chunk 0, head B's last pass
 //
 // 10 workgroup barriers per step instead of 18.  LDS: 2 x 53.3 KB + 48 KB ring + 3 KB of 2-bit codes = 159.6 KB.
+#include <chrono>
+#include <cstdio>
+
 #include "gnn_tc_dev.h"
 
 #ifndef TK_SLOW_ATTR
@@ -403,7 +406,11 @@ __global__ __launch_bounds__(512, 2) void fused_front_tk_kernel(ArgsK a) {
                     kmer_q<9>(quads, max(ua - 5, 0), code, dirty);
                     const bool nn = all_n_tokens<9>(dirty);
                     va_slow = ua < 5 || (dirty != 0u && !nn);
+#ifdef TK_ABL_NOMPA
+                    va = (float)code;
+#else
                     va = a.mpa_tbl[(size_t)ea * K9_ROWS + (dirty == 0u ? code : K9_NN)];
+#endif
                 }
                 const int ea_cur = ea, ea_end_cur = ea_end, ua_cur = ua;
                 ea = more ? a.bucket_ptr[0][step + 1] + ht : 0;                  // the next step's entry and its position
@@ -666,24 +673,41 @@ int build_kmer_tables(gnn_ctx* ctx, size_t reserve) {
         return e == hipErrorOutOfMemory ? GNN_ERR_NOMEM : GNN_ERR_HIP;
     };
     hipError_t e;
+    // GNN_TABLE_TIMING=1 (debug aid): seconds of every stage on stderr (a stream synchronisation after each)
+    static const bool timing = debug_switch("GNN_TABLE_TIMING");
+    auto t_last = std::chrono::steady_clock::now();
+    auto lap = [&](const char* what) {
+        if (!timing) return;
+        (void)hipStreamSynchronize(ctx->stream);
+        const auto now = std::chrono::steady_clock::now();
+        std::fprintf(stderr, "genomad_nn k-mer tables: %-40s %.3f s\n", what, std::chrono::duration<double>(now - t_last).count());
+        t_last = now;
+    };
     if ((e = hipMalloc(&x2, x2_b)) != hipSuccess) return fail(e, "hipMalloc of the 14-mer table");
+    lap("hipMalloc 137 GB");
     if ((e = hipMalloc(&mpa, mpa_b)) != hipSuccess) return fail(e, "hipMalloc of head A's pair-product table");
     if ((e = hipMalloc(&x1, x1_b)) != hipSuccess) return fail(e, "hipMalloc of the 9-mer x1 table");
     if ((e = hipMalloc(&pt, pt_b)) != hipSuccess) return fail(e, "hipMalloc of conv2's tap tables");
     if ((e = hipMalloc(&P, p_b)) != hipSuccess) return fail(e, "hipMalloc of the f64 tap tables");
+    lap("hipMalloc of the other four");
     for (int j = 0; j < KS; ++j)
         if (build_wva_rows_table(ctx, d.conv_k[0] + (size_t)j * C * C, static_cast<float*>(pt) + (size_t)j * WvaTable::ROWS * C)) return fail(hipGetLastError(), "launch of a tap-table build");
+    lap("tap tables over WvaTable's rows (6 x 2.7 M)");
     hipStream_t st = ctx->stream;
     hipLaunchKernelGGL(x1tab_kernel, dim3(K9_ROWS), dim3(128), 0, st, d.conv1_pairs6, static_cast<float*>(x1));
     if ((e = hipGetLastError()) != hipSuccess) return fail(e, "launch of x1tab_kernel");
+    lap("x1 per 9-mer");
     hipLaunchKernelGGL(pj_kernel, dim3((K9_ROWS + PJ_ROWS - 1) / PJ_ROWS, KS), dim3(128), 0, st, static_cast<const float*>(x1), d.conv_k[0], static_cast<double*>(P));
     if ((e = hipGetLastError()) != hipSuccess) return fail(e, "launch of pj_kernel");
+    lap("f64 tap tables per 9-mer");
     hipLaunchKernelGGL(x2tab_kernel, dim3((X2_ROWS + X2TAB_ROWS - 1) / X2TAB_ROWS), dim3(256), 0, st, static_cast<const double*>(P), d.conv_b[0], static_cast<float*>(x2));
     if ((e = hipGetLastError()) != hipSuccess) return fail(e, "launch of x2tab_kernel");
+    lap("x2 per 14-mer (137 GB)");
     hipLaunchKernelGGL(mpa_kernel, dim3((K9_ROWS + MPA_T - 1) / MPA_T, (NPAIR + MPA_T - 1) / MPA_T), dim3(256), 0, st, static_cast<const float*>(x1),
                        d.weff_sorted[0], static_cast<float*>(mpa));
     if ((e = hipGetLastError()) != hipSuccess) return fail(e, "launch of mpa_kernel");
     if ((e = hipStreamSynchronize(st)) != hipSuccess) return fail(e, "building the tables");
+    lap("head A's pair products (8.8 GB)");
     (void)hipFree(x1);
     (void)hipFree(P);
     x1 = P = nullptr;

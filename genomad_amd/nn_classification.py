@@ -27,6 +27,7 @@ import os
 import shutil
 import sys
 import threading
+import time
 from datetime import datetime, timezone
 from pathlib import Path
 
@@ -258,7 +259,48 @@ _WARNED = set()
 
 # what to recompute a batch with when an f16-operand arithmetic returns non-finite scores: the Toom-Cook form's transformed
 # activations leave the f16 range first (|activation| > ~2 000), the direct f16 forms at 65 504, bf16x3 has the f32 range
-RANGE_FALLBACKS = {"f16x3tc": ("f16x3", "bf16x3"), "f16x3": ("bf16x3",), "f16c6": ("bf16x3",)}
+RANGE_FALLBACKS = {"f16x3tk": ("f16x3", "bf16x3"), "f16x3tc": ("f16x3", "bf16x3"), "f16x3": ("bf16x3",), "f16c6": ("bf16x3",)}
+
+# ---- the k-mer tables of "f16x3tk" (gnn_fused_tk.hip): conv2 as a 137 GB table of all 14-mers, head A's pair products as an 8.8 GB
+# (entry, 9-mer) table.  1.4x the default arithmetic's speed, the same scores to 1e-6 - and 1.5 .. 6 seconds of hipMalloc to set up,
+# which a window costing 5 us repays after a few million windows.  GENOMAD_AMD_KMER_TABLES: "auto" (default) builds them when the
+# run's input is at least GENOMAD_AMD_KMER_TABLES_MIN_GB (default 18 = 3 M windows) of FASTA or the engine already has them,
+# "1" always, "0" never.  A device that cannot hold them (146 GB + workspaces) keeps the default arithmetic; so does the whole
+# run when ANY rank cannot (the scores must not depend on which rank classified a contig).  The decision depends on the input,
+# never on the number of ranks: a run gives the same bits on 1 GPU and on 8.
+KMER_TABLES_MIN_GB = 18.0
+
+
+def select_arithmetic(eng, precision: str, input_bytes: int, comm=None, console=None) -> str:
+    """The arithmetic main() classifies with: ``precision`` (configured_precision()), promoted from "f16x3tc" to "f16x3tk" when the
+    k-mer tables are there or worth building (see above).  An explicit GENOMAD_AMD_PRECISION=f16x3tk that cannot be served is an
+    error; every other arithmetic is returned as it is."""
+    if precision not in ("f16x3tc", "f16x3tk") or not hasattr(eng, "build_kmer_tables"):
+        return precision
+    policy = os.environ.get("GENOMAD_AMD_KMER_TABLES", "auto").lower()
+    if policy not in ("auto", "0", "1"):
+        raise ValueError(f"GENOMAD_AMD_KMER_TABLES={policy!r}: expected auto, 0 or 1")
+    explicit = precision == "f16x3tk"
+    min_bytes = float(os.environ.get("GENOMAD_AMD_KMER_TABLES_MIN_GB", KMER_TABLES_MIN_GB)) * 1e9
+    want = explicit or policy == "1" or (policy == "auto" and (eng.has_kmer_tables() or input_bytes >= min_bytes))
+    if comm is not None:                       # eng.has_kmer_tables() is per process: every rank follows rank-independent facts only
+        want = comm.allreduce_max(1.0 if want else 0.0) > 0.0
+    ok = False
+    if want:
+        t = time.perf_counter()
+        had = eng.has_kmer_tables()
+        ok = eng.build_kmer_tables()
+        if ok and not had and console is not None:
+            console.log(f"k-mer tables built on the device in {time.perf_counter() - t:.1f} s (14-mer table of conv2, 9-mer table of head A's pair products).")
+    if comm is not None:
+        ok = comm.allreduce_max(0.0 if ok else 1.0) == 0.0
+    if want and not ok:
+        if explicit:
+            raise RuntimeError("GENOMAD_AMD_PRECISION=f16x3tk: the device cannot hold the k-mer tables (146 GB + workspaces); "
+                               "unset it to run the default arithmetic")
+        if console is not None:
+            console.log("k-mer tables not built (device memory): classifying with the default arithmetic f16x3tc.")
+    return "f16x3tk" if ok else "f16x3tc"
 
 
 def _range_fallback(console, what, to):
@@ -363,6 +405,9 @@ class GpuBackend:
         self.eng = _engine()
         self.chunk = max(int(batch_size), 4096)
         self.precision = configured_precision()
+        if (self.precision == "f16x3tc" and getattr(self.eng, "has_kmer_tables", lambda: False)()
+                and os.environ.get("GENOMAD_AMD_KMER_TABLES", "auto") != "0"):
+            self.precision = "f16x3tk"          # an engine that already holds the tables (a long-lived process) uses them
         self.console = console
         self.sentinel = None          # max |dscore| of the first windows this backend scored (parity_sentinel)
         self._sentinel_done = False
@@ -567,6 +612,8 @@ def main(input_path, output_path, single_window, batch_size, restart, threads, v
             precision = configured_precision()
             _warn_out_of_tolerance(console, precision)
             eng = _engine()
+            size = Path(fasta).stat().st_size * (1 if sequence.compression_of(fasta) == "uncompressed" else 4)
+            precision = select_arithmetic(eng, precision, size, comm, console)
             parts = []
             sentinel = {"d": None, "done": False}
 

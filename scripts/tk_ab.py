@@ -31,7 +31,7 @@ _lib.check(eng.lib.gnn_phase_cycles(eng.ctx, 0, out))
 per = [v / (4096 * 63) for v in out]
 print(f"{ms / l / 4:.3f} ms per 4096 windows = {N / (ms / l) * 1e3:.0f} windows/s | matrix {sum(per[:8]):.0f} " + " ".join(f"{v:.0f}" for v in per[:8]) + f" | helper {sum(per[8:]):.0f} " + " ".join(f"{v:.0f}" for v in per[8:]))
 '''
-libs = [a for a in sys.argv[1:] if not a.startswith("--")]
+libs = [a for i, a in enumerate(sys.argv[1:], 1) if not a.startswith("--") and sys.argv[i - 1] != "--rounds"]
 rounds = int(sys.argv[sys.argv.index("--rounds") + 1]) if "--rounds" in sys.argv else 1
 for r in range(rounds):
     for lib in libs:

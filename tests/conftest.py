@@ -43,5 +43,20 @@ def engine(request, synth_weights):
 
 
 @pytest.fixture(scope="session")
+def kmer_tables(engine):
+    """The session engine with the k-mer tables of "f16x3tk" built (146 GB, 1.5 .. 6 s once per session); tests that need them are
+    skipped on a device that cannot hold them."""
+    if not engine.build_kmer_tables():
+        pytest.skip("the device cannot hold the k-mer tables (146 GB + workspaces)")
+    return engine
+
+
+def need_tables(request, prec):
+    """parametrised tests: build / require the k-mer tables only for the arithmetic that reads them"""
+    if prec == "f16x3tk":
+        request.getfixturevalue("kmer_tables")
+
+
+@pytest.fixture(scope="session")
 def golden_dir():
     return GOLDEN

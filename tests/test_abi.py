@@ -88,7 +88,7 @@ def test_precision_enum_matches_the_binding_and_rows_per_step():
     lib = _lib.load()
     for name, val in _lib.PRECISIONS.items():
         rows = lib.gnn_fused_rows_per_step(val)
-        assert rows == (0 if name == "f32" else 96 if name == "f16x3tc" else 128 if name != "f16c6" else rows) and rows % 32 == 0
+        assert rows == (0 if name == "f32" else 96 if name in ("f16x3tc", "f16x3tk") else 128 if name != "f16c6" else rows) and rows % 32 == 0
     assert lib.gnn_fused_rows_per_step(_lib.PRECISIONS["f16c6"]) in (128, 160)
     assert lib.gnn_fused_rows_per_step(77) < 0
     from genomad_amd import nn_classification

@@ -171,18 +171,20 @@ def test_errors_are_reported_not_swallowed(engine):
 # The parametrised matrix covers the arithmetics that can ship: the default (f16x3), its f32-range fallback (bf16x3) and the one
 # opt-in fast mode (f16c6).  f16c8 and the round-1 kernel (single-pass bf16) were removed in round 6: one test that the enum values answer
 # with an error (test_removed_arithmetics_answer_with_an_error).
-FUSED = ["f16c6", "f16x3", "f16x3tc", "bf16x3"]
+FUSED = ["f16c6", "f16x3", "f16x3tc", "f16x3tk", "bf16x3"]      # f16x3tk (round 6): needs the k-mer tables (skipped on a device that cannot hold them)
+from tests.conftest import need_tables  # noqa: E402
 # the contig front end is exercised with the default arithmetic first (what main() runs), then the fallback
 from genomad_amd._lib import DEFAULT_PRECISION  # noqa: E402
-CONTIG_PRECS = [DEFAULT_PRECISION, "bf16x3"]
+CONTIG_PRECS = [DEFAULT_PRECISION, "f16x3tk", "bf16x3"]
 
 
 @pytest.mark.parametrize("prec", FUSED)
-def test_fused_intermediates(engine, oracle16, prec):
+def test_fused_intermediates(engine, oracle16, prec, request):
     """Fused kernels (activations in LDS, low-precision MFMA operands) against the fp64 oracle, per stage."""
+    need_tables(request, prec)
     bases, scores64, t64 = oracle16
     scores, taps = engine.debug_forward(bases, prec)
-    loose = {"f16c6": 2.5, "f16x3": 0.25, "f16x3tc": 0.25}.get(prec, 1.0)   # 4-bit correction terms / 11+11-bit limbs vs bf16's 8+8
+    loose = {"f16c6": 2.5, "f16x3": 0.25, "f16x3tc": 0.25, "f16x3tk": 0.25}.get(prec, 1.0)   # 4-bit correction terms / 11+11-bit limbs vs bf16's 8+8
     checks = [("m_a", "mA", 1e-4), ("m_b", "mB", 1e-3), ("yp_a", "ypA", 1e-4), ("yp_b", "ypB", 1e-3),
               ("alpha_a", "alphaA", 1e-5), ("alpha_b", "alphaB", 2e-4), ("feat", "f", 5e-4)]
     for mine, ref, tol in checks:
@@ -200,8 +202,9 @@ def oracle256(synth_weights):
 
 
 @pytest.mark.parametrize("prec", FUSED)
-def test_fused_scores_256_windows(engine, oracle256, prec):
+def test_fused_scores_256_windows(engine, oracle256, prec, request):
     """256 synthetic windows (padded and N-run windows included) within 1e-4 of the fp32 oracle."""
+    need_tables(request, prec)
     bases, want = oracle256
     got = engine.classify(bases, prec)
     err = np.abs(got - want).max()
@@ -210,7 +213,8 @@ def test_fused_scores_256_windows(engine, oracle256, prec):
 
 
 @pytest.mark.parametrize("prec", FUSED)
-def test_fused_equals_f32_path_and_is_batch_invariant(engine, prec):
+def test_fused_equals_f32_path_and_is_batch_invariant(engine, prec, request):
+    need_tables(request, prec)
     bases = synthetic.synth_windows(5000, 96)
     a = engine.classify(bases, prec)
     b = engine.classify(bases, "f32")
@@ -222,7 +226,8 @@ def test_fused_equals_f32_path_and_is_batch_invariant(engine, prec):
 
 
 @pytest.mark.parametrize("prec", FUSED)
-def test_fused_edge_windows(engine, synth_weights, prec):
+def test_fused_edge_windows(engine, synth_weights, prec, request):
+    need_tables(request, prec)
     wins = [b"", b"ACGT", b"ACGT" * 1500, b"A" * 6000, (b"ACGT" * 700), b"N" * 2999 + b"ACGTACGT"]
     bases = np.stack([_pad(w) for w in wins])
     got = engine.classify(bases, prec)
@@ -586,7 +591,10 @@ def test_config2_10k_windows_vs_reference_graph_golden(engine, golden_dir):
     n = len(ref32)
     assert n == 10_000
     worst = {}
-    for prec, tol64 in (("f32", 2e-5), ("f16x3", 2e-5), ("f16x3tc", 2e-5), ("bf16x3", SCORE_TOL), ("f16c6", SCORE_TOL)):
+    precs = [("f32", 2e-5), ("f16x3", 2e-5), ("f16x3tc", 2e-5), ("bf16x3", SCORE_TOL), ("f16c6", SCORE_TOL)]
+    if engine.build_kmer_tables():                      # the k-mer-table arithmetic on a device that can hold its tables
+        precs.insert(3, ("f16x3tk", 2e-5))
+    for prec, tol64 in precs:
         got = _classify_resident(engine, 0, n, prec)
         assert np.isfinite(got).all() and np.allclose(got.sum(1), 1.0, atol=1e-5)
         e32, e64 = np.abs(got - ref32).max(), np.abs(got - truth).max()
@@ -636,9 +644,10 @@ def test_config3_1m_windows_sharding_determinism_and_accuracy(engine, golden_dir
 
 # ------------------------------------------------------------------ contig front end
 @pytest.mark.parametrize("prec", CONTIG_PRECS)
-def test_contig_front_end_equals_window_path(engine, synth_weights, golden_dir, prec):
+def test_contig_front_end_equals_window_path(engine, synth_weights, golden_dir, prec, request):
     """classify_contigs (device-side upper-casing/padding/N rule/segment mean on spans of the packed
     buffer) == reference windowing rules (golden FASTA fixture) + classify + segment mean."""
+    need_tables(request, prec)
     from genomad_amd import sequence
     path = os.path.join(golden_dir, "fasta_fixture.fna.gz")
     names, seq, offsets = sequence.read_fasta_packed(path)
@@ -656,11 +665,12 @@ def test_contig_front_end_equals_window_path(engine, synth_weights, golden_dir, 
 
 
 @pytest.mark.parametrize("prec", CONTIG_PRECS)
-def test_config5_metagenome_contigs_resident_in_hbm(engine, prec):
+def test_config5_metagenome_contigs_resident_in_hbm(engine, prec, request):
     """BASELINE config 5 at reduced size: a 48 Mbp synthetic metagenome (mixed 1-500 kbp contigs,
     log-uniform) generated IN HBM, through the contig front end (spans -> N rule -> upper-case/pad ->
     encode+IGLOO -> per-contig mean), against the same rules applied on the host + the window path;
     plus the properties that hold at any size: contig sharding does not change a bit, rows sum to 1."""
+    need_tables(request, prec)
     from genomad_amd import sequence
     nwin = 8000
     offsets = synthetic.synth_metagenome_offsets(nwin * 6000, seed=99)
@@ -892,12 +902,13 @@ def test_second_weight_set_and_engine(synth_weights):
     assert err["f16c6"] <= 2 * SCORE_TOL
 
 
-@pytest.mark.parametrize("prec", ["f16c6", "f16x3", "f16x3tc", "bf16x3"])
-def test_padding_skip_is_bit_identical(engine, prec):
+@pytest.mark.parametrize("prec", ["f16c6", "f16x3", "f16x3tc", "f16x3tk", "bf16x3"])
+def test_padding_skip_is_bit_identical(engine, prec, request):
     """The streaming kernels (f16c6; f16x3 / bf16x3 of gnn_fused_x3.hip) copy the yp rows and pair products of a window's all-N tail from an all-N window instead of
     computing them (the padding of a contig's last window, nn_classification.py:72).  With the skip switched off the
     scores AND the intermediates must be the same bits: windows of every length class (empty, shorter than a step,
     ending exactly on / one base around a step boundary, N runs inside, IUPAC codes and lower case in the tail, full)."""
+    need_tables(request, prec)
     from genomad_amd import _lib
     rng = np.random.default_rng(11)
     def win(n, tail=b"N"):
@@ -938,10 +949,11 @@ def test_a_misaligned_window_buffer_gives_the_same_scores(engine):
         engine.synth_windows_dev(0, n, buf.ptr)
         engine.sync()
         host = buf.download((n * 6000,), np.uint8)
-        want = {prec: engine.classify(host.reshape(n, 6000), prec) for prec in FUSED}
+        fused = [p_ for p_ in FUSED if p_ != "f16x3tk" or engine.build_kmer_tables()]
+        want = {prec: engine.classify(host.reshape(n, 6000), prec) for prec in fused}
         for shift in (1, 2, 3):
             buf.upload(np.concatenate([np.zeros(shift, np.uint8), host, np.zeros(8 - shift, np.uint8)]))
-            for prec in FUSED:
+            for prec in fused:
                 engine.classify_dev(buf.ptr + shift, n, out.ptr, prec)
                 engine.sync()
                 assert np.array_equal(out.download((n, 3), np.float32), want[prec]), (shift, prec)
@@ -1141,7 +1153,9 @@ def test_time_split_small_batches_are_bit_identical(engine):
     wins[9] = _pad(b"ACGT" * 700)                          # 2800 bases
     wins[10, 3000:3300] = ord("N")
     try:
-        for prec in ("f16x3", "f16x3tc", "bf16x3"):
+        for prec in ("f16x3", "f16x3tc", "f16x3tk", "bf16x3"):
+            if prec == "f16x3tk" and not engine.build_kmer_tables():
+                continue
             for n in (1, 2, 40, 64, 65, 86, 128, 130):
                 for skip in (1, 0):
                     _lib.check(engine.lib.gnn_debug_set_pad_skip(engine.ctx, skip))
@@ -1152,7 +1166,7 @@ def test_time_split_small_batches_are_bit_identical(engine):
                     assert np.array_equal(got, want), (prec, n, skip)
                     for k in wt:
                         assert np.array_equal(gt[k], wt[k]), (prec, n, skip, k)
-                if n > 40 and prec != "f16x3":
+                if n > 40 and prec not in ("f16x3", "f16x3tk"):
                     break                                  # the fallback: the small sizes are enough
         _lib.check(engine.lib.gnn_debug_set_pad_skip(engine.ctx, 1))
         # the point of it: one call of 128 windows through the host-buffer entry point
@@ -1175,7 +1189,8 @@ def test_time_split_small_batches_are_bit_identical(engine):
         _lib.check(engine.lib.gnn_debug_set_pad_skip(engine.ctx, 1))
 
 
-def test_toomcook_kernel_is_bit_identical_under_delay_injection(tmp_path):
+@pytest.mark.parametrize("prec", ["f16x3tc", "f16x3tk"])
+def test_toomcook_kernel_is_bit_identical_under_delay_injection(tmp_path, prec):
     """The default kernel orders its LDS producers and consumers with 18 bare s_barriers per step (tests/test_kernel_schedule.py
     models the schedule).  libgenomad_nn_hip_jitter.so is the same library with every wave sleeping a pseudo-random 0..2 000
     cycles behind every barrier (3.5x the run time): scores, pair products and pooled y @ w_v rows of 600 / 128 / 40 windows
@@ -1189,9 +1204,148 @@ def test_toomcook_kernel_is_bit_identical_under_delay_injection(tmp_path):
     script = os.path.join(root, "scripts", "tc_jitter_check.py")
     ref = str(tmp_path / "ref.npz")
     env = {k: v for k, v in os.environ.items() if k != "GENOMAD_AMD_LIB"}
-    r = subprocess.run([sys.executable, script, "ref", ref], env=env, capture_output=True, text=True, timeout=300, cwd=root)
+    r = subprocess.run([sys.executable, script, "ref", ref, prec], env=env, capture_output=True, text=True, timeout=300, cwd=root)
+    if r.returncode == 77:
+        pytest.skip("the device cannot hold the k-mer tables")
     assert r.returncode == 0, r.stderr[-1500:]
     for _ in range(2):
-        r = subprocess.run([sys.executable, script, "cmp", ref], env=dict(env, GENOMAD_AMD_LIB=jitter), capture_output=True, text=True,
+        r = subprocess.run([sys.executable, script, "cmp", ref, prec], env=dict(env, GENOMAD_AMD_LIB=jitter), capture_output=True, text=True,
                            timeout=300, cwd=root)
         assert r.returncode == 0 and "OK:" in r.stdout, (r.stdout[-800:], r.stderr[-800:])
+
+
+# ------------------------------------------------------------------ f16x3tk: conv2 and head A read from k-mer tables in HBM (round 6)
+_DIG = {65: 0, 67: 1, 71: 2, 84: 3}
+
+
+def test_kmer_table_rows_are_the_exact_paths_activations(kmer_tables):
+    """The 14-mer table holds x2[t] = LeakyReLU(conv2(x1))[t] (igloo.py:65-67) for the 14 bases t-10 .. t+3, head A's table the pair product
+    of (entry, 9-mer at its position) (igloo.py:192-204 folded): rows fetched through the test aid against the exact-f32 path's x2
+    tap at the positions of a synthetic window (f64 accumulation, rounded once: within 4e-6 of the f32 FMA chain)."""
+    import ctypes
+    from genomad_amd import _lib
+    eng = kmer_tables
+    wins = synthetic.synth_windows(11, 1)
+    wins[0, 3000:3020] = ord("N")
+    _, t = eng.debug_forward(wins, "f32", taps=("x2",))
+    row = np.empty(128, np.float32)
+    worst = 0.0
+    for pos in (10, 11, 12, 13, 97, 1000, 2999 - 4, 3020 + 10, 5995, 5996):
+        code = 0
+        for b in wins[0, pos - 10:pos + 4]:
+            code = code * 4 + _DIG[int(b)]
+        _lib.check(eng.lib.gnn_debug_kmer_table_row(eng.ctx, 0, ctypes.c_uint64(code), row.ctypes.data))
+        worst = max(worst, float(np.abs(row - t["x2"][0, pos]).max()))
+    assert worst <= 4e-6, worst
+    # the all-N-token row = x2 deep inside an N run
+    _lib.check(eng.lib.gnn_debug_kmer_table_row(eng.ctx, 0, ctypes.c_uint64(1 << 28), row.ctypes.data))
+    alln = np.frombuffer(b"N" * 6000, np.uint8).reshape(1, 6000)
+    _, tn = eng.debug_forward(alln, "f32", taps=("x2",))
+    assert np.abs(row - tn["x2"][0, 3000]).max() <= 4e-6
+    with pytest.raises(_lib.GnnError, match="out of range"):
+        _lib.check(eng.lib.gnn_debug_kmer_table_row(eng.ctx, 0, ctypes.c_uint64((1 << 28) + 1), row.ctypes.data))
+
+
+def test_kmer_tables_rows_no_table_holds(kmer_tables, synth_weights):
+    """What the 14-mer table cannot index - the first ten positions of a window (absent tokens), k-mers that mix ACGT with other bytes
+    (single Ns, N-run edges at every alignment, IUPAC codes, lower case), the window's last positions - goes through conv2's tap
+    tables (<= 6 row reads per position) and, for head A's entries, a per-entry dot product: every stage within the default
+    arithmetic's tolerances of the fp64 oracle, scores within 1e-4 / 2 of it, and the same bits whatever the batch."""
+    eng = kmer_tables
+    rng = np.random.default_rng(17)
+    base = synthetic.synth_windows(900, 12).copy()
+    base[0, :1] = ord("N")                               # N at the very first base
+    base[1, 5:6] = ord("N")
+    base[2, 9:14] = ord("N")
+    base[3, 5996:] = ord("N")                            # the last token
+    for k, a in enumerate(range(1000, 1000 + 40 * 97, 97)):          # N runs of every length 1 .. 40 at every alignment mod 4 and mod 96
+        base[4, a:a + k + 1] = ord("N")
+    base[5, rng.integers(0, 6000, 300)] = ord("N")       # 5 % scattered N: most 14-mers of the window are mixed
+    base[6, rng.integers(0, 6000, 60)] = rng.choice(list(b"RYKMSWBDHVN"), 60)
+    base[7, 1200:2400] += 32                             # a lower-case (soft-masked) stretch
+    base[8, 0:3] = ord("N")
+    base[9, 2000:] = ord("N")                            # a contig's last window: padding
+    base[10, :] = ord("N")
+    base[11, 95:97] = ord("N")                           # across the first step boundary
+    want, t64 = igloo_oracle.forward(sequence_oracle.tokenize_closed_form(base), synth_weights, np.float64, return_taps=True)
+    got, taps = eng.debug_forward(base, "f16x3tk")
+    for mine, ref, tol in (("m_a", "mA", 1e-4), ("m_b", "mB", 2.5e-4), ("yp_a", "ypA", 1e-4), ("yp_b", "ypB", 2.5e-4), ("feat", "f", 1.25e-4)):
+        err = np.abs(taps[mine] - t64[ref]).max()
+        assert err <= tol, f"{mine}: {err:.3e}"
+    assert np.abs(got - want).max() <= SCORE_TOL / 2
+    assert np.array_equal(eng.classify(base[3:9], "f16x3tk"), got[3:9])
+    assert np.abs(got - eng.classify(base, "f16x3tc")).max() <= 2e-5
+
+
+def test_kmer_tables_that_do_not_fit_leave_the_default_arithmetic(synth_weights):
+    """A device that cannot hold the tables behind the reserve asked for answers GNN_ERR_NOMEM with nothing allocated (the Python side:
+    False), F16X3TK then answers GNN_ERR_STATE, F16X3TC keeps serving; dropping built tables returns their memory."""
+    from genomad_amd._lib import GnnError
+    from genomad_amd.engine import NNEngine
+    with NNEngine(0, synth_weights) as eng:
+        free0 = eng.mem_info()[0]
+        assert eng.build_kmer_tables(reserve_bytes=1 << 50) is False
+        assert not eng.has_kmer_tables() and abs(eng.mem_info()[0] - free0) < (64 << 20)
+        b = synthetic.synth_windows(0, 4)
+        with pytest.raises(GnnError, match="k-mer tables"):
+            eng.classify(b, "f16x3tk")
+        ref = eng.classify(b, "f16x3tc")
+        if eng.build_kmer_tables(reserve_bytes=0):          # a second set beside the session engine's only fits a large device
+            assert eng.has_kmer_tables() and eng.mem_info()[0] < free0 - (140 << 30)
+            assert np.abs(eng.classify(b, "f16x3tk") - ref).max() <= 2e-5
+            eng.drop_kmer_tables()
+            assert not eng.has_kmer_tables() and eng.mem_info()[0] > free0 - (1 << 30)
+
+
+def test_config3_1m_windows_through_the_kmer_tables(kmer_tables, golden_dir):
+    """BASELINE configs 3/4 with the arithmetic bench.py times on a device that holds the tables: run-to-run bit identity, 8 contiguous
+    shards == one pass, and every 64th of the 2^20 windows against the outputs of the reference's own graph within half the tolerance."""
+    eng = kmer_tables
+    n = 1 << 20
+    one = _classify_resident(eng, 0, n, "f16x3tk")
+    assert hashlib.sha256(one.tobytes()).hexdigest() == hashlib.sha256(_classify_resident(eng, 0, n, "f16x3tk").tobytes()).hexdigest()
+    assert np.array_equal(one, _classify_resident(eng, 0, n, "f16x3tk", shards=8))
+    assert np.isfinite(one).all() and np.abs(one.sum(1) - 1.0).max() < 1e-5
+    assert np.array_equal(one[777_000:777_512], _classify_resident(eng, 777_000, 512, "f16x3tk"))
+    g = np.load(os.path.join(golden_dir, "config3_strided_golden.npz"))
+    idx = g["indices"]
+    e32 = float(np.abs(one[idx] - g["scores_refgraph32"]).max())
+    e64 = float(np.abs(one[idx] - g["scores_oracle64"]).max())
+    print(f"config 3, {len(idx)} windows strided over 2^20, f16x3tk: max |dscore| vs reference graph {e32:.3e}, vs fp64 oracle {e64:.3e}")
+    assert e32 <= SCORE_TOL / 2 and e64 <= SCORE_TOL / 2
+
+
+def test_main_promotes_the_default_arithmetic_to_the_kmer_tables(kmer_tables, synth_weights, tmp_path, monkeypatch):
+    """main() (nn_classification.py:21-30) on an engine that holds the tables classifies with f16x3tk (GENOMAD_AMD_KMER_TABLES=auto),
+    with the default arithmetic under GENOMAD_AMD_KMER_TABLES=0: the per-contig scores agree to 2e-5, both are within 1e-4 of the
+    oracle chain, and the explicit GENOMAD_AMD_PRECISION=f16x3tk gives the bits of the promoted run."""
+    from genomad_amd import nn_classification as nnc
+    from genomad_amd import weights as W
+    rng = np.random.default_rng(21)
+    recs = [("k1", "".join(rng.choice(list("ACGT"), 30000))), ("k2", "NN" + "".join(rng.choice(list("ACGTN"), 14000, p=[.24, .24, .24, .24, .04]))),
+            ("k3", "".join(rng.choice(list("acgt"), 700)))]
+    fa = tmp_path / "k.fna"
+    fa.write_text("".join(f">{n}\n{s}\n" for n, s in recs))
+    wpath = tmp_path / "w.npz"
+    W.save_npz(wpath, synth_weights)
+    monkeypatch.setenv("GENOMAD_AMD_WEIGHTS", str(wpath))
+    monkeypatch.setattr(nnc, "_ENGINE", kmer_tables)
+    seen = []
+    real = nnc.classify_contigs_safely
+    monkeypatch.setattr(nnc, "classify_contigs_safely", lambda eng, sq, off, sw, prec, console=None: (seen.append(prec), real(eng, sq, off, sw, prec, console))[1])
+    preds = {}
+    for tag, env in (("auto", {}), ("off", {"GENOMAD_AMD_KMER_TABLES": "0"}), ("explicit", {"GENOMAD_AMD_PRECISION": "f16x3tk"})):
+        for k in ("GENOMAD_AMD_KMER_TABLES", "GENOMAD_AMD_PRECISION"):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        out = tmp_path / tag
+        nnc.main(fa, out, False, 128, True, 1, False, False)
+        preds[tag] = np.load(out / "k_nn_classification" / "k_nn_classification.npz")["predictions"]
+    assert seen == ["f16x3tk", "f16x3tc", "f16x3tk"], seen
+    names, ids, wins = sequence_oracle.encode_fasta(fa)
+    want = sequence_oracle.segment_mean(igloo_oracle.classify_windows(wins, synth_weights, np.float32), ids)
+    for tag in preds:
+        assert np.abs(preds[tag] - want).max() <= SCORE_TOL, tag
+    assert np.array_equal(preds["auto"], preds["explicit"])
+    assert 0 < np.abs(preds["auto"] - preds["off"]).max() <= 2e-5
