@@ -57,7 +57,8 @@ constexpr int QUAD_OFF = VRING_OFF + VRING * VSLOT;
 constexpr int BIASK_OFF = QUAD_OFF + ((QUAD_N * 2 + 15) / 16) * 16;
 constexpr int DIRTY_OFF = BIASK_OFF + C * 4;        // [0] count, [1..] buffer rows no table holds
 constexpr int DIRTY_MAX = BUF_ROWS;
-constexpr int LASTK_OFF = DIRTY_OFF + ((4 + DIRTY_MAX + 15) / 16) * 16;
+constexpr int BKT_OFF = DIRTY_OFF + ((4 + DIRTY_MAX + 15) / 16) * 16;      // entry ranges per step of both heads: 2 x (STEPST + 1) ints
+constexpr int LASTK_OFF = BKT_OFF + 2 * (STEPST + 1) * 4;
 constexpr int SMEMK = LASTK_OFF + 16;
 constexpr int X2_PER_WAVE = (BUF_ROWS + 3) / 4;     // 26 rows of the next step per helper wave (the last wave: 23)
 static_assert(SMEMK <= 160 * 1024, "LDS budget");
@@ -259,6 +260,8 @@ __global__ __launch_bounds__(512, 2) void fused_front_tk_kernel(ArgsK a) {
     for (int q = tid; q < QUAD_N; q += 512)
         quads[q] = q < QUADS ? (uint16_t)quad_of(reinterpret_cast<const uint32_t*>(bases)[q]) : (uint16_t)0;
     if (tid < C) bias_s[tid] = a.conv_b3[tid];
+    int* bkt = reinterpret_cast<int*>(smem + BKT_OFF);             // bkt[h * (STEPST + 1) + s]
+    if (tid >= 128 && tid < 128 + 2 * (STEPST + 1)) bkt[tid - 128] = a.bucket_ptr[(tid - 128) / (STEPST + 1)][(tid - 128) % (STEPST + 1)];
     if (tid == 0) {
         *s_last = -1;
         *reinterpret_cast<uint32_t*>(smem + DIRTY_OFF) = 0u;
@@ -378,72 +381,95 @@ __global__ __launch_bounds__(512, 2) void fused_front_tk_kernel(ArgsK a) {
             __builtin_amdgcn_s_setprio(3);
             if constexpr (PROF) tick_ = __builtin_readcyclecounter();
             Raw16 ra, rb;
-            PairPass p0, p1;
-            p0.u = p1.u = 0;
-            // head A's entry of this thread in the first step (its position is requested a step ahead)
-            int ea = a.bucket_ptr[0][s_lo] + ht;
-            int ea_end = a.bucket_ptr[0][s_lo + 1];
-            int ua = ea < ea_end ? a.pos_sorted[0][ea] : 0;
+            PairPass p0, p1, p2;          // head B's three passes: all requested in front of E (three sets fit: the helper role has no x1 gather to hold)
+            p0.u = p1.u = p2.u = 0;
+            // Per-step bookkeeping of the helpers - head A's entry of this thread (MpaTable read), the entry ranges of both heads - is
+            // fetched at the END of the step before, in front of the x2 rows' requests: a wave's loads return in order and the compiler
+            // waits with vmcnt(0) for loads it issued under a condition, so anything consumed while the x2 rows travel would wait for
+            // their whole round trip to HBM (measured: +3 k cycles per step).
+            struct StepA {
+                int ea, ea_end, ua;
+            };
+            StepA cur, nxt;               // this step; the next one (position requested behind c_7, located behind E)
+            cur.ea = cur.ea_end = cur.ua = 0;
+            float va = 0.f;               // MpaTable value of cur's entry (requested at the top of the step, behind the x2 rows)
+            bool va_slow = false, nxt_slow = false;
+            const float* nxt_ptr = a.mpa_tbl;
+            auto fetch = [&](int st, bool valid) {               // nxt = entry and position of step st (valid: st < s_hi); entry ranges from LDS
+                nxt.ea = valid ? bkt[st] + ht : 0;
+                nxt.ea_end = valid ? bkt[st + 1] : 0;
+                nxt.ua = nxt.ea < nxt.ea_end ? a.pos_sorted[0][nxt.ea] : 0;
+            };
+            // nxt -> where head A's pair product of that entry sits in MpaTable.  This CONSUMES the position: the compiler waits for it
+            // with vmcnt(0) (a load under a condition), so it happens where nothing long is pending - behind E, in front of the pair products
+            auto locate = [&]() {
+                nxt_slow = false;
+                uint32_t code = 0, dirty = 0;
+                if (nxt.ea < nxt.ea_end) {
+                    kmer_q<9>(quads, max(nxt.ua - 5, 0), code, dirty);
+                    const bool nn = all_n_tokens<9>(dirty);
+                    nxt_slow = nxt.ua < 5 || (dirty != 0u && !nn);
+                }
+                nxt_ptr = a.mpa_tbl + ((size_t)max(nxt.ea, 0) * K9_ROWS + (dirty == 0u ? code : K9_NN));
+            };
+            fetch(s_lo, true);
+            locate();
             {                                                                    // V3 chunk 0 of the first step
                 const HLane h0 = hlane(smem, (s_lo & 1) * BUF_BYTES, hw, lane);
                 load_rows(ra, h0, 0);
                 transform_store(ra, h0, 0);
                 load_rows(ra, h0, 2);
             }
+
 #pragma unroll 1
             for (int step = s_lo; step < s_hi; ++step) {
                 const int t0 = step * FTT;
                 const int xoff = (step & 1) * BUF_BYTES, yoff = BUF_BYTES - xoff;
                 const HLane hx = hlane(smem, xoff, hw, lane), hy = hlane(smem, yoff, hw, lane);
                 const bool more = step + 1 < s_hi;
-                const PairJob jb = {smem + xoff, a.weff_b, a.pos_sorted[1], mp_w[1], t0, a.bucket_ptr[1][step], a.bucket_ptr[1][step + 1]};
-                // head A's pair product of this thread's entry: one table read, requested first (a wave's loads return in order: behind the x2 rows
-                // it would hold their stores back for its own round trip, a 4-byte read at a random address of an 8.8 GB table), stored behind E
-                float va = 0.f;
-                bool va_slow = false;
-                if (ea < ea_end) {
-                    uint32_t code, dirty;
-                    kmer_q<9>(quads, max(ua - 5, 0), code, dirty);
-                    const bool nn = all_n_tokens<9>(dirty);
-                    va_slow = ua < 5 || (dirty != 0u && !nn);
-#ifdef TK_ABL_NOMPA
-                    va = (float)code;
-#else
-                    va = a.mpa_tbl[(size_t)ea * K9_ROWS + (dirty == 0u ? code : K9_NN)];
-#endif
-                }
-                const int ea_cur = ea, ea_end_cur = ea_end, ua_cur = ua;
-                ea = more ? a.bucket_ptr[0][step + 1] + ht : 0;                  // the next step's entry and its position
-                ea_end = more ? a.bucket_ptr[0][step + 2] : 0;
-                ua = ea < ea_end ? a.pos_sorted[0][ea] : 0;
-                // x2 of the next step: 26 rows per wave, requested a few at a time beside the conv loop (their misses share the vector L1
-                // with the matrix waves' weight stream), stored behind c_6 when nobody reads buf[(s+1) & 1] any more
+                const PairJob jb = {smem + xoff, a.weff_b, a.pos_sorted[1], mp_w[1], t0, bkt[STEPST + 1 + step], bkt[STEPST + 1 + step + 1]};
+                // The x2 rows of the NEXT step: 26 per wave, all requested here - between head B's pair products of the last step and c_0,
+                // with NO load pending in front of them (every register the allocator recycles for their addresses is then free of
+                // pending writes: it put an s_waitcnt vmcnt(0) into the middle of the 26 requests otherwise; the pair products' stores may
+                // be) -, stored behind c_6.  They
+                // are requested and stored inside one iteration: carried around the loop, the allocator copied one row register at the
+                // loop header and waited there for all 26.  Behind them the one long read nobody waits for before E: head A's table.
+                // (A wave's loads return in order and the compiler waits with vmcnt(0) for loads issued under a condition: whatever is
+                // consumed while the rows travel would wait for their whole round trip to HBM.)
+                cur = nxt;
+                va_slow = nxt_slow;
+                const float* va_ptr = nxt_ptr;
                 X2Rows xr;
                 const uint32_t my_row = x2_rows_index(smem, quads, t0 + FTT - CARRY, hw, lane, more);
+#ifdef TK_WAIT_BEFORE_ROWS
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+                GNN_REGION_END();
+                x2_rows_issue<0, X2_PER_WAVE>(xr, a.x2_tbl, my_row, lane);
+                GNN_REGION_END();
+#ifdef TK_ABL_NOMPA
+                va = 0.f;
+#else
+                va = cur.ea < cur.ea_end ? *va_ptr : 0.f;
+#endif
                 GNN_TICK(14)
                 TC_HPRIO_HIGH();
                 HBAR_W(15, 8);                                                   // c_0
-                x2_rows_issue<0, 5>(xr, a.x2_tbl, my_row, lane);
                 load_rows(rb, hx, 3);
                 transform_store(ra, hx, 2);
                 HBAR_W(9, 8);                                                    // c_1
-                x2_rows_issue<5, 10>(xr, a.x2_tbl, my_row, lane);
                 load_rows(ra, hx, 4);
                 transform_store(rb, hx, 0);
                 HBAR_W(10, 8);                                                   // c_2
-                x2_rows_issue<10, 14>(xr, a.x2_tbl, my_row, lane);
                 load_rows(rb, hx, 5);
                 transform_store(ra, hx, 1);
                 HBAR_W(10, 8);                                                   // c_3
-                x2_rows_issue<14, 18>(xr, a.x2_tbl, my_row, lane);
                 load_rows(ra, hx, 6);
                 transform_store(rb, hx, 2);
                 HBAR_W(10, 8);                                                   // c_4
-                x2_rows_issue<18, 22>(xr, a.x2_tbl, my_row, lane);
                 load_rows(rb, hx, 7);
                 transform_store(ra, hx, 0);
                 HBAR_W(10, 8);                                                   // c_5
-                x2_rows_issue<22, X2_PER_WAVE>(xr, a.x2_tbl, my_row, lane);
                 transform_store(rb, hx, 1);
                 HBAR_W(11, 8);                                                   // c_6: V3 is complete, buf[(s+1) & 1] (x3(s-1)) is dead
                 x2_rows_store(xr, smem + yoff, my_row, hw, lane);
@@ -451,6 +477,9 @@ __global__ __launch_bounds__(512, 2) void fused_front_tk_kernel(ArgsK a) {
                     dirty_rows_fill<256>(smem, smem + yoff, t0 + FTT - CARRY, bases, a.pt_tbl, a.conv2_b, ht);
                 }
                 HBAR_W(12, 8);                                                   // c_7: x2(s+1) is in buf[(s+1) & 1]
+#ifndef TK_HPRIO_LATE
+                TC_HPRIO_LOW();                                                  // the matrix waves' last unit and epilogue are the critical path now
+#endif
                 if (ht == 0) *reinterpret_cast<volatile uint32_t*>(smem + DIRTY_OFF) = 0u;
                 if (more) {                                                      // V3(s+1) chunk 0 (ring slot 0: chunk 6 was read in front of c_7)
                     load_rows(ra, hy, 0);
@@ -459,16 +488,18 @@ __global__ __launch_bounds__(512, 2) void fused_front_tk_kernel(ArgsK a) {
                 }
                 pass_issue(p0, jb, 0, hw, lane);
                 pass_issue(p1, jb, 1, hw, lane);
+                pass_issue(p2, jb, 2, hw, lane);
+                fetch(step + 1, more);                                           // head A's entry of the next step: its position, located behind E
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 HBAR(13, 8);                                                     // ---- E: x3 is in buf[s & 1]
                 TC_HPRIO_LOW();
+                locate();
                 pass_compute(p0, jb, 0, hw, lane);
-                pass_issue(p0, jb, 2, hw, lane);
                 pass_compute(p1, jb, 1, hw, lane);
-                if (ea_cur < ea_end_cur) {
-                    if (va_slow) va = pair_a_slow(bases, a.pairs6, a.weff_a, ea_cur, ua_cur);
-                    mp_w[0][ea_cur] = va;
-                    for (int e = ea_cur + 256; e < ea_end_cur; e += 256) {       // a crowded step (more than 256 entries; rare)
+                if (cur.ea < cur.ea_end) {
+                    if (va_slow) va = pair_a_slow(bases, a.pairs6, a.weff_a, cur.ea, cur.ua);
+                    mp_w[0][cur.ea] = va;
+                    for (int e = cur.ea + 256; e < cur.ea_end; e += 256) {       // a crowded step (more than 256 entries; rare)
                         const int u = a.pos_sorted[0][e];
                         uint32_t code, dirty;
                         kmer_q<9>(quads, max(u - 5, 0), code, dirty);
@@ -477,7 +508,7 @@ __global__ __launch_bounds__(512, 2) void fused_front_tk_kernel(ArgsK a) {
                                                                       : a.mpa_tbl[(size_t)e * K9_ROWS + (dirty == 0u ? code : K9_NN)];
                     }
                 }
-                pass_compute(p0, jb, 2, hw, lane);
+                pass_compute(p2, jb, 2, hw, lane);
                 pass_rest(p0, jb, 3, hw, lane);
             }
         }
