@@ -306,12 +306,14 @@ __global__ __launch_bounds__(512, 2) void fused_front_tk_kernel(ArgsK a) {
                 }
             }
             __syncthreads();
+            GNN_TICK(6)
             if (dirty_count(smem)) {
                 dirty_rows_fill<512>(smem, buf, tb, bases, a.pt_tbl, a.conv2_b, tid);
                 __syncthreads();
                 if (tid == 0) *reinterpret_cast<uint32_t*>(smem + DIRTY_OFF) = 0u;
             }
             __syncthreads();
+            GNN_TICK(7)
         }
 
         if (!helper) {

@@ -57,6 +57,18 @@ for d in u8 bf16 f32; do
   done
 done
 cd $ROOT
-python scripts/hbm_traffic_json.py --tc-dir $OUT --out $OUT/hbm_traffic.json > $OUT/hbm_traffic_json.log 2>&1
+# 4. FETCH_SIZE against a known byte count for the row-gather access form (MI355X_MICROARCH.md: "calibrate on a known byte count in your
+# own access pattern"): one launch per access form over a 128 MiB (Infinity-Cache resident) and a 137 GB table
+if [ -x build_variants/probe_gather_big ]; then
+  cd /tmp
+  for k in 9 14; do
+    rm -rf /tmp/cal
+    timeout 200 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d /tmp/cal -- $ROOT/build_variants/probe_gather_big calib $k > $OUT/fetch_calibration_$k.log 2>&1
+    summarise "$(find /tmp/cal -name '*counter_collection.csv' | head -1)" "$(find /tmp/cal -name '*kernel_trace.csv' | head -1)" > $OUT/fetch_calibration_$k.txt
+  done
+  cd $ROOT
+fi
+KIND=${PROFILE_KIND:-tk}
+python scripts/hbm_traffic_json.py --$KIND-dir $OUT --out $OUT/hbm_traffic.json > $OUT/hbm_traffic_json.log 2>&1
 ls -la $OUT
 cat $OUT/pmc_1.txt | grep fused; cat $OUT/pmc_2.txt | grep fused; cat $OUT/encoder_*_WRITE_SIZE.txt

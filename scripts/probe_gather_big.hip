@@ -44,6 +44,49 @@ __global__ __launch_bounds__(256) void gather_kernel(const uint4* __restrict__ t
     out[(size_t)blockIdx.x * 256 + threadIdx.x] = make_uint4(__float_as_uint(acc.x), __float_as_uint(acc.y), __float_as_uint(acc.z), __float_as_uint(acc.w));
 }
 
+// the access form of the product kernels: one row = 64 lanes x 8 B (gnn_fused_tk.hip: x2_rows_issue, gnn_tc_dev.h: wva_issue)
+template <int INFLIGHT>
+__global__ __launch_bounds__(256) void gather_b64_kernel(const uint2* __restrict__ table, const uint32_t* __restrict__ codes, long positions,
+                                                        int k, long rows, uint2* __restrict__ out) {
+    const int sub = threadIdx.x & 63, r = threadIdx.x >> 6;
+    const unsigned long mask = (unsigned long)rows - 1;
+    const long per_block = (positions + gridDim.x - 1) / gridDim.x;
+    const long p0 = (long)blockIdx.x * per_block, p1 = min(positions, p0 + per_block);
+    float2 acc = make_float2(0.f, 0.f);
+    for (long p = p0 + r * INFLIGHT; p < p1; p += 4 * INFLIGHT) {
+        uint2 v[INFLIGHT];
+#pragma unroll
+        for (int i = 0; i < INFLIGHT; ++i) {
+            const unsigned long row = (codes[p + i] >> (32 - 2 * k)) & mask;
+            v[i] = table[(size_t)row * 64 + sub];
+        }
+#pragma unroll
+        for (int i = 0; i < INFLIGHT; ++i) {
+            acc.x += __uint_as_float(v[i].x);
+            acc.y += __uint_as_float(v[i].y);
+        }
+    }
+    out[(size_t)blockIdx.x * 256 + threadIdx.x] = make_uint2(__float_as_uint(acc.x), __float_as_uint(acc.y));
+}
+
+// probe_gather_big calib <k>: ONE launch of each access form over a 4^k-row table, for a rocprofv3 --pmc FETCH_SIZE pass: the counter
+// against the known byte count (positions x 512) calibrates it for THIS access pattern (MI355X_MICROARCH.md, HBM section)
+static void calib(int k, long positions, const uint32_t* codes) {
+    const long rows = 1L << (2 * k);
+    uint4* table; uint4* out;
+    CK(hipMalloc(&table, (size_t)rows * 512));
+    CK(hipMalloc(&out, (size_t)2048 * 256 * 16));
+    CK(hipMemset(table, 0, (size_t)rows * 512));
+    CK(hipDeviceSynchronize());
+    hipLaunchKernelGGL((gather_kernel<1, 4>), dim3(2048), dim3(256), 0, 0, table, codes, positions, k, rows, out);
+    CK(hipDeviceSynchronize());
+    hipLaunchKernelGGL((gather_b64_kernel<8>), dim3(2048), dim3(256), 0, 0, reinterpret_cast<const uint2*>(table), codes, positions, k, rows,
+                       reinterpret_cast<uint2*>(out));
+    CK(hipDeviceSynchronize());
+    printf("calib: %d-mers (%.2f GB): each kernel gathered %ld rows x 512 B = %.0f KiB\n", k, rows * 512 / 1e9, positions, positions * 512.0 / 1024);
+    CK(hipFree(table)); CK(hipFree(out));
+}
+
 template <int TABLES, int INFLIGHT>
 static void run(int k, long positions, const uint32_t* bases, int blocks) {
     const long rows = 1L << (2 * k);
@@ -80,6 +123,7 @@ int main(int argc, char** argv) {
     }
     uint32_t* bases; CK(hipMalloc(&bases, h.size() * 4)); CK(hipMemcpy(bases, h.data(), h.size() * 4, hipMemcpyHostToDevice));
     size_t fr, tot; CK(hipMemGetInfo(&fr, &tot)); printf("device memory: %.1f GB free of %.1f GB\n", fr / 1e9, tot / 1e9);
+    if (argc > 2 && std::string(argv[1]) == "calib") { calib(atoi(argv[2]), positions, bases); return 0; }
     const int kmax = argc > 1 ? atoi(argv[1]) : 14;
     for (int k = 9; k <= kmax; ++k) {
         run<1, 4>(k, positions, bases, 256 * 8);

@@ -1190,7 +1190,7 @@ def test_time_split_small_batches_are_bit_identical(engine):
 
 
 @pytest.mark.parametrize("prec", ["f16x3tc", "f16x3tk"])
-def test_toomcook_kernel_is_bit_identical_under_delay_injection(tmp_path, prec):
+def test_toomcook_kernel_is_bit_identical_under_delay_injection(engine, tmp_path, prec):
     """The default kernel orders its LDS producers and consumers with 18 bare s_barriers per step (tests/test_kernel_schedule.py
     models the schedule).  libgenomad_nn_hip_jitter.so is the same library with every wave sleeping a pseudo-random 0..2 000
     cycles behind every barrier (3.5x the run time): scores, pair products and pooled y @ w_v rows of 600 / 128 / 40 windows
@@ -1202,6 +1202,8 @@ def test_toomcook_kernel_is_bit_identical_under_delay_injection(tmp_path, prec):
     if not os.path.exists(jitter):
         pytest.skip("libgenomad_nn_hip_jitter.so not built (genomad_amd/csrc/build.sh builds it)")
     script = os.path.join(root, "scripts", "tc_jitter_check.py")
+    if prec == "f16x3tk":
+        engine.drop_kmer_tables()          # the subprocesses build their own (one 146 GB set fits beside the session engine, two do not)
     ref = str(tmp_path / "ref.npz")
     env = {k: v for k, v in os.environ.items() if k != "GENOMAD_AMD_LIB"}
     r = subprocess.run([sys.executable, script, "ref", ref, prec], env=env, capture_output=True, text=True, timeout=300, cwd=root)

@@ -1410,3 +1410,69 @@ def test_bench_under_the_drivers_launcher_with_two_ranks_over_the_fake_engine():
     assert o["cpu_baseline"]["omp_num_threads_env"] == "1"                      # the launcher did export it ...
     assert o["cpu_baseline"]["cores"] == o["cpu_baseline"]["host_cpus_visible"] or o["cpu_baseline"]["host_cpus_visible"] == 1   # ... and it did not bind
     assert o["steps_verified"]["mismatching_windows_all_ranks"] == 0 and o["parity"]["ok"] and "failed" not in o
+
+
+# ------------------------------------------------------------------ f16x3tk: when main() builds / uses the k-mer tables (round 6)
+class _TablesEngine:
+    """stand-in for NNEngine's three table methods"""
+
+    def __init__(self, fits=True, has=False):
+        self.fits, self.has, self.builds = fits, has, 0
+
+    def has_kmer_tables(self):
+        return self.has
+
+    def build_kmer_tables(self, reserve_bytes=-1):
+        self.builds += 1
+        self.has = self.has or self.fits
+        return self.has
+
+
+class _Comm:
+    """allreduce_max over a fixed list of what the OTHER ranks contribute"""
+
+    def __init__(self, others):
+        self.others = list(others)
+
+    def allreduce_max(self, v):
+        return max([v] + [self.others.pop(0)] if self.others else [v])
+
+
+def test_select_arithmetic_policy(monkeypatch):
+    """nn_classification.select_arithmetic: the default arithmetic is promoted to f16x3tk when the engine holds the tables, when the
+    input is large enough to repay their set-up (GENOMAD_AMD_KMER_TABLES_MIN_GB) or when GENOMAD_AMD_KMER_TABLES=1; never under
+    =0; a device that cannot hold them keeps f16x3tc; an explicit f16x3tk that cannot be served is an error; other arithmetics pass
+    through; with several ranks ONE rank that cannot build keeps every rank on the default (scores must not depend on the rank)."""
+    from genomad_amd import nn_classification as nnc
+    for k in ("GENOMAD_AMD_KMER_TABLES", "GENOMAD_AMD_KMER_TABLES_MIN_GB"):
+        monkeypatch.delenv(k, raising=False)
+    small, big = 10 ** 9, 30 * 10 ** 9
+    e = _TablesEngine()
+    assert nnc.select_arithmetic(e, "f16x3tc", small) == "f16x3tc" and e.builds == 0
+    assert nnc.select_arithmetic(e, "f16x3tc", big) == "f16x3tk" and e.builds == 1
+    assert nnc.select_arithmetic(e, "f16x3tc", small) == "f16x3tk"              # the engine holds them now
+    for other in ("bf16x3", "f32", "f16x3"):
+        assert nnc.select_arithmetic(_TablesEngine(), other, big) == other
+    assert nnc.select_arithmetic(_TablesEngine(fits=False), "f16x3tc", big) == "f16x3tc"
+    with pytest.raises(RuntimeError, match="cannot hold"):
+        nnc.select_arithmetic(_TablesEngine(fits=False), "f16x3tk", small)
+    assert nnc.select_arithmetic(_TablesEngine(), "f16x3tk", small) == "f16x3tk"
+    monkeypatch.setenv("GENOMAD_AMD_KMER_TABLES", "0")
+    assert nnc.select_arithmetic(_TablesEngine(has=True), "f16x3tc", big) == "f16x3tc"
+    monkeypatch.setenv("GENOMAD_AMD_KMER_TABLES", "1")
+    assert nnc.select_arithmetic(_TablesEngine(), "f16x3tc", small) == "f16x3tk"
+    monkeypatch.setenv("GENOMAD_AMD_KMER_TABLES", "sometimes")
+    with pytest.raises(ValueError, match="GENOMAD_AMD_KMER_TABLES"):
+        nnc.select_arithmetic(_TablesEngine(), "f16x3tc", small)
+    monkeypatch.setenv("GENOMAD_AMD_KMER_TABLES", "auto")
+    monkeypatch.setenv("GENOMAD_AMD_KMER_TABLES_MIN_GB", "0.5")
+    assert nnc.select_arithmetic(_TablesEngine(), "f16x3tc", small) == "f16x3tk"
+    monkeypatch.delenv("GENOMAD_AMD_KMER_TABLES_MIN_GB")
+    # several ranks: first collective = does anybody want them (1.0 = yes), second = did anybody fail (1.0 = yes)
+    assert nnc.select_arithmetic(_TablesEngine(), "f16x3tc", big, _Comm([1.0, 0.0])) == "f16x3tk"
+    assert nnc.select_arithmetic(_TablesEngine(), "f16x3tc", big, _Comm([1.0, 1.0])) == "f16x3tc"       # another rank could not build
+    e = _TablesEngine()
+    assert nnc.select_arithmetic(e, "f16x3tc", small, _Comm([1.0, 0.0])) == "f16x3tk" and e.builds == 1   # another rank already holds them
+    # an engine without the table methods (the CPU stand-in of the multi-rank tests) is left alone
+    assert nnc.select_arithmetic(object(), "f16x3tc", big) == "f16x3tc"
+    assert nnc.RANGE_FALLBACKS["f16x3tk"] == ("f16x3", "bf16x3")

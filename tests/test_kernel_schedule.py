@@ -281,3 +281,91 @@ def test_toomcook_model_has_the_barriers_the_source_has():
     assert calls == want, calls
     per_step_model = len(list(tc_schedule(2))) - len(list(tc_schedule(1)))
     assert n_matrix == len(calls) == per_step_model == 18
+
+
+# ------------------------------------------------------------------ the k-mer-table kernel (gnn_fused_tk.hip): 9 barriers per step, two alternating row buffers
+def tk_schedule(steps: int = 4, store_at: int = 6, chunk0_at: int = 7):
+    """Phases of gnn_fused_tk.hip's step loop.  Regions: buf0 / buf1 (rows of x2(s), overwritten by x3(s); x2(s+1) lands in the other),
+    ring0..2, dirty (the list of rows no 14-mer indexes + its counter).  `store_at` = the conv interval in which the helpers store the
+    gathered x2(s+1) rows (the kernel: behind c_6, when V3(s) is complete ... and x3(s-1) long dead), `chunk0_at` = the interval in which
+    they make V3(s+1) chunk 0 (the kernel: behind c_7, ring slot 0 = chunk 6's slot)."""
+    def buf(s):
+        return f"buf{s & 1}"
+
+    def ring(c):
+        return f"ring{c % 3}"
+
+    # prologue: all waves gather x2(0) (+ the rows the tap tables fill), barrier; matrix: V3(0) chunk 1, helpers: chunk 0
+    yield [("all", "w", buf(0), ("x2", 0), True), ("all", "w", "dirty", ("d", 0), True)]
+    yield [("all", "r", "dirty", ("d", 0), True), ("all", "w", buf(0), ("x2", 0), False)]          # dirty_rows_fill: each thread its own channel of a listed row
+    yield [("all", "w", "dirty", ("d", -1), False)]                                               # one thread resets the list
+    yield [("matrix", "r", buf(0), ("x2", 0), True), ("matrix", "w", ring(1), ("c3", 0, 1), True),
+           ("helper", "r", buf(0), ("x2", 0), True), ("helper", "w", ring(0), ("c3", 0, 0), True)]
+    for s in range(steps):
+        last = s + 1 >= steps
+        for c in range(8):                                                   # ---- conv3: c_0 .. c_7
+            ph = [("matrix", "r", ring(c), ("c3", s, c), True)]
+            if c + 1 < 8:
+                ph.append(("matrix", "r", ring(c + 1), ("c3", s, c + 1), True))
+            if c + 2 < 8:
+                ph += [("helper", "r", buf(s), ("x2", s), True), ("helper", "w", ring(c + 2), ("c3", s, c + 2), True)]
+            if c == 0 and not last:
+                ph.append(("helper", "w", "dirty", ("d", s + 1), True))      # row indices of x2(s+1): rows no table holds go onto the list
+            if c == store_at and not last:
+                ph += [("helper", "w", buf(s + 1), ("x2", s + 1), True),     # a wave stores the rows it requested (other waves read them); listed rows are not stored ...
+                       ("helper", "r", "dirty", ("d", s + 1), False)]        # ... but filled from the tap tables (list written behind c_0)
+            if c == chunk0_at:
+                ph.append(("helper", "w", "dirty", ("d", -1), False))        # one thread resets the list
+                if not last:
+                    ph += [("helper", "r", buf(s + 1), ("x2", s + 1), True), ("helper", "w", ring(0), ("c3", s + 1, 0), True)]
+            if c == 7:
+                ph.append(("matrix", "w", buf(s), ("x3", s), True))          # conv3 epilogue overwrites x2(s) with x3(s)
+            yield ph
+        ph = [("matrix", "r", buf(s), ("x3", s), True),                      # ---- E .. c_0: w_v B(s), then V3(s+1) chunk 1
+              ("helper", "r", buf(s), ("x3", s), True)]                      # head B's pair products (three passes)
+        if not last:
+            ph += [("matrix", "r", buf(s + 1), ("x2", s + 1), True), ("matrix", "w", ring(1), ("c3", s + 1, 1), True)]
+        yield ph
+
+
+def test_kmer_table_kernel_schedule_orders_every_lds_producer_and_consumer_with_a_barrier():
+    for steps in (1, 2, 3, 63):
+        assert check(list(tk_schedule(steps))) == []
+
+
+def test_kmer_table_model_notices_wrong_placements():
+    # x2(s+1) stored while the helpers still transform x2(s)?  No: other buffer.  But stored BEFORE head B's last pass of step s-1 would
+    # be wrong in the real kernel only if that pass ran beside the conv loop; the model's invariants: rows stored behind c_7 (same
+    # interval as chunk 0 of the next step reads them) ...
+    assert any("buf" in msg for _, msg in check(list(tk_schedule(3, store_at=7))))
+    # ... and chunk 0 of the next step written behind c_6 lands in the slot the matrix waves read chunk 6 from
+    assert any("ring0" in msg for _, msg in check(list(tk_schedule(3, chunk0_at=6))))
+
+
+def test_kmer_table_model_has_the_barriers_the_source_has():
+    """Both roles of gnn_fused_tk.hip pass the same number of workgroup barriers per step, in the order the model assumes."""
+    import os
+    import re
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    src = open(os.path.join(root, "genomad_amd", "csrc", "gnn_fused_tk.hip")).read()
+    i = src.index("if (!helper) {")
+    matrix, end = _loop_body_from(src, "for (int step = s_lo; step < s_hi; ++step) {", i)
+    helper, _ = _loop_body_from(src, "for (int step = s_lo; step < s_hi; ++step) {", end)
+    n_matrix = matrix.count("conv_tc(") * 8 + len(re.findall(r"\bTC_BARRIER_W\(\);", matrix)) + len(re.findall(r"\bTC_BARRIER\(\);", matrix))
+    assert matrix.count("conv_tc(") == 1
+    calls = re.findall(r"\bHBAR(?:_W)?\(\d+, \d+\);\s*//\s*(?:-+\s*)?([cE]_?\d?)", helper)
+    assert len(re.findall(r"\bHBAR(?:_W)?\(", helper)) == len(calls), "a helper barrier without a label comment"
+    assert calls == [f"c_{c}" for c in range(8)] + ["E"], calls
+    per_step_model = len(list(tk_schedule(3))) - len(list(tk_schedule(2)))
+    assert n_matrix == len(calls) == per_step_model == 9
+    assert "__syncthreads" not in matrix and "__syncthreads" not in helper      # a __syncthreads() would drain the weight loads in flight
+
+
+def _loop_body_from(src, head, start):
+    i = src.index(head, start)
+    depth, j = 0, src.index("{", i)
+    while True:
+        depth += {"{": 1, "}": -1}.get(src[j], 0)
+        if depth == 0:
+            return src[i:j + 1], j
+        j += 1
