@@ -195,6 +195,58 @@ __device__ TK_SLOW_ATTR void dirty_rows_fill(unsigned char* __restrict__ smem, u
     }
 }
 
+// The same for the prologue (all 512 threads, barriers allowed, the ring free as scratch): every window starts with ten such rows, and
+// the walk above - per row and tap a dependent chain bytes -> index -> table row - cost 31 k cycles per window.  Two phases: the
+// table row of every (listed row, tap) by one thread each into LDS, then every thread requests all table rows of its <= 4 listed
+// rows at once: two round trips instead of one per row and tap.  More than 16 listed rows (an N-rich first step): the walk above.
+constexpr int DIRTY_FAST_MAX = 16;
+__device__ __forceinline__ void dirty_rows_fill_prologue(unsigned char* __restrict__ smem, unsigned char* __restrict__ buf, int tb,
+                                                         const uint8_t* __restrict__ bases, const float* __restrict__ pt,
+                                                         const float* __restrict__ conv2_b, int tid) {
+    const int n = (int)dirty_count(smem);
+    if (n > DIRTY_FAST_MAX) {
+        dirty_rows_fill<512>(smem, buf, tb, bases, pt, conv2_b, tid);
+        return;
+    }
+    const unsigned char* drows = smem + DIRTY_OFF + 4;
+    uint32_t* idxs = reinterpret_cast<uint32_t*>(smem + VRING_OFF);          // [listed row][tap]: table row, ~0u = the tap adds nothing
+    if (tid < n * KS) {
+        const int i = tid / KS, j = tid - i * KS;
+        const int t = min(tb + drows[i], T - 1), p = t - CARRY + j;
+        uint32_t idx = ~0u;
+        if (t >= 0 && p >= 0) {
+            WvaBytes wb;
+            wva_fetch(wb, bases, p);
+            idx = wva_index(wb, p);
+        }
+        idxs[tid] = idx;
+    }
+    __syncthreads();
+    const int c = tid & (C - 1), q = tid >> 7;
+    float v[DIRTY_FAST_MAX / 4][KS];
+#pragma unroll
+    for (int k = 0; k < DIRTY_FAST_MAX / 4; ++k)
+#pragma unroll
+        for (int j = 0; j < KS; ++j) {
+            const int i = q + 4 * k;
+            const uint32_t idx = i < n ? idxs[i * KS + j] : ~0u;
+            v[k][j] = idx != ~0u ? pt[((size_t)j * WvaTable::ROWS + idx) * C + c] : 0.f;
+        }
+    const float b2 = conv2_b[c];
+#pragma unroll
+    for (int k = 0; k < DIRTY_FAST_MAX / 4; ++k) {
+        const int i = q + 4 * k;
+        if (i < n) {
+            const int r = drows[i];
+            float s = b2;
+#pragma unroll
+            for (int j = 0; j < KS; ++j) s += v[k][j];           // the order of dirty_rows_fill: b2 + tap 0 + tap 1 + ... (absent taps add 0)
+            s = vmax_raw(s, s * LRELU);
+            *reinterpret_cast<float*>(buf + r * ROWX + c * 4) = (tb + r) >= 0 ? s : 0.f;
+        }
+    }
+}
+
 // ---------------------------------------------------------------- x2 rows of a step: indices, requests, stores
 struct X2Rows {
     u32x2 v[X2_PER_WAVE];
@@ -308,7 +360,7 @@ __global__ __launch_bounds__(512, 2) void fused_front_tk_kernel(ArgsK a) {
             __syncthreads();
             GNN_TICK(6)
             if (dirty_count(smem)) {
-                dirty_rows_fill<512>(smem, buf, tb, bases, a.pt_tbl, a.conv2_b, tid);
+                dirty_rows_fill_prologue(smem, buf, tb, bases, a.pt_tbl, a.conv2_b, tid);
                 __syncthreads();
                 if (tid == 0) *reinterpret_cast<uint32_t*>(smem + DIRTY_OFF) = 0u;
             }
@@ -494,7 +546,9 @@ __global__ __launch_bounds__(512, 2) void fused_front_tk_kernel(ArgsK a) {
                 fetch(step + 1, more);                                           // head A's entry of the next step: its position, located behind E
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 HBAR(13, 8);                                                     // ---- E: x3 is in buf[s & 1]
-                TC_HPRIO_LOW();
+#ifdef TK_HPRIO_AFTER_E
+                __builtin_amdgcn_s_setprio(TK_HPRIO_AFTER_E);
+#endif
                 locate();
                 pass_compute(p0, jb, 0, hw, lane);
                 pass_compute(p1, jb, 1, hw, lane);
