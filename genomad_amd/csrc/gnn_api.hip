@@ -812,7 +812,7 @@ int gnn_build_kmer_tables(gnn_ctx* ctx, int64_t reserve_bytes) {
 }
 
 int gnn_has_kmer_tables(gnn_ctx* ctx) {
-    return ctx && ctx->w.tk_x2_tbl && ctx->w.tk_mpa_tbl && ctx->w.tk_pt_tbl && ctx->w.tk_yp_const ? 1 : 0;
+    return ctx && ctx->w.tk_x2_tbl && ctx->w.tk_mpa_tbl && ctx->w.tk_pt_tbl && ctx->w.tk_x1t_tbl && ctx->w.tk_yp_const ? 1 : 0;
 }
 
 int gnn_drop_kmer_tables(gnn_ctx* ctx) {

@@ -99,6 +99,7 @@ struct DeviceWeights {
     // (entry, 9-mer) (8.8 GB), that kernel's outputs of an all-N window.  Not in ctx->owned: gnn_drop_kmer_tables frees them
     float* tk_x2_tbl = nullptr;
     float* tk_mpa_tbl = nullptr;
+    float* tk_x1t_tbl = nullptr;    // x1 over WvaTable's index space (1.38 GB): head A's entries at 9-mers MpaTable has no column for
     float* tk_pt_tbl = nullptr;     // conv2's six tap tables over WvaTable's index space (8.3 GB): the rows the 14-mer table cannot index
     float* tk_yp_const = nullptr;
     float* tk_mp_const = nullptr;

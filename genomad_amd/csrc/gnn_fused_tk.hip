@@ -34,6 +34,7 @@
 //
 // 10 workgroup barriers per step instead of 18.  LDS: 2 x 53.3 KB + 48 KB ring + 3 KB of 2-bit codes = 159.6 KB.
 #include <chrono>
+#include <vector>
 #include <cstdio>
 
 #include "gnn_tc_dev.h"
@@ -57,7 +58,9 @@ constexpr int QUAD_OFF = VRING_OFF + VRING * VSLOT;
 constexpr int BIASK_OFF = QUAD_OFF + ((QUAD_N * 2 + 15) / 16) * 16;
 constexpr int DIRTY_OFF = BIASK_OFF + C * 4;        // [0] count, [1..] buffer rows no table holds
 constexpr int DIRTY_MAX = BUF_ROWS;
-constexpr int BKT_OFF = DIRTY_OFF + ((4 + DIRTY_MAX + 15) / 16) * 16;      // entry ranges per step of both heads: 2 x (STEPST + 1) ints
+constexpr int PIDX_N = 32;                          // per helper wave: WvaTable rows of the positions its 26 buffer rows' taps touch (5 + 26)
+constexpr int PIDX_OFF = DIRTY_OFF + ((4 + DIRTY_MAX + 15) / 16) * 16;
+constexpr int BKT_OFF = PIDX_OFF + 4 * PIDX_N * 4;  // entry ranges per step of both heads: 2 x (STEPST + 1) ints
 constexpr int LASTK_OFF = BKT_OFF + 2 * (STEPST + 1) * 4;
 constexpr int SMEMK = LASTK_OFF + 16;
 constexpr int X2_PER_WAVE = (BUF_ROWS + 3) / 4;     // 26 rows of the next step per helper wave (the last wave: 23)
@@ -75,7 +78,7 @@ struct ArgsK {
     const unsigned char* wva_tbl;     // WvaTable
     const float* x2_tbl;              // X2Table
     const float* mpa_tbl;             // MpaTable
-    const float* pairs6;              // conv1 pair tables (slow paths)
+    const float* x1t_tbl;             // x1 over WvaTable's index space (head A's entries MpaTable has no column for)
     const float* pt_tbl;              // conv2's tap tables over WvaTable's index space (rows the 14-mer table cannot index)
     const float* conv2_b;
     const float* weff_a;              // (8400, 128) f32, entry order (slow path)
@@ -132,35 +135,47 @@ __device__ __forceinline__ uint32_t x2_index(const uint16_t* __restrict__ quads,
     if (dirty == 0u) return code;
     return all_n_tokens<14>(dirty) ? X2_NN : (ROW_DIRTY | X2_NN);
 }
-// WvaTable row of the matrix wave's lane (lane l < 24 of wave hw: row 24 hw + l of the step), from the 2-bit codes; a lane whose
-// 9-mer is not all ACGT (or t < 5) makes the wave walk the bytes (wva_index: the side tables S5 / D5)
-__device__ __forceinline__ uint32_t wva_step_index_q(const uint16_t* __restrict__ quads, const uint8_t* __restrict__ bases, int t0, int hw, int lane) {
-    const int t = wva_row(t0, hw, lane);
+// WvaTable row of position t (wva_index of gnn_tc_dev.h: D4 | S5 | D5) from the 2-bit codes instead of the bytes: no memory round trip.
+// Digit of a base = its code, 4 when flagged; t < 5: the bases 0 .. t+3 in base 5; t >= 5: the 9-mer, dense when no base is flagged
+__device__ __forceinline__ uint32_t wva_index_q(const uint16_t* __restrict__ quads, int t) {
     uint32_t code, dirty;
     kmer_q<9>(quads, max(t - 5, 0), code, dirty);
-    uint32_t idx = code;
-    if (__builtin_amdgcn_ballot_w64(t < 5 || dirty != 0u)) {
-        WvaBytes b;
-        wva_fetch(b, bases, t);
-        idx = wva_index(b, t);
+    if (t >= 5 && dirty == 0u) return code;
+    const int np = min(t, 5) + 4;
+    uint32_t i5 = 0;
+#pragma unroll
+    for (int k = 0; k < 9; ++k) {
+        const uint32_t d = ((dirty >> (8 - k)) & 1u) ? 4u : (code >> (2 * (8 - k))) & 3u;
+        i5 = k < np ? i5 * 5u + d : i5;
     }
-    return idx;
+    return t < 5 ? WvaTable::s5_off(t) + i5 : WvaTable::D5_OFF + i5;
+}
+// WvaTable row of the matrix wave's lane (lane l < 24 of wave hw: row 24 hw + l of the step), from the 2-bit codes; a lane whose
+// 9-mer is not all ACGT (or t < 5) indexes the side tables S5 / D5
+__device__ __forceinline__ uint32_t wva_step_index_q(const uint16_t* __restrict__ quads, int t0, int hw, int lane) {
+    return wva_index_q(quads, wva_row(t0, hw, lane));
 }
 
 // ---------------------------------------------------------------- what the k-mer tables cannot index
-// head A's pair product of entry e at position u (igloo.py:192-204 folded): one lane, 128 channels
-__device__ TK_SLOW_ATTR float pair_a_slow(const uint8_t* __restrict__ bases, const float* __restrict__ pairs6, const float* __restrict__ weff_a, int e, int u) {
-    uint32_t r[3];
-#pragma unroll
-    for (int j = 0; j < 3; ++j) r[j] = pair_row(token_state(bases, u - 5 + 2 * j), token_state(bases, u - 4 + 2 * j));
-    float s = 0.f;
-    for (int k = 0; k < C; ++k) {
-        const int perm = ((k >> 2) & 3) * 32 + (k >> 4) * 4 + (k & 3);
-        const float v = pairs6[((size_t)0 * PAIR_ROWS + r[0]) * C + perm] + pairs6[((size_t)1 * PAIR_ROWS + r[1]) * C + perm] +
-                        pairs6[((size_t)2 * PAIR_ROWS + r[2]) * C + perm];
-        s = fmaf(vmax_raw(v, v * LRELU), weff_a[(size_t)e * C + k], s);
+// head A's pair product of entry e at position u (igloo.py:192-204 folded) when MpaTable has no column for the 9-mer (a non-ACGT byte
+// among the nine, or u < 5): the x1 row of that position - a row of X1T, x1 over WvaTable's index space - times the entry's folded
+// weights, one lane, 128 channels, four accumulators
+__device__ TK_SLOW_ATTR float pair_a_slow(const uint16_t* __restrict__ quads, const float* __restrict__ x1t, const float* __restrict__ weff_a, int e, int u) {
+#ifdef TK_ABL_NOSLOWA
+    return 0.f;
+#endif
+    const float4* x = reinterpret_cast<const float4*>(x1t + (size_t)wva_index_q(quads, u) * C);
+    const float4* w = reinterpret_cast<const float4*>(weff_a + (size_t)e * C);
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+#pragma unroll 8
+    for (int i = 0; i < C / 4; ++i) {
+        const float4 xv = x[i], wv = w[i];
+        s0 = fmaf(xv.x, wv.x, s0);
+        s1 = fmaf(xv.y, wv.y, s1);
+        s2 = fmaf(xv.z, wv.z, s2);
+        s3 = fmaf(xv.w, wv.w, s3);
     }
-    return s;
+    return (s0 + s2) + (s1 + s3);
 }
 // The rows of buffer `buf` (row r = position tb + r) that the list in LDS names: x2[t] = LeakyReLU(b2 + sum_j W2[j]^T x1[t-5+j])
 // (igloo.py:65-67) as the sum of <= 6 rows of the tap tables PT[j][row of x1[t-5+j] in WvaTable's index space] (f32; the taps whose
@@ -169,29 +184,44 @@ __device__ TK_SLOW_ATTR float pair_a_slow(const uint8_t* __restrict__ bases, con
 __device__ __forceinline__ uint32_t dirty_count(const unsigned char* __restrict__ smem) {
     return *reinterpret_cast<const volatile uint32_t*>(smem + DIRTY_OFF);
 }
-template <int NT>
-__device__ TK_SLOW_ATTR void dirty_rows_fill(unsigned char* __restrict__ smem, unsigned char* __restrict__ buf, int tb, const uint8_t* __restrict__ bases,
+template <int NT, bool PIDX>
+__device__ TK_SLOW_ATTR void dirty_rows_fill(unsigned char* __restrict__ smem, unsigned char* __restrict__ buf, int tb, const uint16_t* __restrict__ quads,
                                              const float* __restrict__ pt, const float* __restrict__ conv2_b, int tid) {
     const int n = (int)dirty_count(smem);
     const unsigned char* drows = smem + DIRTY_OFF + 4;
     const int c = tid & (C - 1);
-    for (int i = tid >> 7; i < n; i += NT / 128) {
-        const int r = drows[i], t = min(tb + r, T - 1);
-        float v = 0.f;
-        if (t >= 0) {
-            v = conv2_b[c];
+    const float b2 = conv2_b[c];
+    // four listed rows per thread and pass: 24 table rows requested before the first is used (a window with scattered non-ACGT bytes
+    // lists dozens of rows per step; one round trip per row made such windows 7x slower than the default kernel, this way 2x)
+    constexpr int G = NT / 128, U = 4;
+    for (int i0 = tid >> 7; i0 < n; i0 += G * U) {
+        float v[U][KS];
+        int rr[U], tt[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int i = min(i0 + u * G, n - 1);
+            rr[u] = drows[i];
+            tt[u] = min(tb + rr[u], T - 1);
 #pragma unroll
             for (int j = 0; j < KS; ++j) {
-                const int p = t - CARRY + j;
-                if (p >= 0) {
-                    WvaBytes wb;
-                    wva_fetch(wb, bases, p);
-                    v += pt[((size_t)j * WvaTable::ROWS + wva_index(wb, p)) * C + c];
-                }
+                const int p = tt[u] - CARRY + j;
+                // PIDX (the step loop): buffer row r of helper wave r / 26 -> its position list, entry r - 26 (r / 26) + j
+                const uint32_t row = PIDX ? reinterpret_cast<const uint32_t*>(smem + PIDX_OFF)[(rr[u] / X2_PER_WAVE) * PIDX_N + rr[u] % X2_PER_WAVE + j]
+                                          : wva_index_q(quads, max(p, 0));
+                v[u][j] = pt[((size_t)j * WvaTable::ROWS + row) * C + c];
+                v[u][j] = p >= 0 ? v[u][j] : 0.f;
             }
-            v = vmax_raw(v, v * LRELU);
         }
-        *reinterpret_cast<float*>(buf + r * ROWX + c * 4) = v;
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            if (i0 + u * G < n) {
+                float s = b2;
+#pragma unroll
+                for (int j = 0; j < KS; ++j) s += v[u][j];
+                s = vmax_raw(s, s * LRELU);
+                *reinterpret_cast<float*>(buf + rr[u] * ROWX + c * 4) = tt[u] >= 0 ? s : 0.f;
+            }
+        }
     }
 }
 
@@ -201,11 +231,11 @@ __device__ TK_SLOW_ATTR void dirty_rows_fill(unsigned char* __restrict__ smem, u
 // rows at once: two round trips instead of one per row and tap.  More than 16 listed rows (an N-rich first step): the walk above.
 constexpr int DIRTY_FAST_MAX = 16;
 __device__ __forceinline__ void dirty_rows_fill_prologue(unsigned char* __restrict__ smem, unsigned char* __restrict__ buf, int tb,
-                                                         const uint8_t* __restrict__ bases, const float* __restrict__ pt,
+                                                         const uint16_t* __restrict__ quads, const float* __restrict__ pt,
                                                          const float* __restrict__ conv2_b, int tid) {
     const int n = (int)dirty_count(smem);
     if (n > DIRTY_FAST_MAX) {
-        dirty_rows_fill<512>(smem, buf, tb, bases, pt, conv2_b, tid);
+        dirty_rows_fill<512, false>(smem, buf, tb, quads, pt, conv2_b, tid);
         return;
     }
     const unsigned char* drows = smem + DIRTY_OFF + 4;
@@ -213,13 +243,7 @@ __device__ __forceinline__ void dirty_rows_fill_prologue(unsigned char* __restri
     if (tid < n * KS) {
         const int i = tid / KS, j = tid - i * KS;
         const int t = min(tb + drows[i], T - 1), p = t - CARRY + j;
-        uint32_t idx = ~0u;
-        if (t >= 0 && p >= 0) {
-            WvaBytes wb;
-            wva_fetch(wb, bases, p);
-            idx = wva_index(wb, p);
-        }
-        idxs[tid] = idx;
+        idxs[tid] = (t >= 0 && p >= 0) ? wva_index_q(quads, p) : ~0u;
     }
     __syncthreads();
     const int c = tid & (C - 1), q = tid >> 7;
@@ -257,11 +281,16 @@ struct X2Rows {
 __device__ __forceinline__ uint32_t x2_rows_index(unsigned char* __restrict__ smem, const uint16_t* __restrict__ quads, int tb, int w, int lane, bool list) {
     const int r = min(X2_PER_WAVE * w + min(lane, X2_PER_WAVE - 1), BUF_ROWS - 1);
     const uint32_t idx = x2_index(quads, tb + r);
-    if (list && (idx & ROW_DIRTY) && lane < X2_PER_WAVE && X2_PER_WAVE * w + lane < BUF_ROWS) {
+    const bool mine = list && (idx & ROW_DIRTY) && lane < X2_PER_WAVE && X2_PER_WAVE * w + lane < BUF_ROWS;
+    if (mine) {
         uint32_t* dl = reinterpret_cast<uint32_t*>(smem + DIRTY_OFF);
         const uint32_t slot = atomicAdd(dl, 1u);
         smem[DIRTY_OFF + 4 + slot] = (unsigned char)r;
     }
+    // a wave that lists a row leaves the WvaTable rows of the 31 positions its rows' taps touch in LDS (lane l: position tb + 26 w - 5 + l):
+    // the fill behind c_6 then costs one LDS read per (row, tap) instead of 60 integer instructions
+    if (__builtin_amdgcn_ballot_w64(mine) && lane < PIDX_N - 1)
+        reinterpret_cast<uint32_t*>(smem + PIDX_OFF)[w * PIDX_N + lane] = wva_index_q(quads, min(max(tb + X2_PER_WAVE * w - CARRY + lane, 0), T - 1));
     return idx;
 }
 template <int I0, int I1>
@@ -360,7 +389,7 @@ __global__ __launch_bounds__(512, 2) void fused_front_tk_kernel(ArgsK a) {
             __syncthreads();
             GNN_TICK(6)
             if (dirty_count(smem)) {
-                dirty_rows_fill_prologue(smem, buf, tb, bases, a.pt_tbl, a.conv2_b, tid);
+                dirty_rows_fill_prologue(smem, buf, tb, quads, a.pt_tbl, a.conv2_b, tid);
                 __syncthreads();
                 if (tid == 0) *reinterpret_cast<uint32_t*>(smem + DIRTY_OFF) = 0u;
             }
@@ -378,7 +407,7 @@ __global__ __launch_bounds__(512, 2) void fused_front_tk_kernel(ArgsK a) {
             prime_tc(ring, cw, 0, lane);
             {                                                                    // head A's rows of the first step: nothing to hide their round trip behind
                 WvaRows w0;
-                wva_issue(w0, tblr, wva_step_index_q(quads, bases, s_lo * FTT, hw, lane), lane);
+                wva_issue(w0, tblr, wva_step_index_q(quads, s_lo * FTT, hw, lane), lane);
                 wva_pool_store(w0, yp_w, s_lo * FTT, hw, lane);
             }
             {                                                                    // V3 chunk 1 of the first step (the helpers make chunk 0)
@@ -387,7 +416,7 @@ __global__ __launch_bounds__(512, 2) void fused_front_tk_kernel(ArgsK a) {
                 load_rows(rm, h0, 1);
                 transform_store(rm, h0, 1);
             }
-            uint32_t wva_next = wva_step_index_q(quads, bases, (s_lo + 1) * FTT, hw, lane);
+            uint32_t wva_next = wva_step_index_q(quads, (s_lo + 1) * FTT, hw, lane);
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             GNN_TICK(6)
 #pragma unroll 1
@@ -426,7 +455,7 @@ __global__ __launch_bounds__(512, 2) void fused_front_tk_kernel(ArgsK a) {
                         transform_store(rm, hn, 1);
                         wva_pool_store(wr, yp_w, t0 + FTT, hw, lane);
                     }
-                    wva_next = wva_step_index_q(quads, bases, t0 + 2 * FTT, hw, lane);
+                    wva_next = wva_step_index_q(quads, t0 + 2 * FTT, hw, lane);
                     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");           // chunk 1's fragments have landed before c_0 releases the readers
                     GNN_TICK(4)
                 }
@@ -528,7 +557,7 @@ __global__ __launch_bounds__(512, 2) void fused_front_tk_kernel(ArgsK a) {
                 HBAR_W(11, 8);                                                   // c_6: V3 is complete, buf[(s+1) & 1] (x3(s-1)) is dead
                 x2_rows_store(xr, smem + yoff, my_row, hw, lane);
                 if (more && dirty_count(smem)) {                                 // rows the 14-mer table cannot index (the list is the next step's)
-                    dirty_rows_fill<256>(smem, smem + yoff, t0 + FTT - CARRY, bases, a.pt_tbl, a.conv2_b, ht);
+                    dirty_rows_fill<256, true>(smem, smem + yoff, t0 + FTT - CARRY, quads, a.pt_tbl, a.conv2_b, ht);
                 }
                 HBAR_W(12, 8);                                                   // c_7: x2(s+1) is in buf[(s+1) & 1]
 #ifndef TK_HPRIO_LATE
@@ -553,14 +582,14 @@ __global__ __launch_bounds__(512, 2) void fused_front_tk_kernel(ArgsK a) {
                 pass_compute(p0, jb, 0, hw, lane);
                 pass_compute(p1, jb, 1, hw, lane);
                 if (cur.ea < cur.ea_end) {
-                    if (va_slow) va = pair_a_slow(bases, a.pairs6, a.weff_a, cur.ea, cur.ua);
+                    if (va_slow) va = pair_a_slow(quads, a.x1t_tbl, a.weff_a, cur.ea, cur.ua);
                     mp_w[0][cur.ea] = va;
                     for (int e = cur.ea + 256; e < cur.ea_end; e += 256) {       // a crowded step (more than 256 entries; rare)
                         const int u = a.pos_sorted[0][e];
                         uint32_t code, dirty;
                         kmer_q<9>(quads, max(u - 5, 0), code, dirty);
                         const bool nn = all_n_tokens<9>(dirty);
-                        mp_w[0][e] = (u < 5 || (dirty != 0u && !nn)) ? pair_a_slow(bases, a.pairs6, a.weff_a, e, u)
+                        mp_w[0][e] = (u < 5 || (dirty != 0u && !nn)) ? pair_a_slow(quads, a.x1t_tbl, a.weff_a, e, u)
                                                                       : a.mpa_tbl[(size_t)e * K9_ROWS + (dirty == 0u ? code : K9_NN)];
                     }
                 }
@@ -706,7 +735,7 @@ static void fill_args(const gnn_ctx* ctx, ArgsK& a, const uint8_t* bases) {
     a.wva_tbl = reinterpret_cast<const unsigned char*>(d.tc_wva_tbl);
     a.x2_tbl = d.tk_x2_tbl;
     a.mpa_tbl = d.tk_mpa_tbl;
-    a.pairs6 = d.conv1_pairs6;
+    a.x1t_tbl = d.tk_x1t_tbl;
     a.pt_tbl = d.tk_pt_tbl;
     a.conv2_b = d.conv_b[0];
     a.weff_a = d.weff_sorted[0];
@@ -723,12 +752,12 @@ static void launch(const ArgsK& a, bool prof, unsigned nwin, hipStream_t stream)
 }  // namespace tk
 
 size_t kmer_tables_bytes() {
-    return (size_t)tk::X2_ROWS * C * 4 + (size_t)NPAIR * tk::K9_ROWS * 4 + (size_t)KS * tc::WvaTable::ROWS * C * 4;
+    return (size_t)tk::X2_ROWS * C * 4 + (size_t)NPAIR * tk::K9_ROWS * 4 + (size_t)(KS + 1) * tc::WvaTable::ROWS * C * 4;
 }
 
 void free_kmer_tables(gnn_ctx* ctx) {
     DeviceWeights& d = ctx->w;
-    for (float** p : {&d.tk_x2_tbl, &d.tk_mpa_tbl, &d.tk_pt_tbl, &d.tk_yp_const, &d.tk_mp_const}) {
+    for (float** p : {&d.tk_x2_tbl, &d.tk_mpa_tbl, &d.tk_pt_tbl, &d.tk_x1t_tbl, &d.tk_yp_const, &d.tk_mp_const}) {
         if (*p) (void)hipFree(*p);
         *p = nullptr;
     }
@@ -738,23 +767,23 @@ void free_kmer_tables(gnn_ctx* ctx) {
 int build_kmer_tables(gnn_ctx* ctx, size_t reserve) {
     using namespace tk;
     DeviceWeights& d = ctx->w;
-    if (d.tk_x2_tbl && d.tk_mpa_tbl && d.tk_pt_tbl && d.tk_yp_const) return GNN_OK;
+    if (d.tk_x2_tbl && d.tk_mpa_tbl && d.tk_pt_tbl && d.tk_x1t_tbl && d.tk_yp_const) return GNN_OK;
     free_kmer_tables(ctx);
     const size_t x2_b = (size_t)X2_ROWS * C * 4, mpa_b = (size_t)NPAIR * K9_ROWS * 4;
     const size_t x1_b = (size_t)K9_ROWS * C * 4, p_b = (size_t)KS * K9_ROWS * C * 8;
     size_t free_b = 0, total_b = 0;
     GNN_HIP(hipMemGetInfo(&free_b, &total_b));
-    const size_t pt_b = (size_t)KS * WvaTable::ROWS * C * 4;
-    const size_t need = x2_b + mpa_b + pt_b + x1_b + p_b + reserve;
+    const size_t pt_b = (size_t)KS * WvaTable::ROWS * C * 4, x1t_b = (size_t)WvaTable::ROWS * C * 4;
+    const size_t need = x2_b + mpa_b + pt_b + x1t_b + x1_b + p_b + reserve;
     if (free_b < need) {
         set_error("k-mer tables: " + std::to_string(need >> 30) + " GiB needed (" + std::to_string((x2_b + mpa_b) >> 30) + " GiB of tables, the rest workspace reserve), " +
                   std::to_string(free_b >> 30) + " GiB free on the device: GNN_PREC_F16X3TC keeps serving");
         return GNN_ERR_NOMEM;
     }
-    void *x1 = nullptr, *P = nullptr, *x2 = nullptr, *mpa = nullptr, *pt = nullptr;
+    void *x1 = nullptr, *P = nullptr, *x2 = nullptr, *mpa = nullptr, *pt = nullptr, *x1t = nullptr, *eye = nullptr;
     auto fail = [&](hipError_t e, const char* what) {
         (void)hipGetLastError();
-        for (void* p : {x1, P, x2, mpa, pt})
+        for (void* p : {x1, P, x2, mpa, pt, x1t, eye})
             if (p) (void)hipFree(p);
         set_error(std::string("k-mer tables: ") + what + " failed: " + hipGetErrorString(e));
         return e == hipErrorOutOfMemory ? GNN_ERR_NOMEM : GNN_ERR_HIP;
@@ -775,7 +804,15 @@ int build_kmer_tables(gnn_ctx* ctx, size_t reserve) {
     if ((e = hipMalloc(&mpa, mpa_b)) != hipSuccess) return fail(e, "hipMalloc of head A's pair-product table");
     if ((e = hipMalloc(&x1, x1_b)) != hipSuccess) return fail(e, "hipMalloc of the 9-mer x1 table");
     if ((e = hipMalloc(&pt, pt_b)) != hipSuccess) return fail(e, "hipMalloc of conv2's tap tables");
+    if ((e = hipMalloc(&x1t, x1t_b)) != hipSuccess) return fail(e, "hipMalloc of the x1 table");
+    if ((e = hipMalloc(&eye, (size_t)C * C * 4)) != hipSuccess) return fail(e, "hipMalloc of the identity");
     if ((e = hipMalloc(&P, p_b)) != hipSuccess) return fail(e, "hipMalloc of the f64 tap tables");
+    {   // x1 over WvaTable's index space = the same builder with the identity as the matrix (products with 0 and 1, summed in f64: exact)
+        std::vector<float> id((size_t)C * C, 0.f);
+        for (int k = 0; k < C; ++k) id[(size_t)k * C + k] = 1.f;
+        if ((e = hipMemcpy(eye, id.data(), id.size() * 4, hipMemcpyHostToDevice)) != hipSuccess) return fail(e, "upload of the identity");
+        if (build_wva_rows_table(ctx, static_cast<const float*>(eye), static_cast<float*>(x1t))) return fail(hipGetLastError(), "launch of the x1 table build");
+    }
     lap("hipMalloc of the other four");
     for (int j = 0; j < KS; ++j)
         if (build_wva_rows_table(ctx, d.conv_k[0] + (size_t)j * C * C, static_cast<float*>(pt) + (size_t)j * WvaTable::ROWS * C)) return fail(hipGetLastError(), "launch of a tap-table build");
@@ -797,10 +834,12 @@ int build_kmer_tables(gnn_ctx* ctx, size_t reserve) {
     lap("head A's pair products (8.8 GB)");
     (void)hipFree(x1);
     (void)hipFree(P);
-    x1 = P = nullptr;
+    (void)hipFree(eye);
+    x1 = P = eye = nullptr;
     d.tk_x2_tbl = static_cast<float*>(x2);
     d.tk_mpa_tbl = static_cast<float*>(mpa);
     d.tk_pt_tbl = static_cast<float*>(pt);
+    d.tk_x1t_tbl = static_cast<float*>(x1t);
     // the all-N window's outputs, computed once by the kernel itself (padding skip)
     void *bn = nullptr, *yc = nullptr, *mc = nullptr;
     if ((e = hipMalloc(&bn, W)) != hipSuccess || (e = hipMalloc(&yc, (size_t)2 * POOLED * C * sizeof(float))) != hipSuccess ||
@@ -808,7 +847,7 @@ int build_kmer_tables(gnn_ctx* ctx, size_t reserve) {
         for (void* p : {bn, yc, mc})
             if (p) (void)hipFree(p);
         free_kmer_tables(ctx);
-        x2 = mpa = pt = nullptr;
+        x2 = mpa = pt = x1t = nullptr;
         return fail(e, "hipMalloc of the all-N window's outputs");
     }
     (void)hipMemsetAsync(bn, 'N', W, st);
@@ -826,7 +865,7 @@ int build_kmer_tables(gnn_ctx* ctx, size_t reserve) {
     d.tk_mp_const = static_cast<float*>(mc);
     if (e != hipSuccess) {
         free_kmer_tables(ctx);
-        x2 = mpa = pt = nullptr;
+        x2 = mpa = pt = x1t = nullptr;
         return fail(e, "the all-N window's launch");
     }
     return GNN_OK;
