@@ -211,14 +211,17 @@ def front_roofline(precision, windows_per_launch, avg_ms, launches, front_ms, ba
     tk_bytes = {"x2_rows_14mer_table": 63 * 101 * 512, "wva_rows_9mer_table": 5992 * 512, "pair_products_a": 8400 * 4, "bases": 6000, "scores": 12}
     if tk:
         alg = int(sum(tk_bytes.values()) * windows_per_launch)
+    elif precision == "f16x3tc":                       # since round 6 head A's y @ w_v rows are read from the 9-mer table: 5 992 rows x 512 B per window
+        alg = int((6012 + tk_bytes["wva_rows_9mer_table"]) * windows_per_launch)
     r = {
         "bound": "mfma", "achieved": round(tflops, 2), "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
         "frac": round(tflops / MFMA_PEAK_TFLOPS, 4), "traffic": traffic, "traffic_source": source,
         "algorithmic_bytes_per_launch": alg,
         "traffic_over_algorithmic": round(traffic / alg, 1) if traffic and alg else None,
-        "traffic_note": "HBM is not the bound (traffic / launch time = 3 % of 8 TB/s); the excess over the algorithmic bytes is the f32 spill of the "
-                        "pooled y @ w_v rows (767 KB/window) and pair products (67 KB/window) from the front end to the back end, written once and "
-                        "read once: the softmax over the 749 pooled positions needs all of a window's 2 100 patches first (DESIGN.md section 3)",
+        "traffic_note": "HBM is not the bound; algorithmic bytes = bases + scores (6 012 B) + for f16x3tc the 5 992 rows of head A's 9-mer table a window "
+                        "gathers (3.07 MB); the excess is the f32 spill of the pooled y @ w_v rows (767 KB/window) and pair products (67 KB/window) from "
+                        "the front end to the back end, written once and read once (the softmax over the 749 pooled positions needs all of a window's "
+                        "2 100 patches first, DESIGN.md section 3), and for f16x3tc the conv1 pair tables and folded IGLOO weights that miss the L2",
         "kernel": FRONT_KERNEL[precision],
         "flop_per_launch": int(FLOP_PER_WINDOW * windows_per_launch), "avg_launch_ms": round(avg_ms, 4),
         "launches": int(launches), "mfma_passes": MFMA_PASSES.get(precision),
