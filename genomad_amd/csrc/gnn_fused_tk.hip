@@ -7,6 +7,8 @@
 //   X2Table   4^14 + 1 rows x 128 f32 = 137.4 GB   x2[t] per 14-mer (row 4^14: every token of the 14 bases is the N token)
 //   MpaTable  8400 x (4^9 + 1) f32    =   8.8 GB   head A's pair product of entry e (igloo.py:192-204 folded) per 9-mer at pos[e]
 //   WvaTable  (gnn_tc_dev.h)          =   1.4 GB   head A's y @ w_v row per 9-mer
+//   PT        6 x 2.7 M rows x 128 f32 =  8.3 GB   conv2's tap j applied to x1 of every row of WvaTable's index space (rows no 14-mer indexes)
+//   X1T       2.7 M rows x 128 f32   =   1.4 GB   x1 over the same index space (head A's entries MpaTable has no column for)
 //
 // conv2 - 43 % of a window's FLOPs, half of the default kernel's MFMAs, weight stream, input transforms and barriers - becomes ONE
 // 512-byte row gather per position (3.1 MB per window; scripts/probe_gather_big.hip: the memory system delivers such rows from a
@@ -16,32 +18,41 @@
 // three f16 products they replace) by gnn_build_kmer_tables() when the device has the memory; otherwise the library keeps serving
 // GNN_PREC_F16X3TC.
 //
-// What a k-mer table cannot index is computed in place, in f32, by the whole workgroup (dirty_rows_pass / pair_a_slow): the first
-// ten positions of a window (tokens before the window start are absent, not N) and k-mers that mix ACGT with other bytes.  A k-mer
-// in which every 4-mer holds a non-ACGT byte (all its tokens are the N token: N runs, the padding of a contig's last window) has
-// its own row.  These are a dozen rows per window start and per N-run edge.
+// What no dense k-mer index covers - the first ten positions of a window (tokens before the window start are absent, not N), k-mers
+// that mix ACGT with other bytes - is summed from conv2's six TAP TABLES over WvaTable's index space (PT[j][row of x1[t-5+j]], 8.3 GB:
+// <= 6 row reads per such position, dirty_rows_fill), head A's entries at such 9-mers are a dot product of a row of X1T (x1 over the
+// same index space, 1.4 GB) with the entry's weights (pair_a_slow).  A k-mer in which every 4-mer holds a non-ACGT byte (all its
+// tokens are the N token: N runs, the padding of a contig's last window) has its own row.  Every index comes from the window's 2-bit
+// codes in LDS, built once per window.
 //
 // Structure (one workgroup = one window, 4 matrix waves + 4 helper waves, steps of 96 rows, the ring of 3 x 16 KB of transformed
 // activations - all as gnn_fused_tc.hip): two row buffers P, Q of 101 rows x 528 B alternate; step s finds x2(s) (rows t0-5 ..
 // t0+95: the five carry rows are gathered again instead of being carried) in buf[s & 1], the conv3 epilogue overwrites it with x3(s)
 // (hi | lo planes), and x2(s+1) lands in the other buffer, whose x3(s-1) is dead by then:
 //
-//   matrix : [c0 it0 | ... | c7 it7] conv3 -> inverse transform -> x3 -> buf[s&1] | E | head A's 24 table rows per wave of step s+1
-//            requested, w_v B(s), pooled -> yp B | F | V3(s+1) chunk 1, 8-row max of the table rows -> yp A
-//   helpers: beside units 0..5: V3 chunks 2..7; c6: row indices of x2(s+1) from the window's 2-bit codes, 26 rows per wave requested
-//            (registers), head A's pair products read from MpaTable; c7: head B's weights requested | E | head B's passes 0, 1,
-//            x2(s+1) rows -> buf[(s+1)&1] | F | (rows no table holds: dirty_rows_pass, all waves) V3(s+1) chunk 0, head B's last pass
+//   matrix : [c0 u0 | ... | c7 u7] conv3 -> inverse transform -> x3 -> buf[s&1] | E | head A's 24 table rows per wave of step s+1
+//            requested, w_v B(s), pooled -> yp B, V3(s+1) chunk 1, 8-row max of the table rows -> yp A
+//   helpers: top of the step: the 26 X2Table rows per wave of step s+1 requested in one burst (registers), behind them head A's
+//            MpaTable read | beside units 0..5: V3 chunks 2..7 | c6: rows -> buf[(s+1)&1], rows no 14-mer indexes from the tap tables |
+//            c7: V3(s+1) chunk 0, head B's three passes of weights and head A's next entry requested | E | next entry located, head B's
+//            pair products, head A's product stored
+//   (tests/test_kernel_schedule.py::tk_schedule is an executable model of this schedule)
 //
-// 10 workgroup barriers per step instead of 18.  LDS: 2 x 53.3 KB + 48 KB ring + 3 KB of 2-bit codes = 159.6 KB.
+// 9 workgroup barriers per step instead of 18.  Two rules shaped the helpers' side (DESIGN.md section 4.0 has the A/Bs): a wave's
+// loads return IN ORDER, and the compiler waits with vmcnt(0) for any load it issued under a condition - so the burst of row
+// requests sits where nothing is pending in front of it and nothing requested behind it is needed before the rows are.
+// LDS: 2 x 53.3 KB + 48 KB ring + 3 KB of 2-bit codes + small lists = 160.5 KB.
+//
+// Compile-time switches: -DTC_JITTER only (libgenomad_nn_hip_jitter.so, a test build).  The measurement variants behind
+// profiles/r06/tk_first/ (TK_ABL_NOX2LOAD, TK_ABL_SMALLTBL, TK_ABL_NOMPA, TK_X2_TRICKLE, TK_HPRIO_*, ...) are those of commit 75dfcae;
+// they were removed from this file afterwards (the device code did not change by a byte).
 #include <chrono>
 #include <vector>
 #include <cstdio>
 
 #include "gnn_tc_dev.h"
 
-#ifndef TK_SLOW_ATTR
-#define TK_SLOW_ATTR __noinline__
-#endif
+#define __noinline__ __noinline__
 
 namespace gnn {
 namespace tk {
@@ -160,10 +171,7 @@ __device__ __forceinline__ uint32_t wva_step_index_q(const uint16_t* __restrict_
 // head A's pair product of entry e at position u (igloo.py:192-204 folded) when MpaTable has no column for the 9-mer (a non-ACGT byte
 // among the nine, or u < 5): the x1 row of that position - a row of X1T, x1 over WvaTable's index space - times the entry's folded
 // weights, one lane, 128 channels, four accumulators
-__device__ TK_SLOW_ATTR float pair_a_slow(const uint16_t* __restrict__ quads, const float* __restrict__ x1t, const float* __restrict__ weff_a, int e, int u) {
-#ifdef TK_ABL_NOSLOWA
-    return 0.f;
-#endif
+__device__ __noinline__ float pair_a_slow(const uint16_t* __restrict__ quads, const float* __restrict__ x1t, const float* __restrict__ weff_a, int e, int u) {
     const float4* x = reinterpret_cast<const float4*>(x1t + (size_t)wva_index_q(quads, u) * C);
     const float4* w = reinterpret_cast<const float4*>(weff_a + (size_t)e * C);
     float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
@@ -185,7 +193,7 @@ __device__ __forceinline__ uint32_t dirty_count(const unsigned char* __restrict_
     return *reinterpret_cast<const volatile uint32_t*>(smem + DIRTY_OFF);
 }
 template <int NT, bool PIDX>
-__device__ TK_SLOW_ATTR void dirty_rows_fill(unsigned char* __restrict__ smem, unsigned char* __restrict__ buf, int tb, const uint16_t* __restrict__ quads,
+__device__ __noinline__ void dirty_rows_fill(unsigned char* __restrict__ smem, unsigned char* __restrict__ buf, int tb, const uint16_t* __restrict__ quads,
                                              const float* __restrict__ pt, const float* __restrict__ conv2_b, int tid) {
     const int n = (int)dirty_count(smem);
     const unsigned char* drows = smem + DIRTY_OFF + 4;
@@ -297,17 +305,9 @@ template <int I0, int I1>
 __device__ __forceinline__ void x2_rows_issue(X2Rows& x, const float* __restrict__ tbl, uint32_t my_row, int lane) {
 #pragma unroll
     for (int i = I0; i < I1; ++i) {
-#ifdef TK_ABL_SMALLTBL      // measurement: the same requests against TK_ABL_SMALLTBL rows of the table (wrong results)
-        const uint32_t row = __builtin_amdgcn_readlane(my_row, i) & (TK_ABL_SMALLTBL - 1u);
-#else
         const uint32_t row = __builtin_amdgcn_readlane(my_row, i) & ~ROW_DIRTY;
-#endif
         const unsigned char* p = reinterpret_cast<const unsigned char*>(tbl) + (size_t)row * (C * 4);      // wave-uniform 64-bit base
-#ifdef TK_ABL_NOX2LOAD
-        x.v[i] = u32x2{row, (uint32_t)(uintptr_t)p};
-#else
         x.v[i] = *reinterpret_cast<const u32x2*>(p + lane * 8);                                           // 64 lanes x 8 B = one row
-#endif
     }
 }
 __device__ __forceinline__ void x2_rows_store(const X2Rows& x, unsigned char* __restrict__ buf, uint32_t my_row, int w, int lane) {
@@ -524,17 +524,10 @@ __global__ __launch_bounds__(512, 2) void fused_front_tk_kernel(ArgsK a) {
                 const float* va_ptr = nxt_ptr;
                 X2Rows xr;
                 const uint32_t my_row = x2_rows_index(smem, quads, t0 + FTT - CARRY, hw, lane, more);
-#ifdef TK_WAIT_BEFORE_ROWS
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#endif
                 GNN_REGION_END();
                 x2_rows_issue<0, X2_PER_WAVE>(xr, a.x2_tbl, my_row, lane);
                 GNN_REGION_END();
-#ifdef TK_ABL_NOMPA
-                va = 0.f;
-#else
                 va = cur.ea < cur.ea_end ? *va_ptr : 0.f;
-#endif
                 GNN_TICK(14)
                 TC_HPRIO_HIGH();
                 HBAR_W(15, 8);                                                   // c_0
@@ -560,9 +553,7 @@ __global__ __launch_bounds__(512, 2) void fused_front_tk_kernel(ArgsK a) {
                     dirty_rows_fill<256, true>(smem, smem + yoff, t0 + FTT - CARRY, quads, a.pt_tbl, a.conv2_b, ht);
                 }
                 HBAR_W(12, 8);                                                   // c_7: x2(s+1) is in buf[(s+1) & 1]
-#ifndef TK_HPRIO_LATE
                 TC_HPRIO_LOW();                                                  // the matrix waves' last unit and epilogue are the critical path now
-#endif
                 if (ht == 0) *reinterpret_cast<volatile uint32_t*>(smem + DIRTY_OFF) = 0u;
                 if (more) {                                                      // V3(s+1) chunk 0 (ring slot 0: chunk 6 was read in front of c_7)
                     load_rows(ra, hy, 0);
@@ -575,9 +566,6 @@ __global__ __launch_bounds__(512, 2) void fused_front_tk_kernel(ArgsK a) {
                 fetch(step + 1, more);                                           // head A's entry of the next step: its position, located behind E
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 HBAR(13, 8);                                                     // ---- E: x3 is in buf[s & 1]
-#ifdef TK_HPRIO_AFTER_E
-                __builtin_amdgcn_s_setprio(TK_HPRIO_AFTER_E);
-#endif
                 locate();
                 pass_compute(p0, jb, 0, hw, lane);
                 pass_compute(p1, jb, 1, hw, lane);
