@@ -622,7 +622,7 @@ def main():
     ap.add_argument("--chunk", type=int, default=16384, help="windows per launch of the fused kernel (183.9 k windows/s against 180.3 k with "
                     "launches of 4096 on one box - the launch's tail is amortised over 64 instead of 16 rounds of workgroups per CU)")
     ap.add_argument("--precision", default="auto", choices=["auto", "f16c6", "f16x3", "f16x3tc", "f16x3tk", "bf16x3", "f32"],
-                    help=f"arithmetic of the fused front end (default auto: f16x3tk when every rank's device can hold the k-mer tables - 146 GB "
+                    help=f"arithmetic of the fused front end (default auto: f16x3tk when every rank's device can hold the k-mer tables - 156 GB "
                          f"built in 1.5 .. 6 s, outside the timed region - else {DEFAULT_PRECISION}; both have margin inside the 1e-4 tolerance; "
                          "f16c6 is faster than f16x3tc and exceeds it on a few of 10^6 windows)")
     ap.add_argument("--no-kmer-tables", action="store_true", help="--precision auto: do not build the k-mer tables (measure f16x3tc)")
@@ -725,13 +725,14 @@ def main():
             built = bool(eng.build_kmer_tables())
         all_built = comm.allreduce_max(0.0 if built else 1.0) == 0.0
         if args.precision == "f16x3tk" and not all_built:
-            raise RuntimeError("--precision f16x3tk: a rank's device cannot hold the k-mer tables (146 GB + workspaces)")
+            raise RuntimeError("--precision f16x3tk: a rank's device cannot hold the k-mer tables (156 GB + workspaces)")
         if built and not all_built:
             eng.drop_kmer_tables()
         kmer = {"built": all_built, "seconds": round(time.perf_counter() - t_k, 2),
                 "gb": round(eng.lib.gnn_kmer_tables_bytes() / 1e9, 1) if all_built else 0.0,
                 "note": "x2 per 14-mer (137.4 GB), head A's pair products per (entry, 9-mer) (8.8 GB), conv2's tap tables for the rows no "
-                        "14-mer indexes (8.3 GB); built by gnn_build_kmer_tables before anything is timed; most of the seconds are hipMalloc"}
+                        "14-mer indexes (8.3 GB), x1 over head A's index space (1.4 GB); built by gnn_build_kmer_tables before anything is timed; "
+                        "most of the seconds are hipMalloc"}
         args.precision = "f16x3tk" if all_built else DEFAULT_PRECISION
 
     def max_over_ranks(x: float) -> float:

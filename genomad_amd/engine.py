@@ -93,7 +93,7 @@ class NNEngine:
         self._weights_keepalive = keep
 
     def build_kmer_tables(self, reserve_bytes: int = -1) -> bool:
-        """The k-mer tables of "f16x3tk" (146 GB: x2 per 14-mer, head A's pair products per (entry, 9-mer)); False - with nothing
+        """The k-mer tables of "f16x3tk" (156 GB: x2 per 14-mer, head A's pair products per (entry, 9-mer), conv2's tap tables and x1 over head A's index space); False - with nothing
         allocated - on a device that cannot hold them behind `reserve_bytes` (< 0: the library's default reserve)."""
         rc = self.lib.gnn_build_kmer_tables(self.ctx, int(reserve_bytes))
         if rc == _lib.ERR_NOMEM:

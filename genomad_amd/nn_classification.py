@@ -265,7 +265,7 @@ RANGE_FALLBACKS = {"f16x3tk": ("f16x3", "bf16x3"), "f16x3tc": ("f16x3", "bf16x3"
 # (entry, 9-mer) table.  1.4x the default arithmetic's speed, the same scores to 1e-6 - and 1.5 .. 6 seconds of hipMalloc to set up,
 # which a window costing 5 us repays after a few million windows.  GENOMAD_AMD_KMER_TABLES: "auto" (default) builds them when the
 # run's input is at least GENOMAD_AMD_KMER_TABLES_MIN_GB (default 18 = 3 M windows) of FASTA or the engine already has them,
-# "1" always, "0" never.  A device that cannot hold them (146 GB + workspaces) keeps the default arithmetic; so does the whole
+# "1" always, "0" never.  A device that cannot hold them (156 GB + workspaces) keeps the default arithmetic; so does the whole
 # run when ANY rank cannot (the scores must not depend on which rank classified a contig).  The decision depends on the input,
 # never on the number of ranks: a run gives the same bits on 1 GPU and on 8.
 KMER_TABLES_MIN_GB = 18.0
@@ -296,7 +296,7 @@ def select_arithmetic(eng, precision: str, input_bytes: int, comm=None, console=
         ok = comm.allreduce_max(0.0 if ok else 1.0) == 0.0
     if want and not ok:
         if explicit:
-            raise RuntimeError("GENOMAD_AMD_PRECISION=f16x3tk: the device cannot hold the k-mer tables (146 GB + workspaces); "
+            raise RuntimeError("GENOMAD_AMD_PRECISION=f16x3tk: the device cannot hold the k-mer tables (156 GB + workspaces); "
                                "unset it to run the default arithmetic")
         if console is not None:
             console.log("k-mer tables not built (device memory): classifying with the default arithmetic f16x3tc.")

@@ -75,7 +75,8 @@ typedef enum gnn_precision {
     GNN_PREC_F16X3TK = 7,    /* round 6 (gnn_fused_tk.hip): F16X3TC with everything that is a function of a short k-mer READ FROM TABLES IN HBM
                                 instead of computed - x2[t] = LeakyReLU(conv2(x1))[t] depends on the bases t-10 .. t+3, so conv2 (43 % of a
                                 window's FLOPs) is one 512-byte row gather per position from a table of all 4^14 fourteen-mers (137.4 GB),
-                                head A's pair products one 4-byte read per entry from an (entry, 9-mer) table (8.8 GB); conv3 and head B's
+                                head A's pair products one 4-byte read per entry from an (entry, 9-mer) table (8.8 GB), rows no 14-mer
+                                indexes (window starts, k-mers with a non-ACGT byte) <= 6 row reads of conv2's tap tables (8.3 GB); conv3 and head B's
                                 y @ w_v stay on the matrix pipe with the F16X3TC arithmetic.  The tables are built on the device by
                                 gnn_build_kmer_tables (f64 accumulation, rounded once: closer to exact f32 than the three f16 products);
                                 without them this value answers GNN_ERR_STATE and the caller stays on F16X3TC.  Same range rule as F16X3TC */
@@ -160,7 +161,7 @@ int gnn_device_mem_info(gnn_ctx* ctx, int64_t* free_bytes, int64_t* total_bytes)
 /* replaces nn_model.load_weights(GenomadData.nn_model_file), nn_classification.py:310 */
 int gnn_load_weights(gnn_ctx* ctx, const gnn_weights* w);
 
-/* The k-mer tables of GNN_PREC_F16X3TK: gnn_kmer_tables_bytes() bytes (146.2 GB) of device memory + 1.7 GB of temporaries while they
+/* The k-mer tables of GNN_PREC_F16X3TK: gnn_kmer_tables_bytes() bytes (155.9 GB) of device memory + 1.7 GB of temporaries while they
  * are built (about a second).  reserve_bytes = device memory that must stay free behind them (the workspaces of the launches to come and
  * the caller's own buffers; < 0 = the library's default: two workspaces of the ctx's launch size + 8 GiB).  GNN_ERR_NOMEM - nothing
  * allocated, message says how much is missing - on a device that cannot hold them: the caller keeps GNN_PREC_F16X3TC.  Idempotent.

@@ -44,11 +44,11 @@ def engine(request, synth_weights):
 
 @pytest.fixture
 def kmer_tables(engine):
-    """The session engine with the k-mer tables of "f16x3tk" built (155 GB; 0.2 .. 6 s the first time, nothing when they are there:
+    """The session engine with the k-mer tables of "f16x3tk" built (156 GB; 0.2 .. 6 s the first time, nothing when they are there:
     function scope, because a test may drop them to make room for a subprocess); tests that need them are skipped on a device that
     cannot hold them."""
     if not engine.build_kmer_tables():
-        pytest.skip("the device cannot hold the k-mer tables (146 GB + workspaces)")
+        pytest.skip("the device cannot hold the k-mer tables (156 GB + workspaces)")
     return engine
 
 

@@ -1203,7 +1203,7 @@ def test_toomcook_kernel_is_bit_identical_under_delay_injection(engine, tmp_path
         pytest.skip("libgenomad_nn_hip_jitter.so not built (genomad_amd/csrc/build.sh builds it)")
     script = os.path.join(root, "scripts", "tc_jitter_check.py")
     if prec == "f16x3tk":
-        engine.drop_kmer_tables()          # the subprocesses build their own (one 146 GB set fits beside the session engine, two do not)
+        engine.drop_kmer_tables()          # the subprocesses build their own (one 156 GB set fits beside the session engine, two do not)
     ref = str(tmp_path / "ref.npz")
     env = {k: v for k, v in os.environ.items() if k != "GENOMAD_AMD_LIB"}
     r = subprocess.run([sys.executable, script, "ref", ref, prec], env=env, capture_output=True, text=True, timeout=300, cwd=root)
