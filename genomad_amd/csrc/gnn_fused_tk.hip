@@ -524,11 +524,11 @@ __global__ __launch_bounds__(512, 2) void fused_front_tk_kernel(ArgsK a) {
                 const float* va_ptr = nxt_ptr;
                 X2Rows xr;
                 const uint32_t my_row = x2_rows_index(smem, quads, t0 + FTT - CARRY, hw, lane, more);
+                GNN_TICK(14)
                 GNN_REGION_END();
                 x2_rows_issue<0, X2_PER_WAVE>(xr, a.x2_tbl, my_row, lane);
                 GNN_REGION_END();
                 va = cur.ea < cur.ea_end ? *va_ptr : 0.f;
-                GNN_TICK(14)
                 TC_HPRIO_HIGH();
                 HBAR_W(15, 8);                                                   // c_0
                 load_rows(rb, hx, 3);
