@@ -1351,3 +1351,29 @@ def test_main_promotes_the_default_arithmetic_to_the_kmer_tables(kmer_tables, sy
         assert np.abs(preds[tag] - want).max() <= SCORE_TOL, tag
     assert np.array_equal(preds["auto"], preds["explicit"])
     assert 0 < np.abs(preds["auto"] - preds["off"]).max() <= 2e-5
+
+
+def test_crowded_steps_take_the_overflow_loops(engine, synth_weights):
+    """A weight set whose random patches are concentrated in the first 600 positions: ~1 300 entries per 96-row step instead of ~134, so
+    head B's passes beyond the third (pass_rest) and head A's entries beyond one per helper thread (the loop behind E in gnn_fused_tk.hip)
+    run - neither ever does with uniformly drawn patches.  Both Toom-Cook kernels against the exact-f32 path, which has no step structure."""
+    from genomad_amd.engine import NNEngine
+    w = dict(synth_weights)
+    rng = np.random.default_rng(31)
+    for head in ("iglooA", "iglooB"):
+        p = np.sort(rng.integers(0, 600, size=w[f"{head}_patches"].shape).astype(np.int32), axis=1)
+        p[:40, :, 0] = np.sort(rng.integers(0, 12, size=(40, p.shape[1])), axis=1)      # a crowd at the window start: head A's x1-table path as well
+        w[f"{head}_patches"] = p
+    bases = synthetic.synth_windows(321, 6).copy()
+    bases[1, 40:60] = ord("N")
+    bases[2, 300:] = ord("N")
+    engine.drop_kmer_tables()                      # room for this engine's own tables
+    with NNEngine(0, w) as e2:
+        ref, rt = e2.debug_forward(bases, "f32", taps=("m_a", "m_b", "feat"))
+        precs = ["f16x3tc"] + (["f16x3tk"] if e2.build_kmer_tables() else [])
+        for prec in precs:
+            got, t = e2.debug_forward(bases, prec, taps=("m_a", "m_b", "feat"))
+            assert np.abs(t["m_a"] - rt["m_a"]).max() <= 2e-5, prec
+            assert np.abs(t["m_b"] - rt["m_b"]).max() <= 2e-4, prec
+            assert np.abs(got - ref).max() <= SCORE_TOL / 2, (prec, float(np.abs(got - ref).max()))
+            assert np.array_equal(e2.classify(bases, prec), got)
