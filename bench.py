@@ -233,6 +233,7 @@ def front_roofline(precision, windows_per_launch, avg_ms, launches, front_ms, ba
         share = 0.42675 + 0.0711                       # conv2 + head A's y @ w_v of the algorithmic FLOPs are table reads
         r["table_reads"] = {
             "share_of_algorithmic_flops": round(share, 4), "flop_executed_per_window": int(FLOP_PER_WINDOW * (1.0 - share)),
+            "frac_counting_executed_flops_only": round(tflops * (1.0 - share) / MFMA_PEAK_TFLOPS, 4),
             "bytes_per_window": tk_bytes, "gather_gb_per_s": round(sum(tk_bytes.values()) * windows_per_launch / (avg_ms * 1e-3) / 1e9, 1) if avg_ms > 0 else None,
             "gather_frac_of_hbm_peak": round(sum(tk_bytes.values()) * windows_per_launch / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if avg_ms > 0 else None,
             "probe": "scripts/probe_gather_big.hip: 512-byte rows at random 14-mers of a 137 GB table arrive at 5.9 TB/s (11.6 G rows/s) on this chip: "
