@@ -286,7 +286,7 @@ def engine_scores_unscaled(synth_weights, bases):
         return e0.classify(bases, "f32")
 
 
-def test_toomcook_range_band_falls_back_to_the_direct_f16_form(synth_weights, tmp_path, monkeypatch):
+def test_toomcook_range_band_falls_back_to_the_direct_f16_form(engine, synth_weights, tmp_path, monkeypatch):
     """between |activation| ~4e3 and 65 504 only the Toom-Cook form's TRANSFORMED operands (up to 32x the activations)
     leave the f16 range.  There f16x3tc must return non-finite scores (inf / -inf limb pairs -> NaN, NaN-propagating pool), never
     finite wrong ones; the direct f16x3 form is still exact; and main() hops exactly once, f16x3tc -> f16x3."""
@@ -304,6 +304,13 @@ def test_toomcook_range_band_falls_back_to_the_direct_f16_form(synth_weights, tm
         tc, direct = e2.classify(bases, "f16x3tc"), e2.classify(bases, "f16x3")
         assert not np.isfinite(tc).all()
         assert np.isfinite(direct).all() and np.abs(direct - exact).max() <= SCORE_TOL / 2
+        # the k-mer-table form reads x2 from a table (exact f32, so it is finite) but still transforms it into f16 operands for conv3:
+        # the same band must turn its scores non-finite too (when this engine's own 156 GB of tables fit beside the session engine's)
+        monkeypatch.setenv("GENOMAD_AMD_KMER_TABLES", "0")                    # main() below: the default arithmetic's chain
+        engine.drop_kmer_tables()                                             # room for e2's own set
+        if e2.build_kmer_tables():
+            assert not np.isfinite(e2.classify(bases, "f16x3tk")).all()
+            e2.drop_kmer_tables()
         monkeypatch.delenv("GENOMAD_AMD_PRECISION", raising=False)
         monkeypatch.setattr(nnc, "_ENGINE", e2)
         nnc._WARNED.clear()
