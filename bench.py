@@ -26,6 +26,11 @@ reference shapes, resident in HBM before the timed region.  A "step" is one pass
 `value` = windows of all ranks / max-over-ranks wall time, barrier + stream sync on both sides, the gather
 and the copy of the scores to the host of rank 0 inside the timed region.
 
+Arithmetic (--precision auto, the default): "f16x3tk" when EVERY rank's device can hold the 156 GB of k-mer tables (conv2 read from a
+table of all 14-mers, head A from 9-mer tables: genomad_amd/csrc/gnn_fused_tk.hip) - built by gnn_build_kmer_tables before anything is
+timed, `kmer_tables` in the line says how long that took - else the default "f16x3tc"; --no-kmer-tables measures the latter.
+`roofline.table_reads` lists what f16x3tk reads instead of computing (half of the algorithmic FLOPs) and the bytes that costs.
+
 After the timed region (untimed) every window of the job is classified once more with the exact-f32 device path and,
 bit for bit, through the synchronous entry point: `parity` reports max |dscore| over ALL timed windows, how many exceed
 1e-4 and 5e-5, and the process exits non-zero if any window exceeds the 1e-4 tolerance or any bit differs.
