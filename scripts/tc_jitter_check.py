@@ -13,7 +13,7 @@ from genomad_amd import synthetic, _lib  # noqa: E402
 from genomad_amd.engine import NNEngine  # noqa: E402
 
 mode, path = sys.argv[1], sys.argv[2]
-prec = sys.argv[3] if len(sys.argv) > 3 else "f16x3tc"       # "f16x3tk": the k-mer-table kernel (10 barriers per step), same method
+prec = sys.argv[3] if len(sys.argv) > 3 else "f16x3tc"       # "f16x3tk": the k-mer-table kernel (9 barriers per step), same method
 eng = NNEngine(0, synthetic.synth_weights())
 if prec == "f16x3tk" and not eng.build_kmer_tables():
     print("the device cannot hold the k-mer tables")
