@@ -283,8 +283,8 @@ def select_arithmetic(eng, precision: str, input_bytes: int, comm=None, console=
     explicit = precision == "f16x3tk"
     min_bytes = float(os.environ.get("GENOMAD_AMD_KMER_TABLES_MIN_GB", KMER_TABLES_MIN_GB)) * 1e9
     want = explicit or policy == "1" or (policy == "auto" and (eng.has_kmer_tables() or input_bytes >= min_bytes))
-    if comm is not None:                       # eng.has_kmer_tables() is per process: every rank follows rank-independent facts only
-        want = comm.allreduce_max(1.0 if want else 0.0) > 0.0
+    if comm is not None:                       # eng.has_kmer_tables() is per process: every rank follows what ANY rank wants
+        want = bool(np.asarray(comm.allgather_i64([1 if want else 0])).any())
     ok = False
     if want:
         t = time.perf_counter()
@@ -292,8 +292,8 @@ def select_arithmetic(eng, precision: str, input_bytes: int, comm=None, console=
         ok = eng.build_kmer_tables()
         if ok and not had and console is not None:
             console.log(f"k-mer tables built on the device in {time.perf_counter() - t:.1f} s (14-mer table of conv2, 9-mer table of head A's pair products).")
-    if comm is not None:
-        ok = comm.allreduce_max(0.0 if ok else 1.0) == 0.0
+    if comm is not None:                       # ... and what EVERY rank could build (allgather_i64: the transport every comm of sharding.py has)
+        ok = bool(np.asarray(comm.allgather_i64([1 if ok else 0])).all())
     if want and not ok:
         if explicit:
             raise RuntimeError("GENOMAD_AMD_PRECISION=f16x3tk: the device cannot hold the k-mer tables (156 GB + workspaces); "

@@ -1429,13 +1429,13 @@ class _TablesEngine:
 
 
 class _Comm:
-    """allreduce_max over a fixed list of what the OTHER ranks contribute"""
+    """allgather_i64 over a fixed list of what the OTHER rank contributes to each collective"""
 
     def __init__(self, others):
         self.others = list(others)
 
-    def allreduce_max(self, v):
-        return max([v] + [self.others.pop(0)] if self.others else [v])
+    def allgather_i64(self, values):
+        return np.array([list(values), [int(self.others.pop(0))]], dtype=np.int64)
 
 
 def test_select_arithmetic_policy(monkeypatch):
@@ -1468,11 +1468,13 @@ def test_select_arithmetic_policy(monkeypatch):
     monkeypatch.setenv("GENOMAD_AMD_KMER_TABLES_MIN_GB", "0.5")
     assert nnc.select_arithmetic(_TablesEngine(), "f16x3tc", small) == "f16x3tk"
     monkeypatch.delenv("GENOMAD_AMD_KMER_TABLES_MIN_GB")
-    # several ranks: first collective = does anybody want them (1.0 = yes), second = did anybody fail (1.0 = yes)
-    assert nnc.select_arithmetic(_TablesEngine(), "f16x3tc", big, _Comm([1.0, 0.0])) == "f16x3tk"
-    assert nnc.select_arithmetic(_TablesEngine(), "f16x3tc", big, _Comm([1.0, 1.0])) == "f16x3tc"       # another rank could not build
+    # several ranks: first collective = who wants them, second = who could build them
+    assert nnc.select_arithmetic(_TablesEngine(), "f16x3tc", big, _Comm([1, 1])) == "f16x3tk"
+    assert nnc.select_arithmetic(_TablesEngine(), "f16x3tc", big, _Comm([1, 0])) == "f16x3tc"       # the other rank could not build
     e = _TablesEngine()
-    assert nnc.select_arithmetic(e, "f16x3tc", small, _Comm([1.0, 0.0])) == "f16x3tk" and e.builds == 1   # another rank already holds them
+    assert nnc.select_arithmetic(e, "f16x3tc", small, _Comm([1, 1])) == "f16x3tk" and e.builds == 1   # the other rank already holds them
+    e = _TablesEngine()
+    assert nnc.select_arithmetic(e, "f16x3tc", small, _Comm([0, 1])) == "f16x3tc" and e.builds == 0   # nobody wants them
     # an engine without the table methods (the CPU stand-in of the multi-rank tests) is left alone
     assert nnc.select_arithmetic(object(), "f16x3tc", big) == "f16x3tc"
     assert nnc.RANGE_FALLBACKS["f16x3tk"] == ("f16x3", "bf16x3")
