@@ -59,6 +59,7 @@ namespace tk {
 
 using namespace tc;
 
+constexpr int YP_NT = 2;                            // cache policy of the pooled rows' stores: nt (bit 1) - this kernel never reads them again (+0.5 %)
 constexpr uint32_t X2_ROWS = (1u << 28) + 1u;       // 4^14 fourteen-mers + the all-N-token row
 constexpr uint32_t X2_NN = 1u << 28;
 constexpr uint32_t K9_ROWS = (1u << 18) + 1u;       // 4^9 nine-mers + the all-N-token 9-mer
@@ -307,7 +308,9 @@ __device__ __forceinline__ void x2_rows_issue(X2Rows& x, const float* __restrict
     for (int i = I0; i < I1; ++i) {
         const uint32_t row = __builtin_amdgcn_readlane(my_row, i) & ~ROW_DIRTY;
         const unsigned char* p = reinterpret_cast<const unsigned char*>(tbl) + (size_t)row * (C * 4);      // wave-uniform 64-bit base
-        x.v[i] = *reinterpret_cast<const u32x2*>(p + lane * 8);                                           // 64 lanes x 8 B = one row
+        // 64 lanes x 8 B = one row; non-temporal: a row is read once per window and never again - without the hint the 52 KB a step gathers
+        // push weights and head A's table rows out of the L2 / Infinity Cache (+1.8 %, profiles/r06/tk_first/ab_x2_rows_nontemporal.txt)
+        x.v[i] = __builtin_nontemporal_load(reinterpret_cast<const u32x2*>(p + lane * 8));
     }
 }
 __device__ __forceinline__ void x2_rows_store(const X2Rows& x, unsigned char* __restrict__ buf, uint32_t my_row, int w, int lane) {
@@ -408,7 +411,7 @@ __global__ __launch_bounds__(512, 2) void fused_front_tk_kernel(ArgsK a) {
             {                                                                    // head A's rows of the first step: nothing to hide their round trip behind
                 WvaRows w0;
                 wva_issue(w0, tblr, wva_step_index_q(quads, s_lo * FTT, hw, lane), lane);
-                wva_pool_store(w0, yp_w, s_lo * FTT, hw, lane);
+                wva_pool_store<YP_NT>(w0, yp_w, s_lo * FTT, hw, lane);
             }
             {                                                                    // V3 chunk 1 of the first step (the helpers make chunk 0)
                 const HLane h0 = hlane(smem, (s_lo & 1) * BUF_BYTES, hw, lane);
@@ -446,14 +449,14 @@ __global__ __launch_bounds__(512, 2) void fused_front_tk_kernel(ArgsK a) {
                         for (int r = 0; r < 16; ++r) ac[mb][r] = 0.f;
                     wv_tile(smem, xoff + CARRY * ROWX, ring, ac, lane);
                     prime_tc(ring, cw, 0, lane);
-                    wv_pool_store(ac, yp_w, POOLED * C * 4, t0, hw, lane);
+                    wv_pool_store<YP_NT>(ac, yp_w, POOLED * C * 4, t0, hw, lane);
                     GNN_TICK(3)
                     if (step + 1 < s_hi) {
                         const HLane hn = hlane(smem, yoff, hw, lane);            // V3 chunk 1 of the next step: x2(s+1) is in buf[(s+1) & 1] since c_7
                         Raw16 rm;
                         load_rows(rm, hn, 1);
                         transform_store(rm, hn, 1);
-                        wva_pool_store(wr, yp_w, t0 + FTT, hw, lane);
+                        wva_pool_store<YP_NT>(wr, yp_w, t0 + FTT, hw, lane);
                     }
                     wva_next = wva_step_index_q(quads, t0 + 2 * FTT, hw, lane);
                     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");           // chunk 1's fragments have landed before c_0 releases the readers
@@ -528,7 +531,7 @@ __global__ __launch_bounds__(512, 2) void fused_front_tk_kernel(ArgsK a) {
                 GNN_REGION_END();
                 x2_rows_issue<0, X2_PER_WAVE>(xr, a.x2_tbl, my_row, lane);
                 GNN_REGION_END();
-                va = cur.ea < cur.ea_end ? *va_ptr : 0.f;
+                va = cur.ea < cur.ea_end ? __builtin_nontemporal_load(va_ptr) : 0.f;       // read once: non-temporal like the x2 rows (+0.4 %)
                 TC_HPRIO_HIGH();
                 HBAR_W(15, 8);                                                   // c_0
                 load_rows(rb, hx, 3);

@@ -178,6 +178,7 @@ __device__ __forceinline__ void prime_wv(WU (&ring)[RINGT], wrsrc_t wr, int lane
 }
 
 // MaxPool1D(8) of the y @ w_v tile -> yp rows (igloo.py:209-210); gnn_fused_x3.hip, wv_pool_store
+template <int AUX = 0>      // cache policy bits of the stores (bit 1 = nt: the rows are not read again by this kernel)
 __device__ __forceinline__ void wv_pool_store(const f32x16 (&acc)[NMB], wrsrc_t yp_w, int head_off, int t0, int wave, int lane) {
     float m[4 * NMB];
 #pragma unroll
@@ -194,7 +195,7 @@ __device__ __forceinline__ void wv_pool_store(const f32x16 (&acc)[NMB], wrsrc_t 
         const uint32_t voff = (uint32_t)(wave * 32 + lane) * 4u;
 #pragma unroll
         for (int i = 0; i < 4 * NMB; ++i)
-            if (i < nq) __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(m[i]), yp_w, voff, head_off + (q0 + i) * (C * 4), 0);
+            if (i < nq) __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(m[i]), yp_w, voff, head_off + (q0 + i) * (C * 4), AUX);
     }
 }
 
@@ -280,6 +281,7 @@ __device__ __forceinline__ void wva_issue(WvaRows& r, wrsrc_t tbl, uint32_t my_r
     }
 }
 // MaxPool1D(8) over the gathered rows -> 3 pooled rows of yp (igloo.py:209-210)
+template <int AUX = 0>
 __device__ __forceinline__ void wva_pool_store(const WvaRows& r, wrsrc_t yp_w, int t0, int hw, int lane) {
     const int q0 = t0 / GNN_POOL + 3 * hw;
 #pragma unroll
@@ -290,7 +292,7 @@ __device__ __forceinline__ void wva_pool_store(const WvaRows& r, wrsrc_t yp_w, i
             m0 = max_nan(m0, __uint_as_float(r.v[8 * p + j][0]));
             m1 = max_nan(m1, __uint_as_float(r.v[8 * p + j][1]));
         }
-        if (q0 + p < POOLED) __builtin_amdgcn_raw_buffer_store_b64(u32x2{__float_as_uint(m0), __float_as_uint(m1)}, yp_w, (uint32_t)lane * 8u, (q0 + p) * (C * 4), 0);
+        if (q0 + p < POOLED) __builtin_amdgcn_raw_buffer_store_b64(u32x2{__float_as_uint(m0), __float_as_uint(m1)}, yp_w, (uint32_t)lane * 8u, (q0 + p) * (C * 4), AUX);
     }
 }
 
