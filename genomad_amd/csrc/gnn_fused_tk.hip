@@ -282,7 +282,7 @@ __device__ __forceinline__ void dirty_rows_fill_prologue(unsigned char* __restri
 
 // ---------------------------------------------------------------- x2 rows of a step: indices, requests, stores
 struct X2Rows {
-    u32x2 v[X2_PER_WAVE];
+    u32x4 v[X2_PER_WAVE / 2];      // instruction i: lanes 0..31 hold row 2 i, lanes 32..63 row 2 i + 1 (16 B = 4 channels per lane)
 };
 // lane l < X2_PER_WAVE of wave part w (0..3): buffer row 26 w + l (position tb + row); rows behind the buffer's 101 are clamped
 // (requested twice, stored once).  A row no table holds goes onto the list in LDS (`list`) and keeps its flag: it is requested as the
@@ -304,21 +304,26 @@ __device__ __forceinline__ uint32_t x2_rows_index(unsigned char* __restrict__ sm
 }
 template <int I0, int I1>
 __device__ __forceinline__ void x2_rows_issue(X2Rows& x, const float* __restrict__ tbl, uint32_t my_row, int lane) {
+    static_assert(I0 % 2 == 0 && I1 % 2 == 0, "two rows per request");
 #pragma unroll
-    for (int i = I0; i < I1; ++i) {
-        const uint32_t row = __builtin_amdgcn_readlane(my_row, i) & ~ROW_DIRTY;
-        const unsigned char* p = reinterpret_cast<const unsigned char*>(tbl) + (size_t)row * (C * 4);      // wave-uniform 64-bit base
-        // 64 lanes x 8 B = one row; non-temporal: a row is read once per window and never again - without the hint the 52 KB a step gathers
+    for (int i = I0 / 2; i < I1 / 2; ++i) {
+        // two rows per request (16 B per lane): the vector memory pipe is ISSUE-bound beside the matrix waves' weight and table-row
+        // requests, and a 16-byte request costs what an 8-byte one does (MI355X_MICROARCH.md, the store tail of T21)
+        const uint32_t r0 = __builtin_amdgcn_readlane(my_row, 2 * i), r1 = __builtin_amdgcn_readlane(my_row, 2 * i + 1);
+        const uint32_t row = (lane < 32 ? r0 : r1) & ~ROW_DIRTY;
+        const unsigned char* p = reinterpret_cast<const unsigned char*>(tbl) + (size_t)row * (C * 4) + (lane & 31) * 16;
+        // non-temporal: a row is read once per window and never again - without the hint the 52 KB a step gathers
         // push weights and head A's table rows out of the L2 / Infinity Cache (+1.8 %, profiles/r06/tk_first/ab_x2_rows_nontemporal.txt)
-        x.v[i] = __builtin_nontemporal_load(reinterpret_cast<const u32x2*>(p + lane * 8));
+        x.v[i] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(p));
     }
 }
 __device__ __forceinline__ void x2_rows_store(const X2Rows& x, unsigned char* __restrict__ buf, uint32_t my_row, int w, int lane) {
 #pragma unroll
-    for (int i = 0; i < X2_PER_WAVE; ++i) {
-        const int r = X2_PER_WAVE * w + i;
-        const bool dirty = (__builtin_amdgcn_readlane(my_row, i) & ROW_DIRTY) != 0u;
-        if (r < BUF_ROWS && !dirty) *reinterpret_cast<u32x2*>(buf + r * ROWX + lane * 8) = x.v[i];
+    for (int i = 0; i < X2_PER_WAVE / 2; ++i) {
+        const int r = X2_PER_WAVE * w + 2 * i + (lane >> 5);
+        const uint32_t r0 = __builtin_amdgcn_readlane(my_row, 2 * i), r1 = __builtin_amdgcn_readlane(my_row, 2 * i + 1);
+        const bool dirty = ((lane < 32 ? r0 : r1) & ROW_DIRTY) != 0u;
+        if (r < BUF_ROWS && !dirty) *reinterpret_cast<u32x4*>(buf + r * ROWX + (lane & 31) * 16) = x.v[i];
     }
 }
 
@@ -569,6 +574,10 @@ __global__ __launch_bounds__(512, 2) void fused_front_tk_kernel(ArgsK a) {
                 fetch(step + 1, more);                                           // head A's entry of the next step: its position, located behind E
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 HBAR(13, 8);                                                     // ---- E: x3 is in buf[s & 1]
+                // everything requested in front of E (the three passes' weights, the next entry's position) has to be here now, and the
+                // compiler must KNOW it: every pass sits under a condition, so without this it waits with vmcnt(0) at the top of each
+                // pass - behind the store of the pass before (stores count in vmcnt on gfx9): four store round trips in a row
+                __builtin_amdgcn_s_waitcnt(0x0F70);                              // vmcnt(0)
                 locate();
                 pass_compute(p0, jb, 0, hw, lane);
                 pass_compute(p1, jb, 1, hw, lane);

@@ -268,31 +268,39 @@ __device__ __forceinline__ uint32_t wva_step_index(const uint16_t* __restrict__ 
     return idx;
 }
 struct WvaRows {
-    u32x2 v[WVA_ROWS_PER_WAVE];     // 24 table rows, two channels per lane
+    u32x4 v[WVA_ROWS_PER_WAVE / 2];     // 24 table rows: request i holds row 2 i in lanes 0..31 and row 2 i + 1 in lanes 32..63, four channels per lane
 };
-// all 24 row requests of a wave: 64 lanes x 8 B = one 512-byte row per instruction, the row's byte offset in an SGPR
+// all 24 rows of a wave in 12 requests of 64 lanes x 16 B (two 512-byte rows each): behind E the vector memory pipe carries the w_v
+// weights, these rows, the helpers' x2 rows and pair weights, and a request of 16 B per lane costs what one of 8 B does (one row per
+// request, 24 of them: w_v B + pool 5.5 k -> 4.4 k cycles per step, profiles/r06/ab/ab14_wva_rows_16B.txt)
 template <int I0 = 0, int I1 = WVA_ROWS_PER_WAVE>
 __device__ __forceinline__ void wva_issue(WvaRows& r, wrsrc_t tbl, uint32_t my_row, int lane) {
-    const uint32_t l8 = (uint32_t)lane * 8u;
+    static_assert(I0 % 2 == 0 && I1 % 2 == 0, "two rows per request");
+    const uint32_t l16 = (uint32_t)(lane & 31) * 16u;
 #pragma unroll
-    for (int i = I0; i < I1; ++i) {
-        const uint32_t row = __builtin_amdgcn_readlane(my_row, i);
-        r.v[i] = __builtin_amdgcn_raw_buffer_load_b64(tbl, l8, row * WvaTable::ROW_BYTES, 0);
+    for (int i = I0 / 2; i < I1 / 2; ++i) {
+        const uint32_t r0 = __builtin_amdgcn_readlane(my_row, 2 * i), r1 = __builtin_amdgcn_readlane(my_row, 2 * i + 1);
+        r.v[i] = __builtin_amdgcn_raw_buffer_load_b128(tbl, (lane < 32 ? r0 : r1) * WvaTable::ROW_BYTES + l16, 0, 0);
     }
 }
-// MaxPool1D(8) over the gathered rows -> 3 pooled rows of yp (igloo.py:209-210)
+// MaxPool1D(8) over the gathered rows -> 3 pooled rows of yp (igloo.py:209-210): the even rows' maximum in lanes 0..31, the odd rows' in
+// lanes 32..63 (max is exact and commutative: any order gives the same bits), one half-swap, lanes 0..31 store the row
 template <int AUX = 0>
 __device__ __forceinline__ void wva_pool_store(const WvaRows& r, wrsrc_t yp_w, int t0, int hw, int lane) {
     const int q0 = t0 / GNN_POOL + 3 * hw;
 #pragma unroll
     for (int p = 0; p < 3; ++p) {
-        float m0 = __uint_as_float(r.v[8 * p][0]), m1 = __uint_as_float(r.v[8 * p][1]);
+        u32x4 out;
 #pragma unroll
-        for (int j = 1; j < 8; ++j) {
-            m0 = max_nan(m0, __uint_as_float(r.v[8 * p + j][0]));
-            m1 = max_nan(m1, __uint_as_float(r.v[8 * p + j][1]));
+        for (int c = 0; c < 4; ++c) {
+            float m = __uint_as_float(r.v[4 * p][c]);
+#pragma unroll
+            for (int j = 1; j < 4; ++j) m = max_nan(m, __uint_as_float(r.v[4 * p + j][c]));
+            const unsigned bits = __float_as_uint(m);
+            const auto sw = __builtin_amdgcn_permlane32_swap(bits, bits, false, false);
+            out[c] = __float_as_uint(max_nan(__uint_as_float(sw[0]), __uint_as_float(sw[1])));
         }
-        if (q0 + p < POOLED) __builtin_amdgcn_raw_buffer_store_b64(u32x2{__float_as_uint(m0), __float_as_uint(m1)}, yp_w, (uint32_t)lane * 8u, (q0 + p) * (C * 4), AUX);
+        if (lane < 32 && q0 + p < POOLED) __builtin_amdgcn_raw_buffer_store_b128(out, yp_w, (uint32_t)lane * 16u, (q0 + p) * (C * 4), AUX);
     }
 }
 
