@@ -375,24 +375,36 @@ __global__ __launch_bounds__(512, 2) void fused_front_tk_kernel(ArgsK a) {
     if constexpr (PROF) tick_ = t_entry;
 
     if (s_hi > s_lo) {
-        // x2 of the first step: every wave gathers 13 of its 101 rows, nothing hides the round trip (once per window / part)
+        // x2 of the first step: every wave gathers 14 of its 101 rows - all requested at once, two rows per 16-byte request like the
+        // step loop's burst, ONE round trip that nothing hides (once per window / part); behind them, on the matrix waves, head A's table
+        // rows of the first step, so that their round trip runs beside this one
+        WvaRows w0;
         {
             const int tb = s_lo * FTT - CARRY;
             unsigned char* buf = smem + (s_lo & 1) * BUF_BYTES;
-            const int r = min(13 * wave + min(lane, 12), BUF_ROWS - 1);
+            constexpr int PR = 14;                                           // 8 waves x 14 rows >= 101
+            const int r = min(PR * wave + min(lane, PR - 1), BUF_ROWS - 1);
             const uint32_t idx = x2_index(quads, tb + r);
-            if ((idx & ROW_DIRTY) && lane < 13 && 13 * wave + lane < BUF_ROWS) {
+            if ((idx & ROW_DIRTY) && lane < PR && PR * wave + lane < BUF_ROWS) {
                 const uint32_t slot = atomicAdd(reinterpret_cast<uint32_t*>(smem + DIRTY_OFF), 1u);
                 smem[DIRTY_OFF + 4 + slot] = (unsigned char)r;
             }
-#pragma unroll 1
-            for (int i = 0; i < 13; ++i) {
-                const int rr = 13 * wave + i;
-                const uint32_t row = __builtin_amdgcn_readlane(idx, i);
-                if (rr < BUF_ROWS && !(row & ROW_DIRTY)) {
-                    const unsigned char* p = reinterpret_cast<const unsigned char*>(a.x2_tbl) + (size_t)row * (C * 4);
-                    *reinterpret_cast<u32x2*>(buf + rr * ROWX + lane * 8) = *reinterpret_cast<const u32x2*>(p + lane * 8);
-                }
+            u32x4 v[PR / 2];
+#pragma unroll
+            for (int i = 0; i < PR / 2; ++i) {
+                const uint32_t r0 = __builtin_amdgcn_readlane(idx, 2 * i), r1 = __builtin_amdgcn_readlane(idx, 2 * i + 1);
+                const uint32_t row = (lane < 32 ? r0 : r1) & ~ROW_DIRTY;
+                const unsigned char* p = reinterpret_cast<const unsigned char*>(a.x2_tbl) + (size_t)row * (C * 4) + (lane & 31) * 16;
+                v[i] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(p));
+            }
+            if (!helper)
+                wva_issue(w0, make_wrsrc(a.wva_tbl, (int)(WvaTable::ROWS * WvaTable::ROW_BYTES)), wva_step_index_q(quads, s_lo * FTT, hw, lane), lane);
+#pragma unroll
+            for (int i = 0; i < PR / 2; ++i) {
+                const int rr = PR * wave + 2 * i + (lane >> 5);
+                const uint32_t r0 = __builtin_amdgcn_readlane(idx, 2 * i), r1 = __builtin_amdgcn_readlane(idx, 2 * i + 1);
+                const bool dirty = ((lane < 32 ? r0 : r1) & ROW_DIRTY) != 0u;
+                if (rr < BUF_ROWS && !dirty) *reinterpret_cast<u32x4*>(buf + rr * ROWX + (lane & 31) * 16) = v[i];
             }
             __syncthreads();
             GNN_TICK(6)
@@ -413,11 +425,7 @@ __global__ __launch_bounds__(512, 2) void fused_front_tk_kernel(ArgsK a) {
             const wrsrc_t yp_w = make_wrsrc(reinterpret_cast<const unsigned char*>(a.yp + wi * 2 * (size_t)POOLED * C), 2 * POOLED * C * 4);
             WU ring[RINGT];
             prime_tc(ring, cw, 0, lane);
-            {                                                                    // head A's rows of the first step: nothing to hide their round trip behind
-                WvaRows w0;
-                wva_issue(w0, tblr, wva_step_index_q(quads, s_lo * FTT, hw, lane), lane);
-                wva_pool_store<YP_NT>(w0, yp_w, s_lo * FTT, hw, lane);
-            }
+            wva_pool_store<YP_NT>(w0, yp_w, s_lo * FTT, hw, lane);               // head A's rows of the first step (requested beside the first x2 rows)
             {                                                                    // V3 chunk 1 of the first step (the helpers make chunk 0)
                 const HLane h0 = hlane(smem, (s_lo & 1) * BUF_BYTES, hw, lane);
                 Raw16 rm;
