@@ -361,6 +361,28 @@ def test_kmer_table_model_has_the_barriers_the_source_has():
     assert "__syncthreads" not in matrix and "__syncthreads" not in helper      # a __syncthreads() would drain the weight loads in flight
 
 
+def test_kmer_table_helpers_wait_once_behind_E_and_gather_two_rows_per_request():
+    """Two facts the step loop's timing rests on (profiles/r06/ab/ab12..14): (1) everything the helpers requested in front of E is
+    waited for ONCE, right behind E, with the builtin the compiler's wait-count pass sees - every pair pass sits under a condition, and
+    without it the compiler waits with vmcnt(0) at the top of each pass, behind the store of the pass before; (2) table rows travel in
+    16-byte requests, two 512-byte rows per request (the vector memory pipe is bound by the number of requests behind E)."""
+    import os
+    import re
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    src = open(os.path.join(root, "genomad_amd", "csrc", "gnn_fused_tk.hip")).read()
+    hdr = open(os.path.join(root, "genomad_amd", "csrc", "gnn_tc_dev.h")).read()
+    i = src.index("if (!helper) {")
+    _, end = _loop_body_from(src, "for (int step = s_lo; step < s_hi; ++step) {", i)
+    helper, _ = _loop_body_from(src, "for (int step = s_lo; step < s_hi; ++step) {", end)
+    code = re.sub(r"//[^\n]*", "", helper)
+    m = re.search(r"HBAR\(13, 8\);\s*__builtin_amdgcn_s_waitcnt\(0x0F70\);\s*locate\(\);\s*pass_compute\(p0", code)
+    assert m, "the helpers' one wait behind E (vmcnt(0), lgkmcnt / expcnt untouched: 0x0F70) is gone or moved"
+    assert 'asm volatile("s_waitcnt vmcnt' not in helper                     # an inline-asm wait is invisible to the compiler's pass
+    assert re.search(r"struct X2Rows \{\s*u32x4 v\[X2_PER_WAVE / 2\];", src)
+    assert re.search(r"struct WvaRows \{\s*u32x4 v\[WVA_ROWS_PER_WAVE / 2\];", hdr)
+    assert "raw_buffer_load_b64(tbl" not in hdr and "u32x2*>(p + lane * 8)" not in src
+
+
 def _loop_body_from(src, head, start):
     i = src.index(head, start)
     depth, j = 0, src.index("{", i)
