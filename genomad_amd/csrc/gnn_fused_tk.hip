@@ -512,41 +512,52 @@ __global__ __launch_bounds__(512, 2) void fused_front_tk_kernel(ArgsK a) {
                 nxt_ptr = a.mpa_tbl + ((size_t)max(nxt.ea, 0) * K9_ROWS + (dirty == 0u ? code : K9_NN));
             };
             fetch(s_lo, true);
-            locate();
             {                                                                    // V3 chunk 0 of the first step
                 const HLane h0 = hlane(smem, (s_lo & 1) * BUF_BYTES, hw, lane);
                 load_rows(ra, h0, 0);
                 transform_store(ra, h0, 0);
                 load_rows(ra, h0, 2);
             }
+            __builtin_amdgcn_s_waitcnt(0x0F70);                                  // vmcnt(0): the first entry's position (the loop's top consumes it)
 
+            // The loop is ROTATED: an iteration starts behind E of the step before and ends with E of its own step, so that the x2 rows
+            // of the next step are requested and stored inside ONE iteration (carried around the loop they cost a vmcnt(0) at the loop
+            // header) and still travel beside head B's pair products of the step before instead of beside conv3's weight stream: the
+            // vector memory pipe is what bounds the conv loop (512 KB of weights per step at 52 of its 64 B/clk), and 52 KB of rows
+            // arriving in its first units cost it their share.  What IS carried around the loop - the three passes' weights, the next
+            // entry's position - has landed at the latch: the explicit wait behind E.
 #pragma unroll 1
             for (int step = s_lo; step < s_hi; ++step) {
                 const int t0 = step * FTT;
                 const int xoff = (step & 1) * BUF_BYTES, yoff = BUF_BYTES - xoff;
                 const HLane hx = hlane(smem, xoff, hw, lane), hy = hlane(smem, yoff, hw, lane);
                 const bool more = step + 1 < s_hi;
+                const bool prev = step > s_lo;
                 const PairJob jb = {smem + xoff, a.weff_b, a.pos_sorted[1], mp_w[1], t0, bkt[STEPST + 1 + step], bkt[STEPST + 1 + step + 1]};
-                // The x2 rows of the NEXT step: 26 per wave, all requested here - between head B's pair products of the last step and c_0,
-                // with NO load pending in front of them (every register the allocator recycles for their addresses is then free of
-                // pending writes: it put an s_waitcnt vmcnt(0) into the middle of the 26 requests otherwise; the pair products' stores may
-                // be) -, stored behind c_6.  They
-                // are requested and stored inside one iteration: carried around the loop, the allocator copied one row register at the
-                // loop header and waited there for all 26.  Behind them the one long read nobody waits for before E: head A's table.
-                // (A wave's loads return in order and the compiler waits with vmcnt(0) for loads issued under a condition: whatever is
-                // consumed while the rows travel would wait for their whole round trip to HBM.)
+                // head B's pair products of the step BEFORE (x3(s-1) is in the other buffer until c_6); none in front of the first step
+                const PairJob jp = {smem + yoff, a.weff_b, a.pos_sorted[1], mp_w[1], t0 - FTT, prev ? bkt[STEPST + 1 + step - 1] : 0, prev ? bkt[STEPST + 1 + step] : 0};
+                // ---- behind E of the step before: this step's entry of head A located, then the x2 rows of the NEXT step: 26 per wave in
+                // 13 requests, all at once, with NO load pending in front of them; behind them the one long read nobody waits for before
+                // c_7: head A's table.  (A wave's loads return in order and the compiler waits with vmcnt(0) for loads issued under a
+                // condition: whatever is consumed while the rows travel would wait for their whole round trip to HBM - the pair products
+                // below consume nothing that is pending.)
+                locate();
                 cur = nxt;
                 va_slow = nxt_slow;
                 const float* va_ptr = nxt_ptr;
                 X2Rows xr;
                 const uint32_t my_row = x2_rows_index(smem, quads, t0 + FTT - CARRY, hw, lane, more);
-                GNN_TICK(14)
                 GNN_REGION_END();
                 x2_rows_issue<0, X2_PER_WAVE>(xr, a.x2_tbl, my_row, lane);
                 GNN_REGION_END();
                 va = cur.ea < cur.ea_end ? __builtin_nontemporal_load(va_ptr) : 0.f;       // read once: non-temporal like the x2 rows (+0.4 %)
+                GNN_TICK(15)
+                pass_compute(p0, jp, 0, hw, lane);
+                pass_compute(p1, jp, 1, hw, lane);
+                pass_compute(p2, jp, 2, hw, lane);
+                pass_rest(p0, jp, 3, hw, lane);
                 TC_HPRIO_HIGH();
-                HBAR_W(15, 8);                                                   // c_0
+                HBAR_W(14, 8);                                                   // c_0
                 load_rows(rb, hx, 3);
                 transform_store(ra, hx, 2);
                 HBAR_W(9, 8);                                                    // c_1
@@ -576,19 +587,8 @@ __global__ __launch_bounds__(512, 2) void fused_front_tk_kernel(ArgsK a) {
                     transform_store(ra, hy, 0);
                     load_rows(ra, hy, 2);
                 }
-                pass_issue(p0, jb, 0, hw, lane);
-                pass_issue(p1, jb, 1, hw, lane);
-                pass_issue(p2, jb, 2, hw, lane);
-                fetch(step + 1, more);                                           // head A's entry of the next step: its position, located behind E
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                HBAR(13, 8);                                                     // ---- E: x3 is in buf[s & 1]
-                // everything requested in front of E (the three passes' weights, the next entry's position) has to be here now, and the
-                // compiler must KNOW it: every pass sits under a condition, so without this it waits with vmcnt(0) at the top of each
-                // pass - behind the store of the pass before (stores count in vmcnt on gfx9): four store round trips in a row
-                __builtin_amdgcn_s_waitcnt(0x0F70);                              // vmcnt(0)
-                locate();
-                pass_compute(p0, jb, 0, hw, lane);
-                pass_compute(p1, jb, 1, hw, lane);
+                // head A's pair product of this step's entry (read from its table since the top of the step), in front of the passes'
+                // requests: the wait for it covers nothing younger
                 if (cur.ea < cur.ea_end) {
                     if (va_slow) va = pair_a_slow(quads, a.x1t_tbl, a.weff_a, cur.ea, cur.ua);
                     mp_w[0][cur.ea] = va;
@@ -601,8 +601,24 @@ __global__ __launch_bounds__(512, 2) void fused_front_tk_kernel(ArgsK a) {
                                                                       : a.mpa_tbl[(size_t)e * K9_ROWS + (dirty == 0u ? code : K9_NN)];
                     }
                 }
-                pass_compute(p2, jb, 2, hw, lane);
-                pass_rest(p0, jb, 3, hw, lane);
+                pass_issue(p0, jb, 0, hw, lane);
+                pass_issue(p1, jb, 1, hw, lane);
+                pass_issue(p2, jb, 2, hw, lane);
+                fetch(step + 1, more);                                           // head A's entry of the next step: its position, located behind E
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                HBAR(13, 8);                                                     // ---- E: x3 is in buf[s & 1]
+                // everything requested in front of E (the three passes' weights, the next entry's position) has to be here now, and the
+                // compiler must KNOW it: every pass sits under a condition, so without this it waits with vmcnt(0) at the top of each
+                // pass - behind the store of the pass before (stores count in vmcnt on gfx9): four store round trips in a row
+                __builtin_amdgcn_s_waitcnt(0x0F70);                              // vmcnt(0)
+            }
+            {                                                                    // head B's pair products of the last step
+                const int ls = s_hi - 1;
+                const PairJob jl = {smem + (ls & 1) * BUF_BYTES, a.weff_b, a.pos_sorted[1], mp_w[1], ls * FTT, bkt[STEPST + 1 + ls], bkt[STEPST + 1 + ls + 1]};
+                pass_compute(p0, jl, 0, hw, lane);
+                pass_compute(p1, jl, 1, hw, lane);
+                pass_compute(p2, jl, 2, hw, lane);
+                pass_rest(p0, jl, 3, hw, lane);
             }
         }
     }

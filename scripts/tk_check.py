@@ -72,7 +72,7 @@ if len(sys.argv) > 2:
     import ctypes as C
     names = ["conv3 loop (c0..c7)", "conv3 epilogue", "wait E", "w_v B + pool", "V3 chunk 1 + table pool", "loop top", "prologue / 63", "-",
              "h waiting at the barriers (all)", "h c0 .. c1", "h c1 .. c5", "h c5 .. c6", "h c6 .. c7: x2 rows -> LDS, head A's table read",
-             "h c7 .. E: V3 chunk 0, pair weights", "h E .. top: next entry, head B's pair products, next rows' indices", "h the burst of row requests .. c0"]
+             "h c7 .. E: V3 chunk 0, pair weights", "h pair products of the step before .. c0", "h E .. the burst is out: this entry, next rows' indices, 13 requests"]
     _lib.check(eng.lib.gnn_phase_cycles(eng.ctx, 1, None))
     eng.classify_dev(b.ptr, 4096, s.ptr, "f16x3tk")
     eng.sync()

@@ -375,8 +375,12 @@ def test_kmer_table_helpers_wait_once_behind_E_and_gather_two_rows_per_request()
     _, end = _loop_body_from(src, "for (int step = s_lo; step < s_hi; ++step) {", i)
     helper, _ = _loop_body_from(src, "for (int step = s_lo; step < s_hi; ++step) {", end)
     code = re.sub(r"//[^\n]*", "", helper)
-    m = re.search(r"HBAR\(13, 8\);\s*__builtin_amdgcn_s_waitcnt\(0x0F70\);\s*locate\(\);\s*pass_compute\(p0", code)
+    # the loop is rotated: E and the wait are the LAST statements of an iteration, the next one starts with the located entry, the burst of
+    # row requests (requested and stored inside one iteration) and only then the pair products of the step before
+    m = re.search(r"HBAR\(13, 8\);\s*__builtin_amdgcn_s_waitcnt\(0x0F70\);\s*\}\s*$", code)
     assert m, "the helpers' one wait behind E (vmcnt(0), lgkmcnt / expcnt untouched: 0x0F70) is gone or moved"
+    order = [code.index(t) for t in ("locate();", "x2_rows_issue<0, X2_PER_WAVE>", "pass_compute(p0, jp", "HBAR_W(14, 8)", "x2_rows_store(xr", "pass_issue(p0, jb", "HBAR(13, 8)")]
+    assert order == sorted(order), order
     assert 'asm volatile("s_waitcnt vmcnt' not in helper                     # an inline-asm wait is invisible to the compiler's pass
     assert re.search(r"struct X2Rows \{\s*u32x4 v\[X2_PER_WAVE / 2\];", src)
     assert re.search(r"struct WvaRows \{\s*u32x4 v\[WVA_ROWS_PER_WAVE / 2\];", hdr)
