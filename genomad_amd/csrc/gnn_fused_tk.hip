@@ -489,9 +489,9 @@ __global__ __launch_bounds__(512, 2) void fused_front_tk_kernel(ArgsK a) {
             struct StepA {
                 int ea, ea_end, ua;
             };
-            StepA cur, nxt;               // this step; the next one (position requested behind c_7, located behind E)
+            StepA cur, nxt;               // this step; the next one (position requested behind c_7, located at the top of its own iteration: behind E)
             cur.ea = cur.ea_end = cur.ua = 0;
-            float va = 0.f;               // MpaTable value of cur's entry (requested at the top of the step, behind the x2 rows)
+            float va = 0.f;               // MpaTable value of cur's entry (requested at the top of the iteration, behind the x2 rows; stored behind c_7)
             bool va_slow = false, nxt_slow = false;
             const float* nxt_ptr = a.mpa_tbl;
             auto fetch = [&](int st, bool valid) {               // nxt = entry and position of step st (valid: st < s_hi); entry ranges from LDS
@@ -500,7 +500,7 @@ __global__ __launch_bounds__(512, 2) void fused_front_tk_kernel(ArgsK a) {
                 nxt.ua = nxt.ea < nxt.ea_end ? a.pos_sorted[0][nxt.ea] : 0;
             };
             // nxt -> where head A's pair product of that entry sits in MpaTable.  This CONSUMES the position: the compiler waits for it
-            // with vmcnt(0) (a load under a condition), so it happens where nothing long is pending - behind E, in front of the pair products
+            // with vmcnt(0) (a load under a condition), so it happens where nothing is pending - first thing behind E and its explicit wait
             auto locate = [&]() {
                 nxt_slow = false;
                 uint32_t code = 0, dirty = 0;
